@@ -1,0 +1,108 @@
+/*
+ * patolette_amd.h -- additive C-ABI extensions of libpatolette_amd.so (not in the reference).
+ *
+ * The reference exports one monolithic call (include/patolette.h).  The entry points below
+ * expose (1) the same call with inputs already resident in HBM, (2) each stage of the path on
+ * its own -- every one names the reference function it replaces -- so parity tests can check
+ * the HIP path stage by stage against the oracle, (3) a batch call for independent images,
+ * and (4) kernel timing / run statistics for bench.py.  Plain pointers and sizes only.
+ */
+#ifndef PATOLETTE_AMD_H
+#define PATOLETTE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "patolette.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- device management ------------------------------------------------------------------ */
+int  patolette_amd_device_count(void);                 /* 0 if no usable HIP device */
+int  patolette_amd_set_device(int ordinal);            /* 0 ok */
+const char *patolette_amd_last_error(void);            /* message of the last failure on this thread */
+void *patolette_amd_malloc(size_t bytes);              /* hipMalloc; NULL on failure */
+void patolette_amd_free(void *dptr);
+int  patolette_amd_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int  patolette_amd_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int  patolette_amd_synchronize(void);
+/* synthetic inputs generated directly in HBM: planar image of n pixels,
+ * plane p pixel i = u(1000*seed + p, i); weights = 1 + 3*u(1000*seed + 7, i) */
+int  patolette_amd_fill_image(double *d_planar, size_t n, uint64_t seed);
+int  patolette_amd_fill_weights(double *d_weights, size_t n, uint64_t seed);
+
+/* ---- the full path with HBM-resident inputs/outputs --------------------------------------
+ * Same semantics as patolette() (lib/src/patolette.c:157-343) except that d_data / d_weights
+ * are device pointers and the index map is left in HBM at d_palette_map with elements of
+ * map_elem_bytes (1 when palette_size <= 256, else 4; 8 always allowed).  `palette` is host
+ * memory, (palette_size,3) column-major. */
+void patolette_amd_device(size_t width, size_t height, const double *d_data, const double *d_weights,
+                          size_t palette_size, const patolette__QuantizationOptions *options,
+                          double *palette, void *d_palette_map, int map_elem_bytes, int *exit_code);
+
+/* ---- batch of independent images (SURVEY.md 8(b) "Batch extension") -----------------------
+ * count images of identical width x height; data[i] / weights[i] (weights may be NULL or hold
+ * NULL entries) / palettes[i] / palette_maps[i] / exit_codes[i] as for patolette(); device
+ * selects the GPU.  Results are identical to count separate patolette() calls. */
+void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data,
+                         const double *const *weights, size_t palette_size,
+                         const patolette__QuantizationOptions *options, double *const *palettes,
+                         size_t *const *palette_maps, int *exit_codes);
+
+/* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
+enum {
+    PAMD_SRGB_TO_ICTCP = 0,     /* patolette__COLOR_sRGB_Matrix_to_ICtCp_Matrix            color/ICtCp.c:120-146 */
+    PAMD_SRGB_TO_CIELUV = 1,    /* patolette__COLOR_sRGB_Matrix_to_CIELuv_Matrix           color/CIELuv.c:166-197 */
+    PAMD_ICTCP_TO_REC2020 = 2,  /* patolette__COLOR_ICtCp_Matrix_to_Linear_Rec2020_Matrix  color/rec2020.c:128-148 */
+    PAMD_CIELUV_TO_REC2020 = 3, /* patolette__COLOR_CIELuv_Matrix_to_Linear_Rec2020_Matrix color/rec2020.c:150-173 */
+    PAMD_SRGB_TO_REC2020 = 4,   /* patolette__COLOR_sRGB_Matrix_to_Linear_Rec2020_Matrix   color/rec2020.c:175-195 */
+    PAMD_REC2020_TO_SRGB = 5,   /* patolette__COLOR_Linear_Rec2020_Matrix_to_sRGB_Matrix   color/sRGB.c:112-132 */
+    PAMD_CIELUV_TO_ICTCP = 6    /* the Luv->Rec2020->sRGB->ICtCp chain of patolette.c:305-314, fused per pixel */
+};
+/* in place on a planar (n,3) host matrix */
+int patolette_amd_convert(int which, double *planar, size_t n);
+
+/* patolette__GQ_quantize + patolette__LQ_quantize + patolette__PALETTE_create
+ * (quantize/global.c:388-443, quantize/local.c:318-404, palette/create.c:11-33).
+ * colors planar (n,3) already in the quantisation space; centers planar (K,3) out (first
+ * *n_clusters rows valid, palette order).  Returns 0 or -1. */
+int patolette_amd_quantize_clusters(const double *colors, const double *weights, size_t n, size_t K,
+                                    double *centers, size_t *n_clusters);
+
+/* patolette__PALETTE_get_refined_palette (palette/refine.c:165-221 -> patched faiss
+ * kmeans_clustering).  centers_io planar (k,3) f64. */
+int patolette_amd_kmeans_refine(const double *colors, const double *weights, size_t n,
+                                double *centers_io, size_t k, int niter, size_t max_samples);
+
+/* patolette__PALETTE_fill_palette_map_nearest (palette/nearest.c:150-209) */
+int patolette_amd_nn_map(const double *colors, size_t n, const double *palette, size_t k, size_t *map);
+
+/* patolette__DITHER_riemersma (dither/riemersma.c:437-459); colors/palette in linear Rec2020 */
+int patolette_amd_dither(const double *colors, size_t width, size_t height, const double *palette,
+                         size_t k, size_t *map);
+
+/* ---- statistics of the last full-path call on this thread -------------------------------- */
+typedef struct patolette_amd__Stats {
+    double ms_total, ms_upload, ms_convert, ms_gq, ms_lq, ms_kmeans, ms_map, ms_download;
+    size_t n_base_clusters;   /* clusters produced by the global quantiser */
+    size_t n_clusters;        /* final palette rows */
+    size_t split_evals;       /* split_cluster evaluations performed on the GPU */
+    size_t split_px;          /* sum of their sizes: D_eff = split_px / (width*height) */
+    size_t lq_rounds;         /* host<->device round trips of the split loop */
+    size_t kmeans_samples;    /* samples clustered per KMeans iteration */
+} patolette_amd__Stats;
+void patolette_amd_last_stats(patolette_amd__Stats *out);
+
+/* ---- per-kernel timing with HIP events on the launch stream ------------------------------ */
+void patolette_amd_profile_enable(int on);   /* also resets the accumulated numbers */
+/* number of distinct kernels seen; entry i: name (<= 63 chars), accumulated ms, launch count and the
+ * ALGORITHMIC HBM bytes of those launches (per-unit figures in DESIGN.md) */
+int  patolette_amd_profile_count(void);
+int  patolette_amd_profile_get(int i, char *name64, double *total_ms, size_t *launches, double *total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""patolette_amd -- MI355X-native drop-in for big-nacho/patolette's `patolette.quantize()`.
+
+Mirrors the reference's Python surface (src/patolette/patolette.pyx:324-344, 441-473):
+`quantize(...)` with the same positional/keyword arguments, the same validation messages and
+the same `(success, palette, palette_map, message)` return tuple, plus the `ColorSpace_*`
+constants.  The work behind it runs in hand-written HIP kernels on gfx950 through the C ABI of
+`libpatolette_amd.so` (include/patolette.h); there is no CPU fallback.
+
+Additive (not in the reference): the `weights=` keyword (per-pixel weights, what the
+reference derives internally from its saliency map) and `quantize_batch`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import last_stats, profile, profile_results  # noqa: F401
+
+__version__ = "0.1.0"
+
+# patolette.pyx:324-326
+ColorSpace_sRGB = 0
+ColorSpace_CIELuv = 1
+ColorSpace_ICtCp = 2
+
+# patolette.pyx:328-330
+color_mismatch = "The number of colors doesn't match the supplied width and height."
+bad_channel_count = 'Expected colors to be in sRGB[0, 1] space. Channel count mismatch: {} found.'
+bad_tile_size = 'tile_size parameter expected to be in the range [0, inf]'
+
+_no_saliency = (
+    "patolette_amd: tile_size > 0 asks for the reference's saliency-derived weights "
+    "(patolette.pyx:203-313), which this build does not implement yet. Pass tile_size=0 "
+    "(no weights) or weights=<array of width*height floats >= 1>.")
+
+
+def _dp(a):
+    return a.ctypes.data_as(_native.dp) if a is not None and a.size > 0 else None
+
+
+def quantize(width, height, colors, palette_size, dither=True, palette_only=False,
+             color_space=ColorSpace_ICtCp, tile_size=512, kmeans_niter=32, kmeans_max_samples=512 ** 2,
+             verbose=False, weights=None):
+    """Quantise an image; reference `patolette.quantize` (patolette.pyx:332-466).
+
+    colors: (width*height, 3) float64, sRGB in [0,1], row-scan pixel order.
+    Returns (success, palette (K,3) F-ordered | None, palette_map (N,) uintp | None, message).
+    """
+    colors = np.asarray(colors)
+    if colors.ndim != 2:
+        raise ValueError("Buffer has wrong number of dimensions (expected 2, got %d)" % colors.ndim)
+    color_count, channel_count = colors.shape
+    # validations the reference does before crossing into C (patolette.pyx:351-373)
+    if channel_count != 3:
+        return (False, None, None, bad_channel_count.format(channel_count))
+    if color_count != width * height:
+        return (False, None, None, color_mismatch)
+    if tile_size < 0:
+        return (False, None, None, bad_tile_size)
+
+    w = None
+    if weights is not None:
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
+        if w.size != color_count:
+            raise ValueError("weights must hold width*height values")
+    elif tile_size > 0:
+        raise NotImplementedError(_no_saliency)
+
+    opts = _native.QuantizationOptions(bool(dither), bool(palette_only), int(color_space), int(kmeans_niter),
+                                       int(kmeans_max_samples), bool(verbose))
+    data = np.asfortranarray(colors, dtype=np.float64)           # planar R|G|B copy (patolette.pyx:388-391)
+    palette = np.zeros((palette_size, 3), dtype=np.float64, order='F')
+    palette_map = None
+    if not opts.palette_only:
+        palette_map = np.zeros(width * height, dtype=np.uintp)
+    exit_code = C.c_int(0)
+    L = _native.lib()
+    L.patolette(width, height, _dp(data), _dp(w), palette_size, C.byref(opts), _dp(palette),
+                palette_map.ctypes.data_as(_native.zp) if palette_map is not None and palette_map.size > 0 else None,
+                C.byref(exit_code))
+    success = exit_code.value == 0
+    message = L.get_patolette_exit_code_info_message(exit_code.value).decode('UTF-8')
+    if not success:
+        return (success, None, None, message)
+    if opts.palette_only:
+        return (success, palette, None, message)
+    return (success, palette, palette_map, message)
+
+
+def quantize_batch(width, height, images, palette_size, weights=None, **kwargs):
+    """Quantise a list of independent images of identical size on the current GPU.
+
+    Per-image results are identical to separate `quantize` calls (batch
+    extension).  `weights` is None or a list with one entry (array or None) per image.
+    Returns a list of `quantize` tuples.
+    """
+    kwargs.setdefault("tile_size", 0)
+    out = []
+    for i, img in enumerate(images):
+        w = None if weights is None else weights[i]
+        out.append(quantize(width, height, img, palette_size, weights=w, **kwargs))
+    return out
+
+
+__all__ = [
+    "__doc__",
+    "__version__",
+    "quantize",
+    "quantize_batch",
+    "ColorSpace_sRGB",
+    "ColorSpace_CIELuv",
+    "ColorSpace_ICtCp",
+]

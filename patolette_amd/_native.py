@@ -1,0 +1,110 @@
+"""ctypes binding of libpatolette_amd.so -- the C-ABI boundary of the MI355X-native path.
+
+There is no CPU fallback: if the shared library (or a HIP device, at call time) is missing,
+everything here raises.  Build the library with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C patolette_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpatolette_amd.so")
+
+dp = C.POINTER(C.c_double)
+zp = C.POINTER(C.c_size_t)
+
+
+class QuantizationOptions(C.Structure):
+    """patolette__QuantizationOptions, reference lib/include/patolette.h:13-20."""
+    _fields_ = [("dither", C.c_bool), ("palette_only", C.c_bool), ("color_space", C.c_int),
+                ("kmeans_niter", C.c_int), ("kmeans_max_samples", C.c_size_t), ("verbose", C.c_bool)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ms_total", "ms_upload", "ms_convert", "ms_gq", "ms_lq",
+                                          "ms_kmeans", "ms_map", "ms_download")] + \
+               [(n, C.c_size_t) for n in ("n_base_clusters", "n_clusters", "split_evals", "split_px",
+                                          "lq_rounds", "kmeans_samples")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/patolette.h and include/patolette_amd.h declare
+SYMBOLS = {
+    # --- include/patolette.h (the reference's ABI)
+    "patolette": (None, [C.c_size_t, C.c_size_t, dp, dp, C.c_size_t, C.POINTER(QuantizationOptions), dp, zp,
+                         C.POINTER(C.c_int)]),
+    "get_patolette_exit_code_info_message": (C.c_char_p, [C.c_int]),
+    "patolette_create_default_options": (C.POINTER(QuantizationOptions), []),
+    # --- include/patolette_amd.h (additive)
+    "patolette_amd_device_count": (C.c_int, []),
+    "patolette_amd_set_device": (C.c_int, [C.c_int]),
+    "patolette_amd_last_error": (C.c_char_p, []),
+    "patolette_amd_malloc": (C.c_void_p, [C.c_size_t]),
+    "patolette_amd_free": (None, [C.c_void_p]),
+    "patolette_amd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "patolette_amd_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "patolette_amd_synchronize": (C.c_int, []),
+    "patolette_amd_fill_image": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
+    "patolette_amd_fill_weights": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
+    "patolette_amd_device": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.POINTER(QuantizationOptions), dp, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "patolette_amd_batch": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(dp), C.POINTER(dp), C.c_size_t,
+                                   C.POINTER(QuantizationOptions), C.POINTER(dp), C.POINTER(zp), C.POINTER(C.c_int)]),
+    "patolette_amd_convert": (C.c_int, [C.c_int, dp, C.c_size_t]),
+    "patolette_amd_quantize_clusters": (C.c_int, [dp, dp, C.c_size_t, C.c_size_t, dp, zp]),
+    "patolette_amd_kmeans_refine": (C.c_int, [dp, dp, C.c_size_t, dp, C.c_size_t, C.c_int, C.c_size_t]),
+    "patolette_amd_nn_map": (C.c_int, [dp, C.c_size_t, dp, C.c_size_t, zp]),
+    "patolette_amd_dither": (C.c_int, [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp]),
+    "patolette_amd_last_stats": (None, [C.POINTER(Stats)]),
+    "patolette_amd_profile_enable": (None, [C.c_int]),
+    "patolette_amd_profile_count": (C.c_int, []),
+    "patolette_amd_profile_get": (C.c_int, [C.c_int, C.c_char_p, dp, zp, dp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpatolette_amd.so (raises if it has not been built) and type its entry points."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "patolette_amd: %s not found -- build it with `make -C patolette_amd/csrc` "
+                "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)          # AttributeError if the library does not export it
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().patolette_amd_last_error().decode("utf-8", "replace")
+
+
+def last_stats():
+    s = Stats()
+    lib().patolette_amd_last_stats(C.byref(s))
+    return s.as_dict()
+
+
+def profile(enable=True):
+    lib().patolette_amd_profile_enable(1 if enable else 0)
+
+
+def profile_results():
+    L = lib()
+    out = {}
+    for i in range(L.patolette_amd_profile_count()):
+        name = C.create_string_buffer(64)
+        ms = C.c_double(0)
+        n = C.c_size_t(0)
+        by = C.c_double(0)
+        if L.patolette_amd_profile_get(i, name, C.byref(ms), C.byref(n), C.byref(by)) == 0:
+            out[name.value.decode()] = {"total_ms": ms.value, "launches": n.value, "bytes": by.value}
+    return out

@@ -1,0 +1,111 @@
+// color.hip -- per-pixel colour conversions on planar (N,3) f64 matrices (gfx950).
+//
+// Replaces lib/src/color/{ICtCp,CIELuv,rec2020,sRGB,xyz,eotf}.c of the reference.  The
+// reference walks the matrix once per hop (sRGB->XYZ->Rec2020->ICtCp is one fused loop, but
+// the CIELuv no-dither path is three full sweeps, patolette.c:305-314); here every chain is
+// one kernel: 3 coalesced 8-byte loads per pixel, the whole chain in registers, 3 stores.
+// Arithmetic follows the reference expression by expression in f64 with contraction off;
+// only pow() differs (ocml vs glibc, last-ulp).  Bound: 48 B/px of HBM traffic; ~9 f64 pow
+// per pixel make the ICtCp chain VALU-heavy, still under the HBM time at 16 B/lane loads.
+#include "color_device.h"
+#include "common.h"
+#include "devutil.h"
+
+namespace pamd {
+
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_convert(const double *__restrict__ src, double *__restrict__ dst,
+                                                 size_t n, ConvertStats *stats) {
+    // per-plane min / max of the OUTPUT (bounds for the binned accumulators downstream)
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double c[3] = {src[i], src[n + i], src[2 * n + i]};
+        dev_convert<WHICH>(c);
+        dst[i] = c[0]; dst[n + i] = c[1]; dst[2 * n + i] = c[2];
+#pragma unroll
+        for (int p = 0; p < 3; p++) { mn[p] = fmin(mn[p], c[p]); mx[p] = fmax(mx[p], c[p]); }
+    }
+    if (stats) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            double a = mn[p], b = mx[p];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a = fmin(a, __shfl_down(a, o, 64)); b = fmax(b, __shfl_down(b, o, 64)); }
+            if ((threadIdx.x & 63) == 0) {
+                if (a <= b) {   // skip waves that saw no pixel (and NaNs)
+                    atomicMin(&stats->minkey[p], f64_key(a));
+                    atomicMax(&stats->maxkey[p], f64_key(b));
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_weight_stats(const double *__restrict__ w, size_t n, ConvertStats *stats) {
+    double mx = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) mx = fmax(mx, fabs(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&stats->wmaxkey, f64_key(mx));
+}
+
+__global__ void k_init_stats(ConvertStats *s) {
+    if (threadIdx.x == 0) {
+        for (int p = 0; p < 3; p++) { s->minkey[p] = ~0ULL; s->maxkey[p] = 0ULL; }
+        s->wmaxkey = f64_key(0.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_uniform(double *out, size_t n, unsigned long long seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = u01(seed, i);
+}
+__global__ __launch_bounds__(256) void k_fill_weights(double *out, size_t n, unsigned long long seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = 1.0 + 3.0 * u01(seed, i);
+}
+
+static int stream_grid(size_t n) {
+    size_t b = ceil_div(n, 256);
+    if (b > 256 * 16) b = 256 * 16;      // 256 CUs x 16 blocks, grid-stride the rest
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
+    int g = stream_grid(n);
+    KTIME("k_convert", s, 48.0 * n);
+    switch (which) {
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL(k_convert<PAMD_SRGB_TO_ICTCP>, g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL(k_convert<PAMD_SRGB_TO_CIELUV>, g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL(k_convert<PAMD_ICTCP_TO_REC2020>, g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL(k_convert<PAMD_CIELUV_TO_REC2020>, g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL(k_convert<PAMD_SRGB_TO_REC2020>, g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_REC2020_TO_SRGB: hipLaunchKernelGGL(k_convert<PAMD_REC2020_TO_SRGB>, g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_CIELUV_TO_ICTCP: hipLaunchKernelGGL(k_convert<PAMD_CIELUV_TO_ICTCP>, g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_COPY: hipLaunchKernelGGL(k_convert<PAMD_COPY>, g, 256, 0, s, src, dst, n, stats); break;
+        default: throw HipError("patolette_amd: unknown conversion");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_weight_stats(const double *w, size_t n, ConvertStats *stats, hipStream_t s) {
+    KTIME("k_weight_stats", s, 8.0 * n);
+    hipLaunchKernelGGL(k_weight_stats, stream_grid(n), 256, 0, s, w, n, stats);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_fill_image(double *d, size_t n, uint64_t seed, hipStream_t s) {
+    for (int p = 0; p < 3; p++)
+        hipLaunchKernelGGL(k_fill_uniform, stream_grid(n), 256, 0, s, d + (size_t)p * n, n, 1000ULL * seed + (unsigned long long)p);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_fill_weights(double *d, size_t n, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_weights, stream_grid(n), 256, 0, s, d, n, 1000ULL * seed + 7ULL);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace pamd

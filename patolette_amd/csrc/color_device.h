@@ -1,0 +1,139 @@
+// color_device.h -- device-side scalar colour conversions (f64), expression-for-expression the
+// reference's lib/src/color/*.c (cited per function).  Compiled with -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/patolette_amd.h"
+
+namespace pamd {
+
+constexpr int PAMD_COPY = 100;       // internal: no conversion (colour space sRGB)
+
+struct ConvertStats {                // filled by k_convert / k_weight_stats (ordered-key min/max)
+    unsigned long long minkey[3], maxkey[3], wmaxkey;
+};
+
+namespace dc {
+// eotf.c:13-18
+__device__ constexpr double Lp = 10000, m1 = 0.1593017578125, m2 = 78.84375;
+__device__ constexpr double c1 = 0.8359375, c2 = 18.8515625, c3 = 18.6875;
+
+__device__ __forceinline__ double eotf(double v) {                       // eotf.c:29-42
+    double m1d = 1 / m1, m2d = 1 / m2;
+    double V_p = pow(v, m2d);
+    double n = fmax(0.0, V_p - c1);
+    double L = pow((n / (c2 - c3 * V_p)), m1d);
+    return Lp * L;
+}
+__device__ __forceinline__ double eotf_inv(double v) {                   // eotf.c:44-57
+    double y_ = pow(v / Lp, m1);
+    return pow((c1 + c2 * y_) / (1 + c3 * y_), m2);
+}
+__device__ __forceinline__ double gamma_decode(double c) {               // sRGB.c:70-89
+    double r = (c <= 0.0404500) ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4);
+    return fmin(fmax(r, 0.0), 1.0);
+}
+__device__ __forceinline__ double gamma_encode(double c) {               // sRGB.c:91-110
+    double r = (c <= 0.0031308) ? c * 12.92 : 1.055 * pow(c, 1.0 / 2.4) - 0.055;
+    return fmin(fmax(r, 0.0), 1.0);
+}
+__device__ __forceinline__ void srgb_to_xyz(const double c[3], double &x, double &y, double &z) {   // xyz.c:14-40
+    double R = gamma_decode(c[0]), G = gamma_decode(c[1]), B = gamma_decode(c[2]);
+    x = R * 0.4124564 + G * 0.3575761 + B * 0.1804375;
+    y = R * 0.2126729 + G * 0.7151522 + B * 0.0721750;
+    z = R * 0.0193339 + G * 0.1191920 + B * 0.9503041;
+}
+__device__ __forceinline__ void xyz_to_rec2020(double x, double y, double z, double o[3]) {          // rec2020.c:80-102
+    o[0] = x * 1.71666343 + y * -0.35567332 + z * -0.25336809;
+    o[1] = x * -0.66667384 + y * 1.61645574 + z * 0.0157683;
+    o[2] = x * 0.01764248 + y * -0.04277698 + z * 0.94224328;
+}
+__device__ __forceinline__ void srgb_to_rec2020(double c[3]) {          // rec2020.c:104-126
+    double x, y, z;
+    srgb_to_xyz(c, x, y, z);
+    xyz_to_rec2020(x, y, z, c);
+}
+__device__ __forceinline__ void rec2020_to_ictcp(double c[3]) {         // ICtCp.c:41-79 (Ct halved)
+    double r = c[0], g = c[1], b = c[2];
+    double L = (r * 1688 + g * 2146 + b * 262) / 4096;
+    double M = (r * 683 + g * 2951 + b * 462) / 4096;
+    double S = (r * 99 + g * 309 + b * 3688) / 4096;
+    double L_ = eotf_inv(L), M_ = eotf_inv(M), S_ = eotf_inv(S);
+    c[0] = L_ * 0.5 + M_ * 0.5;
+    c[1] = (L_ * 6610 - M_ * 13613 + S_ * 7003) / 4096;
+    c[2] = (L_ * 17933 - M_ * 17390 - S_ * 543) / 4096;
+    c[1] *= 0.5;
+}
+__device__ __forceinline__ void ictcp_to_rec2020(double c[3]) {         // rec2020.c:32-69 (Ct doubled)
+    double I = c[0], Ct = c[1] * 2, Cp = c[2];
+    double L_ = I + 0.00860904 * Ct + 0.11102963 * Cp;
+    double M_ = I - 0.00860904 * Ct - 0.11102963 * Cp;
+    double S_ = I + 0.56003134 * Ct - 0.32062717 * Cp;
+    double L = eotf(L_), M = eotf(M_), S = eotf(S_);
+    c[0] = L * 3.43660669 - M * 2.50645212 + S * 0.06984542;
+    c[1] = -L * 0.79132956 + M * 1.98360045 - S * 0.1922709;
+    c[2] = -L * 0.0259499 - M * 0.09891371 + S * 1.12486361;
+}
+// CIELuv.c:19-25
+__device__ constexpr double rwx = 0.95047, rwy = 1.0, rwz = 1.08883;
+__device__ constexpr double kE = 216.0 / 24389.0, kK = 24389.0 / 27.0, kKE = 8.0;
+
+__device__ __forceinline__ void srgb_to_cieluv(double c[3]) {           // CIELuv.c:166-197 + :54-89
+    double r = gamma_decode(c[0]), g = gamma_decode(c[1]), b = gamma_decode(c[2]);
+    double x = r * 0.4124564 + g * 0.3575761 + b * 0.1804375;
+    double y = r * 0.2126729 + g * 0.7151522 + b * 0.0721750;
+    double z = r * 0.0193339 + g * 0.1191920 + b * 0.9503041;
+    double den = x + 15.0 * y + 3.0 * z;
+    double up = (den > 0.0) ? ((4.0 * x) / (x + 15.0 * y + 3.0 * z)) : 0.0;
+    double vp = (den > 0.0) ? ((9.0 * y) / (x + 15.0 * y + 3.0 * z)) : 0.0;
+    double urp = (4.0 * rwx) / (rwx + 15.0 * rwy + 3.0 * rwz);
+    double vrp = (9.0 * rwy) / (rwx + 15.0 * rwy + 3.0 * rwz);
+    double yr = y / rwy;
+    double L_ = (yr > kE) ? (116.0 * pow(yr, 1.0 / 3.0) - 16.0) : (kK * yr);
+    c[0] = L_;
+    c[1] = 13.0 * L_ * (up - urp);
+    c[2] = 13.0 * L_ * (vp - vrp);
+}
+__device__ __forceinline__ void cieluv_to_rec2020(double c[3]) {        // CIELuv.c:100-164 + rec2020.c:150-173
+    double L = c[0], u = c[1], v = c[2];
+    double y_ = (L > kKE) ? pow((L + 16.0) / 116.0, 3.0) : (L / kK);
+    double u0 = (4.0 * rwx) / (rwx + 15.0 * rwy + 3.0 * rwz);
+    double v0 = (9.0 * rwy) / (rwx + 15.0 * rwy + 3.0 * rwz);
+    double a, a_den = u + 13.0 * L * u0;
+    if (a_den == 0.0) a = 0; else a = (((52.0 * L) / a_den) - 1.0) / 3.0;
+    double b = -5.0 * y_;
+    double cc = -1.0 / 3.0;
+    double d, d_den = v + 13.0 * L * v0;
+    if (d_den == 0.0) d = 0; else d = y_ * (((39.0 * L) / d_den) - 5.0);
+    double x_, x_den = a - cc;
+    if (x_den == 0.0) x_ = 0; else x_ = (d - b) / x_den;
+    double z_ = x_ * a + b;
+    xyz_to_rec2020(x_, y_, z_, c);
+}
+__device__ __forceinline__ void rec2020_to_srgb(double c[3]) {          // sRGB.c:32-59 + xyz.c:42-64
+    double r2 = c[0], g2 = c[1], b2 = c[2];
+    double x = r2 * 0.63695351 + g2 * 0.14461919 + b2 * 0.16885585;
+    double y = r2 * 0.26269834 + g2 * 0.67800877 + b2 * 0.0592929;
+    double z = g2 * 0.02807314 + b2 * 1.06082723;
+    double r = x * 3.2404542 - y * 1.5371385 - z * 0.4985314;
+    double g = -x * 0.9692660 + y * 1.8760108 + z * 0.0415560;
+    double b = x * 0.0556434 - y * 0.2040259 + z * 1.0572252;
+    c[0] = gamma_encode(r); c[1] = gamma_encode(g); c[2] = gamma_encode(b);
+}
+}  // namespace dc
+
+template <int WHICH>
+__device__ __forceinline__ void dev_convert(double c[3]) {
+    if constexpr (WHICH == PAMD_SRGB_TO_ICTCP) { dc::srgb_to_rec2020(c); dc::rec2020_to_ictcp(c); }
+    else if constexpr (WHICH == PAMD_SRGB_TO_CIELUV) { dc::srgb_to_cieluv(c); }
+    else if constexpr (WHICH == PAMD_ICTCP_TO_REC2020) { dc::ictcp_to_rec2020(c); }
+    else if constexpr (WHICH == PAMD_CIELUV_TO_REC2020) { dc::cieluv_to_rec2020(c); }
+    else if constexpr (WHICH == PAMD_SRGB_TO_REC2020) { dc::srgb_to_rec2020(c); }
+    else if constexpr (WHICH == PAMD_REC2020_TO_SRGB) { dc::rec2020_to_srgb(c); }
+    else if constexpr (WHICH == PAMD_CIELUV_TO_ICTCP) {                 // patolette.c:305-314 fused
+        dc::cieluv_to_rec2020(c); dc::rec2020_to_srgb(c); dc::srgb_to_rec2020(c); dc::rec2020_to_ictcp(c);
+    }
+}
+
+}  // namespace pamd

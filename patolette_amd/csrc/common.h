@@ -1,0 +1,108 @@
+// common.h -- shared declarations of the MI355X-native patolette pipeline (product code).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/patolette.h"
+#include "../../include/patolette_amd.h"
+
+namespace pamd {
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            char _buf[512];                                                                     \
+            snprintf(_buf, sizeof _buf, "patolette_amd: HIP error %s at %s:%d (%s)",            \
+                     hipGetErrorString(_e), __FILE__, __LINE__, #expr);                         \
+            throw pamd::HipError(_buf);                                                         \
+        }                                                                                       \
+    } while (0)
+
+constexpr int kBuckets = 512;        // reference: quantize/global.c:22, local.c:15
+constexpr double kDelta = 1e-16;     // reference: math/misc.h:5
+
+// ---- kernel timing (HIP events on the launch stream), enabled by patolette_amd_profile_enable ----
+struct KernelTimer {
+    struct Rec { hipEvent_t a, b; int id; double bytes; };
+    bool enabled = false;
+    std::vector<std::string> names;
+    std::vector<double> total_ms, total_bytes;
+    std::vector<size_t> launches;
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    int id_of(const char *name);
+    hipEvent_t get_event();
+    void begin(int id, hipStream_t s, double bytes);
+    void end(hipStream_t s);
+    void collect();          // call after the stream is synchronised
+    void reset();
+};
+KernelTimer &ktimer();
+
+struct ScopedKernel {
+    bool on;
+    hipStream_t s;
+    ScopedKernel(const char *name, hipStream_t stream, double bytes) : on(ktimer().enabled), s(stream) {
+        if (on) ktimer().begin(ktimer().id_of(name), s, bytes);
+    }
+    ~ScopedKernel() { if (on) ktimer().end(s); }
+};
+#define PAMD_CAT2(a, b) a##b
+#define PAMD_CAT(a, b) PAMD_CAT2(a, b)
+// bytes = ALGORITHMIC HBM bytes of the launch (DESIGN.md lists the per-unit figures)
+#define KTIME(name, stream, bytes) pamd::ScopedKernel PAMD_CAT(_ktime_scope_, __LINE__)(name, stream, (double)(bytes))
+
+// ---- simple device buffer with capacity reuse ----
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        HIP_CHECK(hipMalloc((void **)&p, n * sizeof(T)));
+        cap = n;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// pinned host staging buffer
+template <typename T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        HIP_CHECK(hipHostMalloc((void **)&p, n * sizeof(T), hipHostMallocDefault));
+        cap = n;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+};
+
+inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+}  // namespace pamd

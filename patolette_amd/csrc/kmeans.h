@@ -1,0 +1,29 @@
+// kmeans.h -- KMeans refinement workspace + launchers (kmeans.hip).
+#pragma once
+
+#include "common.h"
+#include "devutil.h"
+
+namespace pamd {
+
+constexpr int kKMeansMaxK = 4096;      // per-wavefront LDS counters in the stable sort: 4 waves x K x 4 B
+
+struct KmSamples { float *x, *y, *z, *w; };
+
+struct KMeansWork {
+    DevBuf<float> sx, sy, sz, sw;      // samples, f32 SoA
+    DevBuf<int> assign;
+    DevBuf<float4> sorted;             // samples grouped by centroid, sample order kept
+    DevBuf<unsigned int> table, rowtot;
+    DevBuf<unsigned long long> rowbase;
+    DevBuf<float> cent, hassign;       // interleaved xyz centroids (faiss layout)
+    DevBuf<float4> c4;                 // (y0,y1,y2,|y|^2)
+    DevBuf<int> perm;                  // subsample indices
+    DevBuf<struct DevMT> mt;
+    void reserve(size_t nx, int k);
+};
+
+void kmeans_gather(const double *d_planar, size_t N, bool weighted, const int *d_perm, size_t nx, KMeansWork &w, hipStream_t s);
+void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s);
+
+}  // namespace pamd

@@ -1,0 +1,15 @@
+// map.h -- launchers of the palette-mapping kernels (map.hip).
+#pragma once
+
+#include "common.h"
+
+namespace pamd {
+
+// colours: planar, plane p at d_colors + p*plane_stride, n pixels mapped; palette planar (k,3);
+// output elements of elem_bytes (1, 4 or 8)
+void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k,
+                   void *d_out, int elem_bytes, hipStream_t s);
+void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
+                   void *d_out, int elem_bytes, hipStream_t s);
+
+}  // namespace pamd

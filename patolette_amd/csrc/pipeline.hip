@@ -1,0 +1,855 @@
+// pipeline.hip -- host orchestration of the MI355X-native patolette path and its C ABI.
+//
+// Stage sequencing follows lib/src/patolette.c:157-343 (convert -> GQ -> LQ -> [KMeans] ->
+// NN map | dither -> palette back-conversion and write-out); everything O(N) runs in the HIP
+// kernels of color.hip / quant.hip / kmeans.hip / map.hip on one stream.  The host keeps only
+// the O(K) control work the reference also does serially: 3x3 eigen-solves, the 512-bucket DP
+// of the global quantiser, and the greedy split selection (local.c:347-390) replayed over the
+// candidate tree the GPU evaluates in rounds.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <memory>
+
+#include "color_device.h"
+#include "common.h"
+#include "host_math.h"
+#include "kmeans.h"
+#include "map.h"
+#include "quant.h"
+
+namespace pamd {
+
+// launchers defined in color.hip
+void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s);
+void launch_weight_stats(const double *w, size_t n, ConvertStats *stats, hipStream_t s);
+void launch_fill_image(double *d, size_t n, uint64_t seed, hipStream_t s);
+void launch_fill_weights(double *d, size_t n, uint64_t seed, hipStream_t s);
+
+// --------------------------------------------------------------------------------------------
+// kernel timer
+// --------------------------------------------------------------------------------------------
+// (never destroyed: HIP objects must not be released after the runtime has shut down)
+KernelTimer &ktimer() { static thread_local KernelTimer *t = new KernelTimer; return *t; }
+int KernelTimer::id_of(const char *name) {
+    for (size_t i = 0; i < names.size(); i++) if (names[i] == name) return (int)i;
+    names.emplace_back(name); total_ms.push_back(0); total_bytes.push_back(0); launches.push_back(0);
+    return (int)names.size() - 1;
+}
+hipEvent_t KernelTimer::get_event() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
+}
+void KernelTimer::begin(int id, hipStream_t s, double bytes) {
+    Rec r; r.id = id; r.bytes = bytes; r.a = get_event(); r.b = get_event();
+    HIP_CHECK(hipEventRecord(r.a, s));
+    pending.push_back(r);
+}
+void KernelTimer::end(hipStream_t s) { HIP_CHECK(hipEventRecord(pending.back().b, s)); }
+void KernelTimer::collect() {
+    for (auto &r : pending) {
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            total_ms[r.id] += ms; total_bytes[r.id] += r.bytes; launches[r.id] += 1;
+        }
+        pool.push_back(r.a); pool.push_back(r.b);
+    }
+    pending.clear();
+}
+void KernelTimer::reset() { collect(); names.clear(); total_ms.clear(); total_bytes.clear(); launches.clear(); }
+
+// --------------------------------------------------------------------------------------------
+// node table scatter / gather (host mirror <-> device table) in one copy + one tiny kernel
+// --------------------------------------------------------------------------------------------
+__global__ void k_put_nodes(NodeDev *table, const NodeDev *stage, const int *ids, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) table[ids[i]] = stage[i];
+}
+__global__ void k_get_nodes(const NodeDev *table, NodeDev *stage, const int *ids, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stage[i] = table[ids[i]];
+}
+
+struct Bounds { double cmax, range, wmax; int e_lin, e_quad; };
+
+static int exp_bound(double v) {                 // smallest E with 2^E > v (v > 0)
+    if (!(v > 0) || !std::isfinite(v)) return 1;
+    return std::ilogb(v) + 1;
+}
+
+// --------------------------------------------------------------------------------------------
+struct Engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    DevBuf<double> src, wsrc, cvt, bufA, bufB, aux;
+    DevBuf<unsigned short> bkt;
+    DevBuf<NodeDev> nodes, stage;
+    DevBuf<int> ids, round_nodes, node_tile0;
+    DevBuf<Tile> tilesA, tilesP;
+    DevBuf<double> hist, sum6, dpal;
+    DevBuf<unsigned long long> hsize, tileoff;
+    DevBuf<unsigned int> hcount, tilecnt;
+    DevBuf<unsigned char> lut, dmap;
+    DevBuf<ConvertStats> cstats;
+    PinBuf<NodeDev> h_stage;
+    PinBuf<int> h_ids;
+    PinBuf<Tile> h_tiles;
+    PinBuf<double> h_dbl;
+    PinBuf<unsigned char> h_bytes;
+    KMeansWork km;
+    patolette_amd__Stats stats{};
+    std::string last_error;
+
+    void init() {
+        if (stream) return;
+        int cnt = 0;
+        if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+            throw HipError("patolette_amd: no HIP device available (this library has no CPU fallback)");
+        if (device < 0) { HIP_CHECK(hipGetDevice(&device)); }
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
+    void sync() { HIP_CHECK(hipStreamSynchronize(stream)); if (ktimer().enabled) ktimer().collect(); }
+};
+
+static Engine &engine() { static thread_local Engine *e = new Engine; return *e; }
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// host mirror of one tree node
+struct HNode {
+    unsigned long long begin = 0, n = 0;
+    int buf = 0;
+    double sw = 0, mean[3] = {0, 0, 0}, cov6[6] = {0, 0, 0, 0, 0, 0}, dist = 0;
+    int left = -1, right = -1;
+    bool split_done = false, nosplit = false;
+};
+
+static void build_tiles(const std::vector<int> &round, const std::vector<HNode> &hn, int tile, std::vector<Tile> &out,
+                        std::vector<int> *tile0) {
+    out.clear();
+    if (tile0) tile0->clear();
+    for (size_t r = 0; r < round.size(); r++) {
+        const HNode &nd = hn[round[r]];
+        if (tile0) tile0->push_back((int)out.size());
+        for (unsigned long long o = 0; o < nd.n; o += (unsigned long long)tile) {
+            Tile t;
+            t.start = nd.begin + o;
+            t.count = (unsigned)std::min<unsigned long long>((unsigned long long)tile, nd.n - o);
+            t.node = (unsigned)round[r];
+            out.push_back(t);
+        }
+    }
+    if (tile0) tile0->push_back((int)out.size());
+}
+
+static NodeDev make_nodedev(const HNode &h, const Bounds &b) {
+    NodeDev d;
+    std::memset(&d, 0, sizeof d);
+    d.begin = h.begin; d.n = h.n; d.buf = h.buf; d.slot = -1; d.child0 = -1; d.nchild = 0;
+    for (int j = 0; j < 3; j++) d.mean[j] = h.mean[j];
+    d.sw = h.sw;
+    int P = 1;
+    while ((1ULL << P) < (h.n > 1 ? h.n : 2)) P++;
+    d.klin = make_bink(b.e_lin, P);
+    d.kquad = make_bink(b.e_quad, P);
+    d.minkey = ~0ULL; d.maxkey = 0ULL; d.split = -1;
+    return d;
+}
+
+static void upload_tiles(Engine &E, const std::vector<Tile> &t, DevBuf<Tile> &dst) {
+    if (t.empty()) return;
+    dst.reserve(t.size());
+    E.h_tiles.reserve(t.size());
+    std::memcpy(E.h_tiles.p, t.data(), t.size() * sizeof(Tile));
+    HIP_CHECK(hipMemcpyAsync(dst.p, E.h_tiles.p, t.size() * sizeof(Tile), hipMemcpyHostToDevice, E.stream));
+    HIP_CHECK(hipStreamSynchronize(E.stream));     // h_tiles is reused right away
+}
+
+static void put_nodes(Engine &E, const std::vector<int> &ids, const std::vector<NodeDev> &recs) {
+    const int n = (int)ids.size();
+    if (!n) return;
+    E.stage.reserve(n); E.ids.reserve(n); E.h_stage.reserve(n); E.h_ids.reserve(n);
+    std::memcpy(E.h_stage.p, recs.data(), n * sizeof(NodeDev));
+    std::memcpy(E.h_ids.p, ids.data(), n * sizeof(int));
+    HIP_CHECK(hipMemcpyAsync(E.stage.p, E.h_stage.p, n * sizeof(NodeDev), hipMemcpyHostToDevice, E.stream));
+    HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
+    hipLaunchKernelGGL(k_put_nodes, (n + 255) / 256, 256, 0, E.stream, E.nodes.p, E.stage.p, E.ids.p, n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(E.stream));
+}
+
+static void get_nodes(Engine &E, const std::vector<int> &ids, std::vector<NodeDev> &recs) {
+    const int n = (int)ids.size();
+    recs.resize(n);
+    if (!n) return;
+    E.stage.reserve(n); E.ids.reserve(n); E.h_stage.reserve(n); E.h_ids.reserve(n);
+    std::memcpy(E.h_ids.p, ids.data(), n * sizeof(int));
+    HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
+    hipLaunchKernelGGL(k_get_nodes, (n + 255) / 256, 256, 0, E.stream, E.nodes.p, E.stage.p, E.ids.p, n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(E.h_stage.p, E.stage.p, n * sizeof(NodeDev), hipMemcpyDeviceToHost, E.stream));
+    E.sync();
+    std::memcpy(recs.data(), E.h_stage.p, n * sizeof(NodeDev));
+}
+
+static void absorb_moments(HNode &h, const NodeDev &d) {
+    for (int q = 0; q < 6; q++) h.cov6[q] = d.acc[q][0] + d.acc[q][1];
+    h.dist = d.acc[6][0] + d.acc[6][1];
+}
+
+// principal axis from the node's covariance sums (pca.c:62-101 divides by sum(w), then dsyev)
+static bool node_axis(const HNode &h, double axis[3]) {
+    double c6[6];
+    for (int q = 0; q < 6; q++) c6[q] = h.cov6[q] / h.sw;
+    return hm::principal_axis(c6, axis);
+}
+
+// --------------------------------------------------------------------------------------------
+// GQ + LQ + PALETTE_create on the converted image in E.cvt (planar, stride N, optional w plane)
+// returns centres planar (len,3)
+// --------------------------------------------------------------------------------------------
+static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const Bounds &bnd,
+                             std::vector<double> &centers, size_t &len) {
+    hipStream_t s = E.stream;
+    const size_t planes = weighted ? 4 : 3;
+    E.bufA.reserve(planes * N); E.bufB.reserve(planes * N); E.bkt.reserve(N);
+    const size_t max_nodes = 4 * K + 64;
+    E.nodes.reserve(max_nodes);
+    std::vector<HNode> hn;
+    hn.reserve(max_nodes);
+    double t0 = now_ms();
+
+    // ---------------- global quantiser (global.c:388-443) ----------------
+    // unweighted PCA of all pixels: mean, centred covariance, dsyev
+    HNode root; root.begin = 0; root.n = N; root.buf = 0; root.sw = (double)N;
+    int rootP = 1; while ((1ULL << rootP) < (N > 1 ? N : 2)) rootP++;
+    E.sum6.reserve(6);
+    launch_sum3(E.cvt.p, N, make_bink(bnd.e_lin, rootP), E.sum6.p, s);
+    E.h_dbl.reserve(16 * kBuckets * 2 + 64);
+    HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.sum6.p, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    E.sync();
+    {
+        const double inv = 1 / (double)N;                       // matrix2D.c:229
+        for (int j = 0; j < 3; j++) root.mean[j] = (E.h_dbl.p[2 * j] + E.h_dbl.p[2 * j + 1]) * inv;
+    }
+    hn.push_back(root);                                         // id 0
+    QuantBuffers qroot{{E.cvt.p, E.bufA.p}, E.bkt.p, N, weighted};
+    QuantBuffers qlq{{E.bufB.p, E.bufA.p}, E.bkt.p, N, weighted};
+    std::vector<int> round = {0};
+    std::vector<Tile> tA, tP;
+    std::vector<int> tile0;
+    build_tiles(round, hn, kTileA, tA, nullptr);
+    upload_tiles(E, tA, E.tilesA);
+    {
+        NodeDev d = make_nodedev(hn[0], bnd);
+        put_nodes(E, {0}, {d});
+    }
+    launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
+    std::vector<NodeDev> got;
+    get_nodes(E, {0}, got);
+    absorb_moments(hn[0], got[0]);
+    double axis[3];
+    if (!node_axis(hn[0], axis)) return -1;
+
+    // projection, 512 buckets, cell moments (sort.c, cells.c:53-139)
+    {
+        NodeDev d = make_nodedev(hn[0], bnd);
+        for (int j = 0; j < 3; j++) d.axis[j] = axis[j];
+        d.slot = 0;
+        put_nodes(E, {0}, {d});
+    }
+    const size_t hs = hist_slot_doubles();
+    E.hist.reserve(hs); E.hsize.reserve(kBuckets); E.hcount.reserve(kBuckets); E.lut.reserve(kBuckets);
+    HIP_CHECK(hipMemsetAsync(E.hist.p, 0, hs * sizeof(double), s));
+    HIP_CHECK(hipMemsetAsync(E.hsize.p, 0, kBuckets * sizeof(unsigned long long), s));
+    HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, kBuckets * sizeof(unsigned int), s));
+    launch_minmax(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
+    launch_hist(qroot, true, E.tilesA.p, (int)tA.size(), N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+    std::vector<double> hh(hs);
+    std::vector<unsigned int> hc(kBuckets);
+    HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.hist.p, hs * sizeof(double), hipMemcpyDeviceToHost, s));
+    E.sync();
+    std::memcpy(hh.data(), E.h_dbl.p, hs * sizeof(double));
+    HIP_CHECK(hipMemcpy(hc.data(), E.hcount.p, kBuckets * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    auto H = [&](int q, int b) { return hh[(size_t)(q * 2 + 0) * kBuckets + b] + hh[(size_t)(q * 2 + 1) * kBuckets + b]; };
+
+    auto cm = std::make_unique<hm::CellMoments>();
+    std::memset(cm.get(), 0, sizeof(hm::CellMoments));
+    for (int b = 0; b < kBuckets; b++) {
+        cm->w0[b + 1] = hc[b];
+        for (int r = 0; r < 3; r++) cm->w1[r][b + 1] = H(r, b);
+        cm->w2[b + 1] = H(3, b);
+        for (int q = 0; q < 6; q++) cm->wrs[q][b + 1] = H(4 + q, b);
+    }
+    for (int i = 1; i <= kBuckets; i++) {                       // cells.c:114-136 sequential prefix
+        cm->w0[i] += cm->w0[i - 1]; cm->w2[i] += cm->w2[i - 1];
+        for (int r = 0; r < 3; r++) cm->w1[r][i] += cm->w1[r][i - 1];
+        for (int q = 0; q < 6; q++) cm->wrs[q][i] += cm->wrs[q][i - 1];
+    }
+    std::vector<size_t> cuts = hm::gq_principal_quantizer(K, *cm);
+    if (cuts.size() < 2) return -1;
+    const int kbase = (int)cuts.size() - 1;
+
+    // base clusters: bucket b belongs to the first cell j with b+1 <= q[j+1] (global.c:328-335)
+    std::vector<unsigned char> lut(kBuckets);
+    for (int b = 0; b < kBuckets; b++) {
+        int j = 0;
+        while (j < kbase - 1 && !((size_t)(b + 1) <= cuts[j + 1])) j++;
+        lut[b] = (unsigned char)j;
+    }
+    std::vector<int> base_ids;
+    {
+        unsigned long long pos = 0;
+        for (int j = 0; j < kbase; j++) {
+            HNode c; c.buf = 1; c.begin = pos;
+            unsigned long long cnt = 0;
+            double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};      // exact: parts lie on the bin grids
+            for (int b = 0; b < kBuckets; b++) if (lut[b] == j) {
+                cnt += hc[b];
+                for (int q = 0; q < (weighted ? 4 : 3); q++) {
+                    int qi = weighted ? 10 + q : q;
+                    s0[q] += hh[(size_t)(qi * 2 + 0) * kBuckets + b];
+                    s1[q] += hh[(size_t)(qi * 2 + 1) * kBuckets + b];
+                }
+            }
+            c.n = cnt;
+            c.sw = weighted ? (s0[3] + s1[3]) : (double)cnt;
+            const double inv = 1 / c.sw;
+            for (int q = 0; q < 3; q++) c.mean[q] = (s0[q] + s1[q]) * inv;
+            pos += cnt;
+            base_ids.push_back((int)hn.size());
+            hn.push_back(c);
+        }
+    }
+    {
+        NodeDev d = make_nodedev(hn[0], bnd);
+        for (int j = 0; j < 3; j++) d.axis[j] = axis[j];
+        d.slot = 0; d.child0 = base_ids[0]; d.nchild = kbase;
+        std::vector<int> ids = {0};
+        std::vector<NodeDev> recs = {d};
+        for (int id : base_ids) { ids.push_back(id); NodeDev c = make_nodedev(hn[id], bnd); c.klin = d.klin; c.kquad = d.kquad; recs.push_back(c); }
+        put_nodes(E, ids, recs);
+    }
+    HIP_CHECK(hipMemcpyAsync(E.lut.p, lut.data(), kBuckets, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    build_tiles(round, hn, kTileP, tP, &tile0);
+    upload_tiles(E, tP, E.tilesP);
+    E.round_nodes.reserve(1); E.node_tile0.reserve(2);
+    HIP_CHECK(hipMemcpyAsync(E.round_nodes.p, round.data(), sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(E.node_tile0.p, tile0.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
+    launch_partition(qroot, E.tilesP.p, (int)tP.size(), N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, s);
+    launch_cov_children(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
+    get_nodes(E, base_ids, got);
+    for (size_t i = 0; i < base_ids.size(); i++) absorb_moments(hn[base_ids[i]], got[i]);
+    E.stats.n_base_clusters = (size_t)kbase;
+    E.stats.ms_gq = now_ms() - t0;
+    t0 = now_ms();
+
+    // ---------------- local quantiser (local.c:318-404) ----------------
+    std::vector<int> result(base_ids);                          // frontier in the reference's order
+    size_t count = result.size();
+    E.stats.split_evals = 0; E.stats.split_px = 0; E.stats.lq_rounds = 0;
+    auto known = [&](const HNode &h) { return h.nosplit || h.n <= 1 || h.split_done; };
+    auto benefit = [&](const HNode &h) -> double {
+        if (h.nosplit || h.n <= 1) return 0;                    // children == NULL -> 0 (local.c:262-264)
+        return h.dist - (hn[h.left].dist + hn[h.right].dist);
+    };
+    if (count < K) {
+        result.resize(K, -1);
+        for (;;) {
+            if (count >= K) break;
+            // one greedy step, exact whenever every undecided node is provably not the arg-max
+            int best = -1; double bv = 0; double max_unknown = -1;
+            for (size_t j = 0; j < count; j++) {
+                const HNode &h = hn[result[j]];
+                if (known(h)) {
+                    double b = benefit(h);
+                    if (best < 0 || b > bv) { bv = b; best = (int)j; }
+                } else if (h.dist > max_unknown) max_unknown = h.dist;
+            }
+            // first maximum among ALL entries = first maximum among the known ones iff every unknown
+            // benefit (<= that node's distortion) is strictly below it
+            if (max_unknown < 0 || (best >= 0 && bv > max_unknown)) {
+                if (!(bv >= kDelta)) break;                     // benefit < DELTA: stop, keep `count` clusters
+                const HNode &h = hn[result[best]];
+                const int l = h.left, r = h.right;
+                result[count] = l;                              // local.c:375-376: palette ORDER
+                result[best] = r;
+                count++;
+                continue;
+            }
+            if (std::max(best >= 0 ? bv : 0.0, max_unknown) < kDelta) break;   // nothing can reach DELTA
+            // blocked: evaluate the splits of every undecided frontier node that could matter
+            const double thr = std::max(kDelta, 0.5 * (best >= 0 ? bv : 0.0));
+            round.clear();
+            for (size_t j = 0; j < count; j++) {
+                HNode &h = hn[result[j]];
+                if (!known(h) && h.dist >= thr) round.push_back(result[j]);
+            }
+            if (round.empty()) {                                // cannot happen (max_unknown >= bv >= thr/0.5)
+                for (size_t j = 0; j < count; j++) if (!known(hn[result[j]])) round.push_back(result[j]);
+            }
+            // axes on the host (dsyev semantics), children ids, device records
+            std::vector<int> todo;
+            std::vector<NodeDev> recs;
+            std::vector<int> ids;
+            for (int id : round) {
+                double ax[3];
+                if (!node_axis(hn[id], ax)) { hn[id].nosplit = true; continue; }
+                if (hn.size() + 2 > max_nodes) throw HipError("patolette_amd: node table overflow");
+                NodeDev d = make_nodedev(hn[id], bnd);
+                for (int j = 0; j < 3; j++) d.axis[j] = ax[j];
+                d.slot = (int)todo.size();
+                d.child0 = (int)hn.size(); d.nchild = 2;
+                hn[id].left = (int)hn.size(); hn[id].right = (int)hn.size() + 1;
+                hn.push_back(HNode()); hn.push_back(HNode());
+                todo.push_back(id); ids.push_back(id); recs.push_back(d);
+            }
+            if (todo.empty()) continue;
+            const int nr = (int)todo.size();
+            size_t rpx = 0;
+            for (int id : todo) rpx += hn[id].n;
+            put_nodes(E, ids, recs);
+            build_tiles(todo, hn, kTileA, tA, nullptr);
+            build_tiles(todo, hn, kTileP, tP, &tile0);
+            upload_tiles(E, tA, E.tilesA);
+            upload_tiles(E, tP, E.tilesP);
+            E.round_nodes.reserve(nr); E.node_tile0.reserve(nr + 1);
+            HIP_CHECK(hipMemcpyAsync(E.round_nodes.p, todo.data(), nr * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(E.node_tile0.p, tile0.data(), (nr + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            const size_t lqs = (size_t)kNQ_LQ * 2 * kBuckets;
+            E.hist.reserve(std::max(hs, lqs * nr)); E.hsize.reserve((size_t)nr * kBuckets); E.hcount.reserve((size_t)nr * kBuckets);
+            E.lut.reserve((size_t)nr * kBuckets);
+            E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
+            HIP_CHECK(hipMemsetAsync(E.hist.p, 0, lqs * nr * sizeof(double), s));
+            HIP_CHECK(hipMemsetAsync(E.hsize.p, 0, (size_t)nr * kBuckets * sizeof(unsigned long long), s));
+            HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, (size_t)nr * kBuckets * sizeof(unsigned int), s));
+            launch_minmax(qlq, E.tilesA.p, (int)tA.size(), rpx, E.nodes.p, s);
+            launch_hist(qlq, false, E.tilesA.p, (int)tA.size(), rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+            launch_cut(weighted, E.nodes.p, E.round_nodes.p, nr, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s);
+            launch_partition(qlq, E.tilesP.p, (int)tP.size(), rpx, E.round_nodes.p, E.node_tile0.p, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, s);
+            launch_cov_children(qlq, E.tilesA.p, (int)tA.size(), rpx, E.nodes.p, s);
+            std::vector<int> cids;
+            for (int id : todo) { cids.push_back(hn[id].left); cids.push_back(hn[id].right); }
+            get_nodes(E, cids, got);
+            for (size_t i = 0; i < cids.size(); i++) {
+                HNode &c = hn[cids[i]];
+                const NodeDev &d = got[i];
+                c.begin = d.begin; c.n = d.n; c.buf = d.buf; c.sw = d.sw;
+                for (int j = 0; j < 3; j++) c.mean[j] = d.mean[j];
+                absorb_moments(c, d);
+            }
+            for (int id : todo) { hn[id].split_done = true; E.stats.split_evals++; E.stats.split_px += hn[id].n; }
+            E.stats.lq_rounds++;
+        }
+        result.resize(count);
+    }
+    len = count;
+    centers.assign(3 * len, 0.0);
+    for (size_t i = 0; i < len; i++) for (int j = 0; j < 3; j++) centers[(size_t)j * len + i] = hn[result[i]].mean[j];   // create.c:11-33
+    E.stats.n_clusters = len;
+    E.stats.ms_lq = now_ms() - t0;
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// KMeans refinement (refine.c:165-221); centres planar (k,3) f64 in/out
+// --------------------------------------------------------------------------------------------
+static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double> &centers, size_t k, int niter, size_t max_samples) {
+    hipStream_t s = E.stream;
+    if (k > (size_t)kKMeansMaxK) throw HipError("patolette_amd: KMeans refinement supports at most 4096 palette entries");
+    std::vector<float> cent(3 * k);
+    for (size_t i = 0; i < k; i++) for (int j = 0; j < 3; j++) cent[3 * i + j] = (float)centers[(size_t)j * k + i];   // refine.c:102-125
+    const size_t min_samples = 256 * 256;                                          // refine.c:21
+    const size_t ms = std::max(max_samples, min_samples);
+    const int mppc = (int)(ms / k);                                                // refine.c:87
+    bool ok = N >= k;                                                              // Clustering.cpp:272-278 (throws -> centres unchanged)
+    size_t nx = N;
+    E.stats.kmeans_samples = 0;
+    if (ok) {
+        const bool sub = N > k * (size_t)mppc;                                     // Clustering.cpp:311-319
+        if (sub) nx = k * (size_t)mppc;
+        E.km.reserve(nx, (int)k);
+        const int *dperm = nullptr;
+        if (sub) {
+            std::vector<int32_t> perm(nx);
+            hm::rand_perm_prefix(N, nx, 1234u, perm.data());                       // random.cpp:184-194, seed 1234
+            HIP_CHECK(hipMemcpyAsync(E.km.perm.p, perm.data(), nx * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            dperm = E.km.perm.p;
+        }
+        if (nx == k) {                                                             // Clustering.cpp:331-352: centroids = first k input vectors
+            std::vector<double> first(3 * k);
+            for (int j = 0; j < 3; j++) HIP_CHECK(hipMemcpy(first.data() + (size_t)j * k, E.cvt.p + (size_t)j * N, k * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < k; i++) for (int j = 0; j < 3; j++) cent[3 * i + j] = (float)first[(size_t)j * k + i];
+        } else {
+            kmeans_gather(E.cvt.p, N, weighted, dperm, nx, E.km, s);
+            HIP_CHECK(hipMemcpyAsync(E.km.cent.p, cent.data(), 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            kmeans_iterate(E.km, nx, (int)k, weighted, niter, s);
+            HIP_CHECK(hipMemcpyAsync(cent.data(), E.km.cent.p, 3 * k * sizeof(float), hipMemcpyDeviceToHost, s));
+            E.sync();
+            E.stats.kmeans_samples = nx;
+        }
+    }
+    for (size_t i = 0; i < k; i++) for (int j = 0; j < 3; j++) centers[(size_t)j * k + i] = (double)cent[3 * i + j];   // refine.c:202-212
+}
+
+static void palette_rows(std::vector<double> &pal, size_t len, void (*f)(double[3])) {
+    for (size_t i = 0; i < len; i++) {
+        double c[3] = {pal[i], pal[len + i], pal[2 * len + i]};
+        f(c);
+        pal[i] = c[0]; pal[len + i] = c[1]; pal[2 * len + i] = c[2];
+    }
+}
+
+static Bounds read_bounds(Engine &E, bool weighted) {
+    ConvertStats cs;
+    HIP_CHECK(hipMemcpyAsync(&cs, E.cstats.p, sizeof cs, hipMemcpyDeviceToHost, E.stream));
+    E.sync();
+    Bounds b;
+    b.cmax = 0; b.range = 0;
+    for (int p = 0; p < 3; p++) {
+        double mn = key_f64(cs.minkey[p]), mx = key_f64(cs.maxkey[p]);
+        if (!(mn <= mx)) { mn = 0; mx = 0; }
+        b.cmax = std::max(b.cmax, std::max(std::fabs(mn), std::fabs(mx)));
+        b.range = std::max(b.range, mx - mn);
+    }
+    b.wmax = weighted ? std::max(1.0, key_f64(cs.wmaxkey)) : 1.0;
+    const double lin = b.wmax * std::max(b.cmax, 1.0);
+    const double quad = 3.0 * b.wmax * std::max(std::max(b.range, b.cmax), 1e-300) * std::max(std::max(b.range, b.cmax), 1e-300);
+    b.e_lin = exp_bound(lin);
+    b.e_quad = exp_bound(std::max(quad, 1e-300));
+    return b;
+}
+
+// --------------------------------------------------------------------------------------------
+// the full path, inputs resident in HBM
+// --------------------------------------------------------------------------------------------
+static void run_device(Engine &E, size_t width, size_t height, const double *d_data, const double *d_weights, size_t K,
+                       const patolette__QuantizationOptions *opt, double *palette, void *d_map, int map_elem) {
+    hipStream_t s = E.stream;
+    const size_t N = width * height;
+    const bool weighted = d_weights != nullptr;
+    const double t_start = now_ms();
+    E.stats = patolette_amd__Stats{};
+    // S1: colour conversion into the working image (x|y|z|w planar), patolette.c:201-207
+    double t0 = now_ms();
+    E.cvt.reserve((weighted ? 4 : 3) * N);
+    E.cstats.reserve(1);
+    int which = PAMD_COPY;
+    if (opt->color_space == patolette__CIELuv) which = PAMD_SRGB_TO_CIELUV;
+    else if (opt->color_space == patolette__ICtCp) which = PAMD_SRGB_TO_ICTCP;
+    launch_convert(which, d_data, E.cvt.p, N, E.cstats.p, s);
+    if (weighted) {
+        HIP_CHECK(hipMemcpyAsync(E.cvt.p + 3 * N, d_weights, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        launch_weight_stats(d_weights, N, E.cstats.p, s);
+    }
+    Bounds bnd = read_bounds(E, weighted);
+    E.stats.ms_convert = now_ms() - t0;
+
+    // S2 + S3: global + local quantiser
+    std::vector<double> pal;
+    size_t len = 0;
+    if (quantize_clusters(E, N, K, weighted, bnd, pal, len) != 0) throw HipError("internal quantization error");
+
+    // S4: optional KMeans refinement
+    t0 = now_ms();
+    if (opt->kmeans_niter > 0) kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples);
+    E.stats.ms_kmeans = now_ms() - t0;
+
+    // S5: palette map
+    t0 = now_ms();
+    if (!opt->palette_only) {
+        E.dpal.reserve(3 * len);
+        if (opt->dither) {                                                     // patolette.c:268-299
+            int pix = PAMD_SRGB_TO_REC2020;
+            void (*pf)(double[3]) = hm::color::srgb_to_rec2020;
+            if (opt->color_space == patolette__CIELuv) { pix = PAMD_CIELUV_TO_REC2020; pf = hm::color::cieluv_to_rec2020; }
+            else if (opt->color_space == patolette__ICtCp) { pix = PAMD_ICTCP_TO_REC2020; pf = hm::color::ictcp_to_rec2020; }
+            E.aux.reserve(3 * N);
+            launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);              // plane stride of cvt is N for x,y,z
+            palette_rows(pal, len, pf);
+            HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            launch_dither(E.aux.p, N, width, height, E.dpal.p, (int)len, d_map, map_elem, s);
+            palette_rows(pal, len, hm::color::rec2020_to_srgb);
+        } else {                                                               // patolette.c:300-324
+            const double *pixels = E.cvt.p;
+            if (opt->color_space == patolette__CIELuv) {
+                E.aux.reserve(3 * N);
+                launch_convert(PAMD_CIELUV_TO_ICTCP, E.cvt.p, E.aux.p, N, nullptr, s);
+                pixels = E.aux.p;
+                palette_rows(pal, len, hm::color::cieluv_to_rec2020);
+                palette_rows(pal, len, hm::color::rec2020_to_srgb);
+                palette_rows(pal, len, hm::color::srgb_to_ictcp);
+            }
+            HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            launch_nn_map(pixels, N, N, E.dpal.p, (int)len, d_map, map_elem, s);
+            palette_rows(pal, len, hm::color::ictcp_to_rec2020);
+            palette_rows(pal, len, hm::color::rec2020_to_srgb);
+        }
+        E.sync();
+    }
+    E.stats.ms_map = now_ms() - t0;
+    // S6: palette write-out, unused rows = -1 (patolette.c:327-336)
+    for (size_t j = 0; j < K * 3; j++) palette[j] = -1.0;
+    for (int j = 0; j < 3; j++) for (size_t i = 0; i < len; i++) palette[K * (size_t)j + i] = pal[(size_t)j * len + i];
+    E.stats.ms_total = now_ms() - t_start;
+}
+
+static int validate(size_t width, size_t height, size_t K) {               // patolette.c:61-95
+    const size_t px = width * height;
+    if (px == 0) return -2;
+    if (K < 1) return -3;
+    if (px > (size_t)40000 * 40000) return -4;
+    return 0;
+}
+
+static int map_elem_for(size_t K) { return K <= 256 ? 1 : 4; }
+
+// host-buffer entry: upload, run, download + widen
+static void run_host(Engine &E, size_t width, size_t height, const double *data, const double *weights, size_t K,
+                     const patolette__QuantizationOptions *opt, double *palette, size_t *palette_map) {
+    const size_t N = width * height;
+    double t0 = now_ms();
+    E.src.reserve(3 * N);
+    HIP_CHECK(hipMemcpyAsync(E.src.p, data, 3 * N * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    if (weights) {
+        E.wsrc.reserve(N);
+        HIP_CHECK(hipMemcpyAsync(E.wsrc.p, weights, N * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(E.stream));
+    const double up = now_ms() - t0;
+    const int me = map_elem_for(K);
+    if (!opt->palette_only) E.dmap.reserve(N * (size_t)me);
+    std::vector<double> pal(3 * K);
+    run_device(E, width, height, E.src.p, weights ? E.wsrc.p : nullptr, K, opt, pal.data(), E.dmap.p, me);
+    t0 = now_ms();
+    if (!opt->palette_only) {
+        const bool touched = !(opt->dither && std::max(width, height) <= 1);   // 1x1 dither visits nothing (riemersma.c:452-456)
+        if (touched) {
+            if (me == 1) {
+                std::vector<unsigned char> tmp(N);
+                HIP_CHECK(hipMemcpy(tmp.data(), E.dmap.p, N, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < N; i++) palette_map[i] = (size_t)tmp[i];
+            } else {
+                std::vector<unsigned int> tmp(N);
+                HIP_CHECK(hipMemcpy(tmp.data(), E.dmap.p, N * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < N; i++) palette_map[i] = (size_t)tmp[i];
+            }
+        }
+    }
+    std::memcpy(palette, pal.data(), 3 * K * sizeof(double));
+    E.stats.ms_upload = up;
+    E.stats.ms_download = now_ms() - t0;
+    E.stats.ms_total += up + E.stats.ms_download;
+}
+
+}  // namespace pamd
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+using namespace pamd;
+
+static const char *kMessages[6] = {                                        // patolette.c:32-38
+    "Quantization successful.", "Internal quantization error.", "Image dimensions should be greater than 0.",
+    "Palette size should be greater than 0.", "Image dimensions are too big.", nullptr};
+
+#define PAMD_GUARD_BEGIN try { Engine &E = engine(); E.init(); (void)E;
+#define PAMD_GUARD_END(ret_fail)                                             \
+    } catch (const std::exception &ex) {                                     \
+        engine().last_error = ex.what();                                     \
+        fprintf(stderr, "%s\n", ex.what());                                  \
+        return ret_fail;                                                     \
+    }
+
+extern "C" {
+
+void patolette(size_t width, size_t height, const double *data, const double *weights, size_t palette_size,
+               const patolette__QuantizationOptions *options, double *palette, size_t *palette_map, int *exit_code) {
+    *exit_code = validate(width, height, palette_size);
+    if (*exit_code != 0) return;
+    try {
+        Engine &E = engine();
+        E.init();
+        run_host(E, width, height, data, weights, palette_size, options, palette, palette_map);
+        *exit_code = 0;
+    } catch (const std::exception &ex) {
+        engine().last_error = ex.what();
+        fprintf(stderr, "patolette: %s\n", ex.what());
+        *exit_code = -1;
+    }
+}
+
+const char *get_patolette_exit_code_info_message(int exit_code) { return kMessages[-1 * exit_code]; }
+
+patolette__QuantizationOptions *patolette_create_default_options(void) {   // patolette.c:107-119
+    patolette__QuantizationOptions *o = (patolette__QuantizationOptions *)malloc(sizeof *o);
+    o->dither = true; o->palette_only = false; o->color_space = patolette__ICtCp;
+    o->kmeans_niter = 32; o->kmeans_max_samples = 512 * 512; o->verbose = false;
+    return o;
+}
+
+int patolette_amd_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+int patolette_amd_set_device(int ordinal) {
+    Engine &E = engine();
+    if (E.stream && E.device != ordinal) return -1;      // one engine (stream, buffers) per thread, bound at first use
+    E.device = ordinal;
+    return hipSetDevice(ordinal) == hipSuccess ? 0 : -1;
+}
+const char *patolette_amd_last_error(void) { return engine().last_error.c_str(); }
+void *patolette_amd_malloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; return p; }
+void patolette_amd_free(void *p) { if (p) (void)hipFree(p); }
+int patolette_amd_memcpy_h2d(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+int patolette_amd_memcpy_d2h(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+int patolette_amd_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : -1; }
+int patolette_amd_fill_image(double *d, size_t n, uint64_t seed) {
+    PAMD_GUARD_BEGIN launch_fill_image(d, n, seed, E.stream); E.sync(); return 0; PAMD_GUARD_END(-1)
+}
+int patolette_amd_fill_weights(double *d, size_t n, uint64_t seed) {
+    PAMD_GUARD_BEGIN launch_fill_weights(d, n, seed, E.stream); E.sync(); return 0; PAMD_GUARD_END(-1)
+}
+
+void patolette_amd_device(size_t width, size_t height, const double *d_data, const double *d_weights, size_t palette_size,
+                          const patolette__QuantizationOptions *options, double *palette, void *d_palette_map,
+                          int map_elem_bytes, int *exit_code) {
+    *exit_code = validate(width, height, palette_size);
+    if (*exit_code != 0) return;
+    try {
+        Engine &E = engine();
+        E.init();
+        std::vector<double> pal(3 * palette_size);
+        run_device(E, width, height, d_data, d_weights, palette_size, options, pal.data(), d_palette_map, map_elem_bytes);
+        std::memcpy(palette, pal.data(), 3 * palette_size * sizeof(double));
+        *exit_code = 0;
+    } catch (const std::exception &ex) {
+        engine().last_error = ex.what();
+        fprintf(stderr, "patolette: %s\n", ex.what());
+        *exit_code = -1;
+    }
+}
+
+void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
+                         size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
+                         size_t *const *palette_maps, int *exit_codes) {
+    for (size_t i = 0; i < count; i++)
+        patolette(width, height, data[i], weights ? weights[i] : nullptr, palette_size, options, palettes[i],
+                  palette_maps ? palette_maps[i] : nullptr, &exit_codes[i]);
+}
+
+int patolette_amd_convert(int which, double *planar, size_t n) {
+    PAMD_GUARD_BEGIN
+    if (n == 0) return 0;
+    E.src.reserve(3 * n); E.aux.reserve(3 * n);
+    HIP_CHECK(hipMemcpy(E.src.p, planar, 3 * n * sizeof(double), hipMemcpyHostToDevice));
+    launch_convert(which, E.src.p, E.aux.p, n, nullptr, E.stream);
+    E.sync();
+    HIP_CHECK(hipMemcpy(planar, E.aux.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+    PAMD_GUARD_END(-1)
+}
+
+int patolette_amd_quantize_clusters(const double *colors, const double *weights, size_t n, size_t K, double *centers, size_t *n_clusters) {
+    PAMD_GUARD_BEGIN
+    if (n == 0 || K == 0) return -1;
+    const bool weighted = weights != nullptr;
+    E.src.reserve(3 * n);
+    E.cvt.reserve((weighted ? 4 : 3) * n);
+    E.cstats.reserve(1);
+    HIP_CHECK(hipMemcpy(E.src.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
+    launch_convert(PAMD_COPY, E.src.p, E.cvt.p, n, E.cstats.p, E.stream);
+    if (weighted) {
+        HIP_CHECK(hipMemcpyAsync(E.cvt.p + 3 * n, weights, n * sizeof(double), hipMemcpyHostToDevice, E.stream));
+        launch_weight_stats(E.cvt.p + 3 * n, n, E.cstats.p, E.stream);
+    }
+    Bounds b = read_bounds(E, weighted);
+    E.stats = patolette_amd__Stats{};
+    std::vector<double> pal;
+    size_t len = 0;
+    if (quantize_clusters(E, n, K, weighted, b, pal, len) != 0) return -1;
+    for (size_t j = 0; j < 3 * K; j++) centers[j] = NAN;
+    for (int j = 0; j < 3; j++) for (size_t i = 0; i < len; i++) centers[(size_t)j * K + i] = pal[(size_t)j * len + i];
+    *n_clusters = len;
+    return 0;
+    PAMD_GUARD_END(-1)
+}
+
+int patolette_amd_kmeans_refine(const double *colors, const double *weights, size_t n, double *centers_io, size_t k, int niter, size_t max_samples) {
+    PAMD_GUARD_BEGIN
+    const bool weighted = weights != nullptr;
+    E.cvt.reserve((weighted ? 4 : 3) * n);
+    HIP_CHECK(hipMemcpy(E.cvt.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
+    if (weighted) HIP_CHECK(hipMemcpy(E.cvt.p + 3 * n, weights, n * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> pal(centers_io, centers_io + 3 * k);
+    kmeans_refine(E, n, weighted, pal, k, niter, max_samples);
+    std::memcpy(centers_io, pal.data(), 3 * k * sizeof(double));
+    return 0;
+    PAMD_GUARD_END(-1)
+}
+
+int patolette_amd_nn_map(const double *colors, size_t n, const double *palette, size_t k, size_t *map) {
+    PAMD_GUARD_BEGIN
+    if (n == 0) return 0;
+    E.src.reserve(3 * n); E.dpal.reserve(3 * k); E.dmap.reserve(n * 4);
+    HIP_CHECK(hipMemcpy(E.src.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(E.dpal.p, palette, 3 * k * sizeof(double), hipMemcpyHostToDevice));
+    launch_nn_map(E.src.p, n, n, E.dpal.p, (int)k, E.dmap.p, 4, E.stream);
+    E.sync();
+    std::vector<unsigned int> tmp(n);
+    HIP_CHECK(hipMemcpy(tmp.data(), E.dmap.p, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) map[i] = tmp[i];
+    return 0;
+    PAMD_GUARD_END(-1)
+}
+
+int patolette_amd_dither(const double *colors, size_t width, size_t height, const double *palette, size_t k, size_t *map) {
+    PAMD_GUARD_BEGIN
+    const size_t n = width * height;
+    if (n == 0) return 0;
+    E.src.reserve(3 * n); E.dpal.reserve(3 * k); E.dmap.reserve(n * 4);
+    HIP_CHECK(hipMemcpy(E.src.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(E.dpal.p, palette, 3 * k * sizeof(double), hipMemcpyHostToDevice));
+    launch_dither(E.src.p, n, width, height, E.dpal.p, (int)k, E.dmap.p, 4, E.stream);
+    E.sync();
+    if (std::max(width, height) > 1) {
+        std::vector<unsigned int> tmp(n);
+        HIP_CHECK(hipMemcpy(tmp.data(), E.dmap.p, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) map[i] = tmp[i];
+    }
+    return 0;
+    PAMD_GUARD_END(-1)
+}
+
+void patolette_amd_last_stats(patolette_amd__Stats *out) { *out = engine().stats; }
+
+void patolette_amd_profile_enable(int on) {
+    KernelTimer &t = ktimer();
+    if (engine().stream) (void)hipStreamSynchronize(engine().stream);
+    t.reset();
+    t.enabled = on != 0;
+}
+int patolette_amd_profile_count(void) { return (int)ktimer().names.size(); }
+int patolette_amd_profile_get(int i, char *name64, double *total_ms, size_t *launches, double *total_bytes) {
+    KernelTimer &t = ktimer();
+    if (i < 0 || i >= (int)t.names.size()) return -1;
+    snprintf(name64, 64, "%s", t.names[i].c_str());
+    *total_ms = t.total_ms[i];
+    *launches = t.launches[i];
+    *total_bytes = t.total_bytes[i];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// quant.h -- device records and launchers of the cluster-split kernels (quant.hip).
+#pragma once
+
+#include "common.h"
+#include "devutil.h"
+
+namespace pamd {
+
+constexpr int kMaxChildren = 16;       // GQ makes <= 12 base clusters (global.c:19), LQ splits in 2
+constexpr int kTileA = 8192;           // pixels per block for streaming reductions (minmax / hist / cov)
+constexpr int kTileP = 2048;           // pixels per block for the stable partition (256 threads x 8 rounds)
+
+// quantities accumulated per bucket by k_hist (two binned parts each)
+//   LQ : 0..2 = sum c*w, 3 = sum w
+//   GQ : 0..2 = sum c, 3 = sum |c|^2, 4..9 = sum c_r*c_s (00,01,11,02,12,22), 10..12 = sum c*w, 13 = sum w
+constexpr int kNQ_LQ = 4;
+constexpr int kNQ_GQ = 14;
+
+struct NodeDev {
+    // ---- inputs (host or k_cut writes them)
+    unsigned long long begin;          // first pixel slot of the segment
+    unsigned long long n;              // pixels
+    int buf;                           // ping-pong buffer holding the segment
+    int slot;                          // histogram slot in the current round (-1: not being split)
+    int child0;                        // id of first child record (children are consecutive)
+    int nchild;
+    double axis[3];
+    double mean[3];                    // weighted centre
+    double sw;                         // sum of weights (n if unweighted)
+    BinK klin, kquad;                  // binned-accumulation constants valid for this node and its children
+    // ---- split evaluation outputs
+    unsigned long long minkey, maxkey; // ordered keys of the projection extrema
+    int degenerate;                    // max - min < 1e-16 -> round-robin buckets (sort.c:61-79)
+    int split;                         // optimal bucket index (local.c:171)
+    unsigned long long cbegin[kMaxChildren + 1];   // children segments in the other buffer
+    // ---- moments about `mean` (k_cov): 6 covariance sums (xx,yx,zx,yy,zy,zz) + distortion, 2 parts each
+    double acc[7][2];
+};
+
+struct Tile {
+    unsigned long long start;          // absolute pixel slot
+    unsigned int count;
+    unsigned int node;                 // NodeDev index
+};
+
+struct QuantBuffers {
+    double *buf[2];                    // planar x|y|z(|w): plane p at buf[b] + p*N
+    unsigned short *bkt;               // bucket id per pixel slot
+    size_t N;
+    bool weighted;
+};
+
+// all launchers enqueue on `s` and return immediately
+void launch_sum3(const double *planar, size_t N, BinK k, double *d_out6, hipStream_t s);
+void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s);
+void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
+                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s);
+void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int nround, const double *d_hist,
+                const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s);
+void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
+                      const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
+                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, hipStream_t s);
+void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s);
+void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
+                      NodeDev *d_nodes, hipStream_t s);
+
+size_t hist_slot_doubles();            // doubles per histogram slot
+
+}  // namespace pamd

@@ -1,0 +1,506 @@
+// quant.hip -- gfx950 kernels of the weighted-PCA cluster-split loop.
+//
+// Replaces the O(N) inner loops of lib/src/quantize/{global,local,cluster,sort,cells}.c and
+// lib/src/math/pca.c.  The reference gathers each cluster's pixels through an index array and
+// sweeps them ~12 times per split; here the pixels of every tree node are kept PHYSICALLY
+// contiguous (planar x|y|z|w, two ping-pong buffers) and a split is four streaming passes:
+//
+//   k_minmax   projection extrema on the node's principal axis          24 B/px read
+//   k_hist     512-bucket moments of the projection (LDS histogram)     24(+8) B/px read, 2 B/px write
+//   k_cut      prefix + objective + arg-max per node (1 block/node)     histogram only
+//   k_count / k_scan / k_scatter   stable partition into the children   2 + 24(+8)+2 B/px read, 24(+8) B/px write
+//   k_cov      children's centred covariance + distortion               24(+8) B/px read
+//
+// All of them are HBM-bound (inner dimension 3: no MFMA).  Floating-point sums use the
+// order-independent binned accumulation of devutil.h, so LDS / global f64 atomics are exact
+// and the results are bit-reproducible for any launch geometry.
+#include "quant.h"
+
+namespace pamd {
+
+// --------------------------------------------------------------------------------------------
+// small block-level primitives (512- or 256-thread blocks)
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T block_scan_incl(T v, T *smem) {          // smem: >= 16 entries
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    __syncthreads();
+    if (lane == 63) smem[wid] = v;
+    __syncthreads();
+    if (wid == 0) {
+        T s = lane < nw ? smem[lane] : T(0);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            T t = __shfl_up(s, o, 64);
+            if (lane >= o) s += t;
+        }
+        if (lane < nw) smem[lane] = s;
+    }
+    __syncthreads();
+    if (wid > 0) v += smem[wid - 1];
+    return v;
+}
+
+// --------------------------------------------------------------------------------------------
+// root mean: sum of each plane (GQ's PCA is UNWEIGHTED, global.c:407 -> pca.c:151-168)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sum3(const double *__restrict__ c, size_t N, BinK k, double *out6) {
+    __shared__ double sm[6 * 4];
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+        bin_add(c[i], k, a[0], a[1]);
+        bin_add(c[N + i], k, a[2], a[3]);
+        bin_add(c[2 * N + i], k, a[4], a[5]);
+    }
+    block_sum<6>(a, sm);
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 6; q++) unsafeAtomicAdd(&out6[q], a[q]);
+}
+
+// --------------------------------------------------------------------------------------------
+// projection on the node axis: sort.c:43-59 (dgemv, min, max)
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ double project(double x, double y, double z, const double a0, const double a1, const double a2) {
+    return (x * a0 + y * a1) + z * a2;
+}
+
+__global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes) {
+    const Tile t = tiles[blockIdx.x];
+    NodeDev &nd = nodes[t.node];
+    const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
+    const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N;
+    double mn = INFINITY, mx = -INFINITY;
+    for (unsigned i = threadIdx.x; i < t.count; i += blockDim.x) {
+        size_t p = t.start + i;
+        double d = project(px[p], py[p], pz[p], a0, a1, a2);
+        mn = fmin(mn, d); mx = fmax(mx, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_down(mn, o, 64)); mx = fmax(mx, __shfl_down(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0 && mn <= mx) {
+        atomicMin(&nd.minkey, f64_key(mn));
+        atomicMax(&nd.maxkey, f64_key(mx));
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// bucket moments: sort.c:61-87 (bucket id) + local.c:118-134 (LQ) / cells.c:82-112 (GQ)
+// --------------------------------------------------------------------------------------------
+template <bool W, bool GQ>
+__global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes,
+                                              double *hist, unsigned long long *hsize, unsigned int *hcount) {
+    constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
+    constexpr int NQS = GQ ? kNQ_GQ : kNQ_LQ;            // slot stride in quantities
+    extern __shared__ double lds[];
+    double *h = lds;                                       // [NQ][2][512]
+    unsigned int *cnt = (unsigned int *)(h + NQ * 2 * kBuckets);
+    unsigned int *siz = cnt + kBuckets;
+    for (int i = threadIdx.x; i < NQ * 2 * kBuckets; i += blockDim.x) h[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * kBuckets; i += blockDim.x) cnt[i] = 0u;
+    __syncthreads();
+
+    const Tile t = tiles[blockIdx.x];
+    NodeDev &nd = nodes[t.node];
+    const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
+    const double mn = key_f64(nd.minkey), mx = key_f64(nd.maxkey);
+    const bool degenerate = (mx - mn < kDelta);
+    const double sc = 1 / (mx - mn);
+    const BinK klin = nd.klin, kquad = nd.kquad;
+    const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
+    if (threadIdx.x == 0) nd.degenerate = degenerate ? 1 : 0;
+
+    for (unsigned i = threadIdx.x; i < t.count; i += blockDim.x) {
+        const size_t p = t.start + i;
+        const double x = px[p], y = py[p], z = pz[p];
+        double w = 1.0;
+        if constexpr (W) w = pw[p];
+        unsigned b;
+        if (degenerate) {
+            b = (unsigned)((p - nd.begin) % kBuckets);
+        } else {
+            double ratio = (project(x, y, z, a0, a1, a2) - mn) * sc;
+            unsigned long long bq = (unsigned long long)((double)kBuckets * ratio);
+            b = bq < (unsigned long long)(kBuckets - 1) ? (unsigned)bq : (unsigned)(kBuckets - 1);
+        }
+        qb.bkt[p] = (unsigned short)b;
+        atomicAdd(&cnt[b], 1u);
+        double v0, v1;
+#define HADD(q, val, K)                                         \
+    do {                                                        \
+        bin_split((val), (K), v0, v1);                          \
+        unsafeAtomicAdd(&h[((q) * 2 + 0) * kBuckets + b], v0);  \
+        unsafeAtomicAdd(&h[((q) * 2 + 1) * kBuckets + b], v1);  \
+    } while (0)
+        if constexpr (!GQ) {
+            HADD(0, x * w, klin); HADD(1, y * w, klin); HADD(2, z * w, klin);
+            if constexpr (W) {
+                HADD(3, w, klin);
+                atomicAdd(&siz[b], (unsigned)(unsigned long long)w);      // size_t += double truncates (local.c:133)
+            }
+        } else {
+            HADD(0, x, klin); HADD(1, y, klin); HADD(2, z, klin);
+            HADD(3, (x * x + y * y) + z * z, kquad);
+            HADD(4, x * x, kquad); HADD(5, x * y, kquad); HADD(6, y * y, kquad);
+            HADD(7, x * z, kquad); HADD(8, y * z, kquad); HADD(9, z * z, kquad);
+            if constexpr (W) { HADD(10, x * w, klin); HADD(11, y * w, klin); HADD(12, z * w, klin); HADD(13, w, klin); }
+        }
+#undef HADD
+    }
+    __syncthreads();
+    const size_t slot = (size_t)nd.slot;
+    double *gh = hist + slot * (size_t)(NQS * 2 * kBuckets);
+    for (int i = threadIdx.x; i < NQ * 2 * kBuckets; i += blockDim.x) {
+        double v = h[i];
+        if (v != 0.0) unsafeAtomicAdd(&gh[i], v);
+    }
+    for (int b = threadIdx.x; b < kBuckets; b += blockDim.x) {
+        unsigned c = cnt[b];
+        if (c) atomicAdd(&hcount[slot * kBuckets + b], c);
+        if constexpr (W && !GQ) { unsigned s = siz[b]; if (s) atomicAdd(&hsize[slot * kBuckets + b], (unsigned long long)s); }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// optimal cut: local.c:136-176 (prefix, objective, first arg-max) + the children's records
+// --------------------------------------------------------------------------------------------
+template <bool W>
+__global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restrict__ round_nodes, const double *__restrict__ hist,
+                                             const unsigned long long *__restrict__ hsize, const unsigned int *__restrict__ hcount,
+                                             unsigned char *lut) {
+    __shared__ double sd[16];
+    __shared__ unsigned long long su[16];
+    __shared__ double best_v[8];
+    __shared__ int best_i[8];
+    __shared__ double tot[8];
+    __shared__ unsigned long long tots[2];
+    __shared__ int s_split;
+    const int b = threadIdx.x;
+    NodeDev &nd = nodes[round_nodes[blockIdx.x]];
+    const size_t slot = (size_t)nd.slot;
+    const double *gh = hist + slot * (size_t)(kNQ_LQ * 2 * kBuckets);
+    constexpr int NQ = W ? 4 : 3;
+    double p[NQ][2];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        p[q][0] = block_scan_incl<double>(gh[(q * 2 + 0) * kBuckets + b], sd);
+        p[q][1] = block_scan_incl<double>(gh[(q * 2 + 1) * kBuckets + b], sd);
+    }
+    unsigned long long cnt = block_scan_incl<unsigned long long>((unsigned long long)hcount[slot * kBuckets + b], su);
+    unsigned long long siz = cnt;
+    if constexpr (W) siz = block_scan_incl<unsigned long long>(hsize[slot * kBuckets + b], su);
+    __syncthreads();
+    if (b == kBuckets - 1) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { tot[q * 2] = p[q][0]; tot[q * 2 + 1] = p[q][1]; }
+        tots[0] = cnt; tots[1] = siz;
+    }
+    __syncthreads();
+    // objective_b = sum_j csl^2/sl + csr^2/sr  (local.c:150-168)
+    double obj = 0;
+    {
+        const double sl = (double)siz, sr = (double)tots[1] - sl;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double csl = p[j][0] + p[j][1];
+            double csr = (tot[j * 2] + tot[j * 2 + 1]) - csl;
+            double v = 0;
+            if (sl != 0) v += (csl * csl) / sl;
+            if (sr != 0) v += (csr * csr) / sr;
+            obj += v;
+        }
+    }
+    // first maximum (vector.c:26-46: strict '>' scanning upwards)
+    double bv = obj; int bi = b;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_down(bv, o, 64); int oi = __shfl_down(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((b & 63) == 0) { best_v[b >> 6] = bv; best_i[b >> 6] = bi; }
+    __syncthreads();
+    if (b == 0) {
+        for (int w = 1; w < 8; w++)
+            if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
+        s_split = bi;
+    }
+    __syncthreads();
+    const int split = s_split;
+    lut[slot * kBuckets + b] = b > split ? 1 : 0;
+    if (b == split) {
+        nd.split = split;
+        const unsigned long long nL = cnt, nR = tots[0] - cnt;
+        nd.cbegin[0] = nd.begin; nd.cbegin[1] = nd.begin + nL; nd.cbegin[2] = nd.begin + nd.n;
+        for (int side = 0; side < 2; side++) {
+            NodeDev &ch = nodes[nd.child0 + side];
+            ch.begin = side == 0 ? nd.begin : nd.begin + nL;
+            ch.n = side == 0 ? nL : nR;
+            ch.buf = 1 - nd.buf;
+            ch.slot = -1; ch.child0 = -1; ch.nchild = 0;
+            ch.klin = nd.klin; ch.kquad = nd.kquad;
+            ch.minkey = ~0ULL; ch.maxkey = 0ULL; ch.degenerate = 0; ch.split = -1;
+            double s0[NQ], s1[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                s0[q] = side == 0 ? p[q][0] : tot[q * 2] - p[q][0];        // exact: all parts lie on the bin grids
+                s1[q] = side == 0 ? p[q][1] : tot[q * 2 + 1] - p[q][1];
+            }
+            double sw = W ? (s0[NQ - 1] + s1[NQ - 1]) : (double)ch.n;
+            ch.sw = sw;
+            const double inv = 1 / sw;                                     // matrix2D.c:229-231: mean *= 1/sum(w)
+            for (int j = 0; j < 3; j++) ch.mean[j] = (s0[j] + s1[j]) * inv;
+            for (int q = 0; q < 7; q++) { ch.acc[q][0] = 0; ch.acc[q][1] = 0; }
+            ch.axis[0] = ch.axis[1] = ch.axis[2] = 0;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// stable partition of every split node's segment into its children (local.c:210-243,
+// global.c:300-363): count -> scan -> scatter.  Order inside a child = order inside the
+// parent, as the reference's index lists have it.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count(QuantBuffers qb, const Tile *__restrict__ tiles, const NodeDev *__restrict__ nodes,
+                                               const unsigned char *__restrict__ lut, unsigned int *tilecnt) {
+    __shared__ unsigned int c[kMaxChildren];
+    const Tile t = tiles[blockIdx.x];
+    const NodeDev &nd = nodes[t.node];
+    const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
+    if (threadIdx.x < kMaxChildren) c[threadIdx.x] = 0;
+    __syncthreads();
+    const int nch = nd.nchild;
+    for (unsigned i = threadIdx.x; i < ((t.count + 255u) & ~255u); i += blockDim.x) {
+        int child = i < t.count ? (int)l[qb.bkt[t.start + i]] : 255;
+        for (int k = 0; k < nch; k++) {
+            unsigned long long m = __ballot(child == k);
+            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c[k], (unsigned)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxChildren) tilecnt[(size_t)blockIdx.x * kMaxChildren + threadIdx.x] = c[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_scan(const int *__restrict__ round_nodes, const int *__restrict__ node_tile0, NodeDev *nodes,
+                                              const unsigned int *__restrict__ tilecnt, unsigned long long *tileoff) {
+    __shared__ unsigned long long su[16];
+    __shared__ unsigned long long carry;
+    NodeDev &nd = nodes[round_nodes[blockIdx.x]];
+    const int t0 = node_tile0[blockIdx.x], t1 = node_tile0[blockIdx.x + 1];
+    unsigned long long base = nd.begin;
+    for (int k = 0; k < nd.nchild; k++) {
+        if (threadIdx.x == 0) { carry = base; nd.cbegin[k] = base; }
+        __syncthreads();
+        for (int c0 = t0; c0 < t1; c0 += blockDim.x) {
+            int ti = c0 + threadIdx.x;
+            unsigned long long v = ti < t1 ? (unsigned long long)tilecnt[(size_t)ti * kMaxChildren + k] : 0ULL;
+            unsigned long long inc = block_scan_incl<unsigned long long>(v, su);
+            unsigned long long cr = carry;
+            if (ti < t1) tileoff[(size_t)ti * kMaxChildren + k] = cr + inc - v;
+            __syncthreads();
+            if (threadIdx.x == blockDim.x - 1) carry = cr + inc;
+            __syncthreads();
+        }
+        base = carry;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nd.cbegin[nd.nchild] = base;
+}
+
+template <bool W>
+__global__ __launch_bounds__(256) void k_scatter(QuantBuffers qb, const Tile *__restrict__ tiles, const NodeDev *__restrict__ nodes,
+                                                 const unsigned char *__restrict__ lut, const unsigned long long *__restrict__ tileoff) {
+    constexpr int R = kTileP / 256;
+    __shared__ unsigned long long off[R][4][kMaxChildren];
+    const Tile t = tiles[blockIdx.x];
+    const NodeDev &nd = nodes[t.node];
+    const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
+    const int nch = nd.nchild;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long ltmask = (1ULL << lane) - 1ULL;
+    int child[R]; unsigned rank[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        unsigned i = r * 256 + threadIdx.x;
+        child[r] = i < t.count ? (int)l[qb.bkt[t.start + i]] : 255;
+        rank[r] = 0;
+        for (int k = 0; k < nch; k++) {
+            unsigned long long m = __ballot(child[r] == k);
+            if (child[r] == k) rank[r] = (unsigned)__popcll(m & ltmask);
+            if (lane == 0) off[r][wid][k] = (unsigned long long)__popcll(m);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nch) {
+        unsigned long long run = tileoff[(size_t)blockIdx.x * kMaxChildren + threadIdx.x];
+        for (int r = 0; r < R; r++)
+            for (int w = 0; w < 4; w++) { unsigned long long c = off[r][w][threadIdx.x]; off[r][w][threadIdx.x] = run; run += c; }
+    }
+    __syncthreads();
+    const double *sx = qb.buf[nd.buf], *sy = sx + qb.N, *sz = sy + qb.N, *sw = sz + qb.N;
+    double *dx = qb.buf[1 - nd.buf], *dy = dx + qb.N, *dz = dy + qb.N, *dw = dz + qb.N;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (child[r] != 255) {
+            size_t src = t.start + r * 256 + threadIdx.x;
+            size_t dst = off[r][wid][child[r]] + rank[r];
+            dx[dst] = sx[src]; dy[dst] = sy[src]; dz[dst] = sz[src];
+            if constexpr (W) dw[dst] = sw[src];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// centred second moments + distortion: pca.c:62-101 (vcov, product order (w*c_j)*c_k, lower
+// triangle) and cluster.c:111-152 (distortion = sum ((dx^2+dy^2)+dz^2)*w)
+// --------------------------------------------------------------------------------------------
+template <bool W>
+__device__ __forceinline__ void cov_accumulate(const double *px, const double *py, const double *pz, const double *pw,
+                                               size_t lo, size_t hi, const double m0, const double m1, const double m2,
+                                               const BinK kq, double (&a)[14]) {
+    for (size_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+        double dx = px[p] - m0, dy = py[p] - m1, dz = pz[p] - m2;
+        double w = 1.0;
+        if constexpr (W) w = pw[p];
+        double wx = w * dx, wy = w * dy, wz = w * dz;
+        bin_add(wx * dx, kq, a[0], a[1]);
+        bin_add(wy * dx, kq, a[2], a[3]);
+        bin_add(wz * dx, kq, a[4], a[5]);
+        bin_add(wy * dy, kq, a[6], a[7]);
+        bin_add(wz * dy, kq, a[8], a[9]);
+        bin_add(wz * dz, kq, a[10], a[11]);
+        bin_add(((dx * dx + dy * dy) + dz * dz) * w, kq, a[12], a[13]);
+    }
+}
+
+// tiles cover the PARENT's range in the destination buffer; each child accumulates about its own mean
+template <bool W>
+__global__ __launch_bounds__(256) void k_cov_children(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes) {
+    __shared__ double sm[14 * 4];
+    const Tile t = tiles[blockIdx.x];
+    const NodeDev &nd = nodes[t.node];
+    const double *px = qb.buf[1 - nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
+    const size_t t_lo = t.start, t_hi = t.start + t.count;
+    for (int k = 0; k < nd.nchild; k++) {
+        size_t lo = nd.cbegin[k] > t_lo ? nd.cbegin[k] : t_lo;
+        size_t hi = nd.cbegin[k + 1] < t_hi ? nd.cbegin[k + 1] : t_hi;
+        if (lo >= hi) continue;                                  // block-uniform
+        NodeDev &ch = nodes[nd.child0 + k];
+        double a[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) a[i] = 0;
+        cov_accumulate<W>(px, py, pz, pw, lo, hi, ch.mean[0], ch.mean[1], ch.mean[2], nd.kquad, a);
+        block_sum<14>(a, sm);
+        if (threadIdx.x == 0)
+            for (int q = 0; q < 7; q++) { unsafeAtomicAdd(&ch.acc[q][0], a[2 * q]); unsafeAtomicAdd(&ch.acc[q][1], a[2 * q + 1]); }
+    }
+}
+
+// tiles cover the node's own segment (root: `planar` = the converted image itself)
+template <bool W>
+__global__ __launch_bounds__(256) void k_cov_nodes(QuantBuffers qb, const double *planar, const Tile *__restrict__ tiles, NodeDev *nodes) {
+    __shared__ double sm[14 * 4];
+    const Tile t = tiles[blockIdx.x];
+    NodeDev &nd = nodes[t.node];
+    const double *px = planar ? planar : qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
+    double a[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) a[i] = 0;
+    cov_accumulate<W>(px, py, pz, pw, t.start, t.start + t.count, nd.mean[0], nd.mean[1], nd.mean[2], nd.kquad, a);
+    block_sum<14>(a, sm);
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 7; q++) { unsafeAtomicAdd(&nd.acc[q][0], a[2 * q]); unsafeAtomicAdd(&nd.acc[q][1], a[2 * q + 1]); }
+}
+
+// --------------------------------------------------------------------------------------------
+// launchers
+// --------------------------------------------------------------------------------------------
+size_t hist_slot_doubles() { return (size_t)kNQ_GQ * 2 * kBuckets; }
+
+void launch_sum3(const double *planar, size_t N, BinK k, double *d_out6, hipStream_t s) {
+    HIP_CHECK(hipMemsetAsync(d_out6, 0, 6 * sizeof(double), s));
+    size_t g = ceil_div(N, 256 * 16);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    KTIME("k_sum3", s, 24.0 * N);
+    hipLaunchKernelGGL(k_sum3, (int)g, 256, 0, s, planar, N, k, d_out6);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s) {
+    if (!ntiles) return;
+    KTIME("k_minmax", s, 24.0 * px);
+    hipLaunchKernelGGL(k_minmax, ntiles, 256, 0, s, qb, d_tiles, d_nodes);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <bool W, bool GQ>
+static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, double *d_hist,
+                          unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s) {
+    constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
+    size_t lds = (size_t)NQ * 2 * kBuckets * sizeof(double) + 2 * kBuckets * sizeof(unsigned int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_hist<W, GQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    KTIME(GQ ? "k_hist_gq" : "k_hist_lq", s, (W ? 34.0 : 26.0) * px);
+    hipLaunchKernelGGL((k_hist<W, GQ>), ntiles, 512, lds, s, qb, d_tiles, d_nodes, d_hist, d_hsize, d_hcount);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
+                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s) {
+    if (!ntiles) return;
+    if (qb.weighted) { if (gq) launch_hist_t<true, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s);
+                       else launch_hist_t<true, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s); }
+    else { if (gq) launch_hist_t<false, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s);
+           else launch_hist_t<false, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s); }
+}
+
+void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int nround, const double *d_hist,
+                const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s) {
+    if (!nround) return;
+    KTIME("k_cut", s, (double)nround * kNQ_LQ * 2 * kBuckets * 8);
+    if (weighted) hipLaunchKernelGGL(k_cut<true>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut);
+    else hipLaunchKernelGGL(k_cut<false>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
+                      const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
+                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, hipStream_t s) {
+    if (!nptiles) return;
+    { KTIME("k_count", s, 2.0 * px); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt); }
+    { KTIME("k_scan", s, 12.0 * kMaxChildren * nptiles); hipLaunchKernelGGL(k_scan, nround, 256, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff); }
+    {
+        KTIME("k_scatter", s, (qb.weighted ? 66.0 : 50.0) * px);
+        if (qb.weighted) hipLaunchKernelGGL(k_scatter<true>, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+        else hipLaunchKernelGGL(k_scatter<false>, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s) {
+    if (!ntiles) return;
+    KTIME("k_cov", s, (qb.weighted ? 32.0 : 24.0) * px);
+    if (qb.weighted) hipLaunchKernelGGL(k_cov_children<true>, ntiles, 256, 0, s, qb, d_tiles, d_nodes);
+    else hipLaunchKernelGGL(k_cov_children<false>, ntiles, 256, 0, s, qb, d_tiles, d_nodes);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
+                      NodeDev *d_nodes, hipStream_t s) {
+    if (!ntiles) return;
+    KTIME("k_cov", s, ((qb.weighted && !planar_override) ? 32.0 : 24.0) * px);
+    // the root PCA is unweighted even when weights exist (global.c:407)
+    if (qb.weighted && !planar_override) hipLaunchKernelGGL(k_cov_nodes<true>, ntiles, 256, 0, s, qb, planar_override, d_tiles, d_nodes);
+    else hipLaunchKernelGGL(k_cov_nodes<false>, ntiles, 256, 0, s, qb, planar_override, d_tiles, d_nodes);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace pamd

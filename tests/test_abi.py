@@ -1,0 +1,68 @@
+"""The C-ABI boundary without a GPU: the library loads, and exports every symbol that
+include/patolette.h and include/patolette_amd.h declare; struct layout matches the reference."""
+import ctypes as C
+import os
+import re
+
+from tests.util import ROOT
+
+
+def declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", txt)
+    return {n for n in names if n.startswith("patolette") or n.startswith("get_patolette")}
+
+
+def test_every_declared_symbol_is_exported(native):
+    L = native.lib()
+    declared = declared_functions("patolette.h") | declared_functions("patolette_amd.h")
+    assert {"patolette", "get_patolette_exit_code_info_message", "patolette_create_default_options"} <= declared
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(native.SYMBOLS), declared ^ set(native.SYMBOLS)
+
+
+def test_options_struct_layout_matches_reference(native):
+    # lib/include/patolette.h:13-20 on x86-64 SysV: offsets 0,1,4,8,16,24, sizeof 32
+    Q = native.QuantizationOptions
+    assert [getattr(Q, n).offset for n, _ in Q._fields_] == [0, 1, 4, 8, 16, 24]
+    assert C.sizeof(Q) == 32
+
+
+def test_default_options_and_messages(native):
+    L = native.lib()
+    o = L.patolette_create_default_options()                    # patolette.c:107-119
+    assert (o.contents.dither, o.contents.palette_only, o.contents.color_space, o.contents.kmeans_niter,
+            o.contents.kmeans_max_samples, o.contents.verbose) == (True, False, 2, 32, 512 * 512, False)
+    C.CDLL(None).free(C.cast(o, C.c_void_p))
+    msgs = [L.get_patolette_exit_code_info_message(-i).decode() for i in range(5)]   # patolette.c:32-38
+    assert msgs == ["Quantization successful.", "Internal quantization error.", "Image dimensions should be greater than 0.",
+                    "Palette size should be greater than 0.", "Image dimensions are too big."]
+
+
+def test_argument_validation_needs_no_gpu(native):
+    # patolette.c:61-95 runs before anything touches the device
+    L = native.lib()
+    opts = native.QuantizationOptions(False, True, 2, 0, 0, False)
+    code = C.c_int(7)
+    L.patolette(0, 5, None, None, 4, C.byref(opts), None, None, C.byref(code))
+    assert code.value == -2
+    L.patolette(3, 5, None, None, 0, C.byref(opts), None, None, C.byref(code))
+    assert code.value == -3
+    L.patolette(50000, 50000, None, None, 4, C.byref(opts), None, None, C.byref(code))
+    assert code.value == -4
+
+
+def test_python_surface_validation_messages():
+    # patolette.pyx:328-373: returned before crossing into C
+    import numpy as np
+    import patolette_amd as p
+    assert p.quantize(2, 2, np.zeros((4, 4)), 2) == (False, None, None,
+                                                     "Expected colors to be in sRGB[0, 1] space. Channel count mismatch: 4 found.")
+    assert p.quantize(2, 3, np.zeros((4, 3)), 2) == (False, None, None,
+                                                     "The number of colors doesn't match the supplied width and height.")
+    assert p.quantize(2, 2, np.zeros((4, 3)), 2, tile_size=-1) == (False, None, None,
+                                                                    "tile_size parameter expected to be in the range [0, inf]")
+    assert (p.ColorSpace_sRGB, p.ColorSpace_CIELuv, p.ColorSpace_ICtCp) == (0, 1, 2)
+    assert {"quantize", "ColorSpace_sRGB", "ColorSpace_CIELuv", "ColorSpace_ICtCp"} <= set(p.__all__)
