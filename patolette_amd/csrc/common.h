@@ -78,6 +78,16 @@ struct DevBuf {
         HIP_CHECK(hipMalloc((void **)&p, n * sizeof(T)));
         cap = n;
     }
+    // grow keeping the first `keep` elements
+    void grow(size_t n, size_t keep) {
+        if (n <= cap) return;
+        T *q = nullptr;
+        size_t ncap = n + n / 2;
+        HIP_CHECK(hipMalloc((void **)&q, ncap * sizeof(T)));
+        if (p && keep) HIP_CHECK(hipMemcpy(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice));
+        if (p) (void)hipFree(p);
+        p = q; cap = ncap;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     ~DevBuf() { release(); }
     DevBuf() = default;

@@ -14,8 +14,7 @@ struct KMeansWork {
     DevBuf<float> sx, sy, sz, sw;      // samples, f32 SoA
     DevBuf<int> assign;
     DevBuf<float4> sorted;             // samples grouped by centroid, sample order kept
-    DevBuf<unsigned int> table, rowtot;
-    DevBuf<unsigned long long> rowbase;
+    DevBuf<unsigned int> table, rowtot, ticket;
     DevBuf<float> cent, hassign;       // interleaved xyz centroids (faiss layout)
     DevBuf<float4> c4;                 // (y0,y1,y2,|y|^2)
     DevBuf<int> perm;                  // subsample indices

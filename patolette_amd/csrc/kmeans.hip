@@ -10,15 +10,20 @@
 //   update   = compute_centroids (Clustering.cpp:135-204): per centroid, in SAMPLE ORDER,
 //              c = fma(x, w, c) (weighted) or c += x; then c *= 1/h.  Sample order is kept by a
 //              stable counting sort of the samples by assignment; one wavefront then replays the
-//              sequential f32 chain of one centroid from coalesced 1-KiB loads.
+//              sequential f32 chain of one centroid from coalesced 1-KiB loads staged in LDS.
 //   split    = split_clusters (Clustering.cpp:216-263) with std::mt19937(1234), on one lane.
-// f32 arithmetic, contraction off, FMAs only where written.  assign is 24 B/sample of HBM
-// traffic and VALU-bound by brute force at k = 256; update is a latency chain.
+// f32 arithmetic, contraction off, FMAs only where written.
+//
+// One Lloyd iteration = 4 launches on one stream, no host round trip:
+//   k_km_assign_count  16 B/sample (12 R + 4 W), VALU-bound by brute force at k = 256
+//   k_km_rowscan       per-centroid scan of the chunk-count table
+//   k_km_scatter       32-36 B/sample
+//   k_km_update        16 B/sample; latency chain per centroid; the last wavefront to finish
+//                      (agent-scope release/acquire ticket) handles empty clusters and prepares
+//                      (y, |y|^2) for the next iteration.
 #include "kmeans.h"
 
 namespace pamd {
-
-constexpr int kChunk = 2048;          // samples per wavefront in the counting sort
 
 // ---- sample extraction: f64 planar -> f32 SoA (refine.c:127-163), optional subsample gather ----
 template <bool W>
@@ -32,19 +37,17 @@ __global__ __launch_bounds__(256) void k_km_gather(const double *__restrict__ pl
     }
 }
 
-__global__ void k_km_prep(const float *__restrict__ cent, int k, float4 *c4) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < k) {
-        float v0 = cent[3 * j], v1 = cent[3 * j + 1], v2 = cent[3 * j + 2];
-        float n = __builtin_fmaf(v2, v2, __builtin_fmaf(v0, v0, v1 * v1));
-        c4[j] = make_float4(v0, v1, v2, n);
-    }
+__device__ __forceinline__ float4 make_c4(float v0, float v1, float v2) {
+    return make_float4(v0, v1, v2, __builtin_fmaf(v2, v2, __builtin_fmaf(v0, v0, v1 * v1)));
 }
 
-__global__ __launch_bounds__(256) void k_km_assign(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, int *__restrict__ assign) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nx) return;
-    const float x0 = s.x[i], x1 = s.y[i], x2 = s.z[i];
+__global__ void k_km_prep(const float *__restrict__ cent, int k, float4 *c4) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < k) c4[j] = make_c4(cent[3 * j], cent[3 * j + 1], cent[3 * j + 2]);
+}
+
+// top-1 of one sample against all centroids, exactly as the AVX2 fused kernel orders it
+__device__ __forceinline__ int km_assign_one(const float x0, const float x1, const float x2, const float4 *c4, const int k) {
     const float m0 = -2 * x0, m1 = -2 * x1, m2 = -2 * x2;
     const float xn = __builtin_fmaf(x2, x2, __builtin_fmaf(x0, x0, x1 * x1));
     float ld[8]; unsigned li[8];
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void k_km_assign(KmSamples s, size_t nx, const
     for (int j = 0; j < ny_p; j += 8) {
 #pragma unroll
         for (int l = 0; l < 8; l++) {
-            const float4 y = c4[j + l];                    // wave-uniform address -> scalar load
+            const float4 y = c4[j + l];                    // wave-uniform LDS address -> broadcast ds_read_b128
             float dp = m0 * y.x;
             dp = __builtin_fmaf(m1, y.y, dp);
             dp = __builtin_fmaf(m2, y.z, dp);
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void k_km_assign(KmSamples s, size_t nx, const
         if (d < 0) d = 0;
         if (cur_d > d) { cur_d = d; cur_i = (unsigned)j0; }
     }
-    assign[i] = (int)cur_i;
+    return (int)cur_i;
 }
 
 // lanes holding the same key (within `valid`) -- nbits ballots
@@ -91,21 +94,27 @@ __device__ __forceinline__ unsigned long long match_mask(int key, int nbits, uns
     return m;
 }
 
-// ---- stable counting sort by assignment: one wavefront owns a chunk of consecutive samples ----
-__global__ __launch_bounds__(256) void k_km_count(const int *__restrict__ assign, size_t nx, int k, int nbits, int nchunks,
-                                                  unsigned int *table /* [k][nchunks] */) {
+// ---- assignment + first half of the stable counting sort: one wavefront owns a chunk of consecutive
+// samples, assigns them 64 at a time and counts per centroid in wave-private LDS ----
+__global__ __launch_bounds__(256) void k_km_assign_count(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, int nbits,
+                                                         int chunk_len, int nchunks, int *__restrict__ assign,
+                                                         unsigned int *table /* [k][nchunks] */) {
     extern __shared__ unsigned int lds_u[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    unsigned int *cnt = lds_u + (size_t)wid * k;
-    const int chunk = blockIdx.x * 4 + wid;
+    float4 *lc4 = (float4 *)lds_u;                                   // [k] centroids + norms, shared by the 4 waves
+    unsigned int *cnt = lds_u + 4 * (size_t)k + (size_t)wid * k;
+    for (int j = threadIdx.x; j < k; j += 256) lc4[j] = c4[j];
     for (int j = lane; j < k; j += 64) cnt[j] = 0u;
+    __syncthreads();
+    const int chunk = blockIdx.x * 4 + wid;
     if (chunk >= nchunks) return;
-    const size_t lo = (size_t)chunk * kChunk;
-    const size_t hi = lo + kChunk < nx ? lo + kChunk : nx;
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
     for (size_t base = lo; base < hi; base += 64) {
         const size_t i = base + lane;
         const bool v = i < hi;
-        const int a = v ? assign[i] : 0;
+        int a = 0;
+        if (v) { a = km_assign_one(s.x[i], s.y[i], s.z[i], lc4, k); assign[i] = a; }
         const unsigned long long valid = __ballot(v);
         const unsigned long long m = match_mask(a, nbits, valid);
         if (v && (m & ((1ULL << lane) - 1ULL)) == 0ULL) cnt[a] += (unsigned)__popcll(m);   // group leader; distinct addresses
@@ -139,42 +148,37 @@ __global__ __launch_bounds__(256) void k_km_rowscan(unsigned int *table, int nch
     if (threadIdx.x == 0) rowtot[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_km_base(const unsigned int *__restrict__ rowtot, int k, unsigned long long *rowbase /* k+1 */) {
-    __shared__ unsigned long long su[16];
-    __shared__ unsigned long long carry;
-    if (threadIdx.x == 0) carry = 0ULL;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int c0 = 0; c0 < k; c0 += 256) {
-        int c = c0 + threadIdx.x;
-        unsigned long long v = c < k ? (unsigned long long)rowtot[c] : 0ULL, inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { unsigned long long t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) su[wid] = inc;
-        __syncthreads();
-        unsigned long long pre = 0;
-        for (int w = 0; w < wid; w++) pre += su[w];
-        const unsigned long long cr = carry;
-        if (c < k) rowbase[c] = cr + pre + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry = cr + pre + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) rowbase[k] = carry;
-}
-
+// second half of the sort: samples -> (x,y,z,w) records grouped by centroid, sample order kept
 template <bool W>
-__global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__restrict__ assign, size_t nx, int k, int nbits, int nchunks,
-                                                    const unsigned int *__restrict__ table, const unsigned long long *__restrict__ rowbase,
-                                                    float4 *sorted) {
+__global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__restrict__ assign, size_t nx, int k, int nbits,
+                                                    int chunk_len, int nchunks, const unsigned int *__restrict__ table,
+                                                    const unsigned int *__restrict__ rowtot, float4 *sorted) {
     extern __shared__ unsigned int lds_u[];
+    __shared__ unsigned int wsum[4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    unsigned int *cnt = lds_u + (size_t)wid * k;
-    const int chunk = blockIdx.x * 4 + wid;
+    unsigned int *rowbase = lds_u;                                   // [k] exclusive prefix of rowtot
+    unsigned int *cnt = lds_u + k + (size_t)wid * k;
+    {   // block-wide exclusive scan of rowtot[0..k): each thread owns a contiguous run
+        const int per = (k + 255) / 256;
+        const int j0 = threadIdx.x * per, j1 = (j0 + per < k) ? j0 + per : k;
+        unsigned sum = 0;
+        for (int j = j0; j < j1; j++) sum += rowtot[j];
+        unsigned inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        unsigned pre = 0;
+        for (int w = 0; w < wid; w++) pre += wsum[w];
+        unsigned run = pre + inc - sum;
+        for (int j = j0; j < j1; j++) { rowbase[j] = run; run += rowtot[j]; }
+    }
     for (int j = lane; j < k; j += 64) cnt[j] = 0u;
+    __syncthreads();
+    const int chunk = blockIdx.x * 4 + wid;
     if (chunk >= nchunks) return;
-    const size_t lo = (size_t)chunk * kChunk;
-    const size_t hi = lo + kChunk < nx ? lo + kChunk : nx;
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
     const unsigned long long lt = (1ULL << lane) - 1ULL;
     for (size_t base = lo; base < hi; base += 64) {
         const size_t i = base + lane;
@@ -192,54 +196,6 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__re
             sorted[dst] = make_float4(s.x[i], s.y[i], s.z[i], w);
         }
         if (v && r == 0) cnt[a] = run + (unsigned)__popcll(m);     // leader
-    }
-}
-
-// ---- centroid update: one wavefront replays one centroid's sequential f32 chain ----
-template <bool W>
-__global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sorted, const unsigned long long *__restrict__ rowbase,
-                                                  float *cent, float *hassign) {
-    const int kidx = blockIdx.x, lane = threadIdx.x;
-    const size_t lo = (size_t)rowbase[kidx], hi = (size_t)rowbase[kidx + 1];
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, h = 0.f;
-    float4 cur = make_float4(0, 0, 0, 0);
-    if (lo + lane < hi) cur = sorted[lo + lane];
-    for (size_t base = lo; base < hi; base += 64) {
-        float4 nxt = make_float4(0, 0, 0, 0);
-        if (base + 64 + lane < hi) nxt = sorted[base + 64 + lane];         // prefetch the next 1 KiB
-        const int cnt = (int)(hi - base < 64 ? hi - base : 64);
-        if (cnt == 64) {
-#pragma unroll
-            for (int t = 0; t < 64; t++) {
-                const float x = __shfl(cur.x, t, 64), y = __shfl(cur.y, t, 64), z = __shfl(cur.z, t, 64);
-                if constexpr (W) {
-                    const float w = __shfl(cur.w, t, 64);
-                    h += w;
-                    c0 = __builtin_fmaf(x, w, c0); c1 = __builtin_fmaf(y, w, c1); c2 = __builtin_fmaf(z, w, c2);
-                } else {
-                    h += 1.0f;
-                    c0 += x; c1 += y; c2 += z;
-                }
-            }
-        } else {
-            for (int t = 0; t < cnt; t++) {
-                const float x = __shfl(cur.x, t, 64), y = __shfl(cur.y, t, 64), z = __shfl(cur.z, t, 64);
-                if constexpr (W) {
-                    const float w = __shfl(cur.w, t, 64);
-                    h += w;
-                    c0 = __builtin_fmaf(x, w, c0); c1 = __builtin_fmaf(y, w, c1); c2 = __builtin_fmaf(z, w, c2);
-                } else {
-                    h += 1.0f;
-                    c0 += x; c1 += y; c2 += z;
-                }
-            }
-        }
-        cur = nxt;
-    }
-    if (lane == 0) {
-        if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
-        cent[3 * kidx] = c0; cent[3 * kidx + 1] = c1; cent[3 * kidx + 2] = c2;
-        hassign[kidx] = h;
     }
 }
 
@@ -267,14 +223,8 @@ struct DevMT {
     }
 };
 
-__global__ void k_km_split(float *cent, float *hassign, int k, unsigned long long n, DevMT *scratch, int *nsplit_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    bool any = false;
-    for (int ci = 0; ci < k; ci++) if (hassign[ci] == 0.f) { any = true; break; }
-    if (!any) { if (nsplit_out) *nsplit_out = 0; return; }
-    DevMT &rng = *scratch;
+__device__ void km_split_clusters(float *cent, float *hassign, int k, unsigned long long n, DevMT &rng) {
     rng.seed(1234u);
-    int nsplit = 0;
     for (int ci = 0; ci < k; ci++) {
         if (hassign[ci] == 0.f) {
             int cj;
@@ -295,22 +245,126 @@ __global__ void k_km_split(float *cent, float *hassign, int k, unsigned long lon
             }
             hassign[ci] = hassign[cj] / 2;
             hassign[cj] -= hassign[ci];
-            nsplit++;
         }
     }
-    if (nsplit_out) *nsplit_out = nsplit;
+}
+
+// ---- centroid update: one wavefront replays one centroid's sequential f32 chain; the last
+// wavefront to finish handles empty clusters and writes (y, |y|^2) for the next assignment ----
+template <bool W>
+__global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sorted, const unsigned int *__restrict__ rowtot, int k,
+                                                  unsigned long long nx, float *cent, float *hassign, float4 *c4,
+                                                  unsigned int *ticket, DevMT *mt) {
+    __shared__ float4 stage[2][64];
+    __shared__ int s_last;
+    const int kidx = blockIdx.x, lane = threadIdx.x;
+    // segment of this centroid = prefix of the row totals
+    unsigned pre = 0;
+    for (int j = lane; j < kidx; j += 64) pre += rowtot[j];
+    pre = wave_sum_u32(pre);
+    pre = __shfl(pre, 0, 64);
+    const size_t lo = pre, hi = lo + rowtot[kidx];
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, h = 0.f;
+    constexpr int D = 8;                                                   // 1-KiB loads kept in flight
+    float4 ring[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        ring[d] = make_float4(0, 0, 0, 0);
+        if (lo + (size_t)d * 64 + lane < hi) ring[d] = sorted[lo + (size_t)d * 64 + lane];
+    }
+    int pb = 0;
+    for (size_t sbase = lo; sbase < hi; sbase += (size_t)D * 64) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const size_t base = sbase + (size_t)d * 64;
+            if (base >= hi) break;                                         // wave-uniform
+            stage[pb][lane] = ring[d];
+            {   // refill this ring slot with the block D steps ahead
+                const size_t nb = base + (size_t)D * 64 + lane;
+                ring[d] = make_float4(0, 0, 0, 0);
+                if (nb < hi) ring[d] = sorted[nb];
+            }
+            __syncthreads();
+            const int cnt = (int)(hi - base < 64 ? hi - base : 64);
+            if (cnt == 64) {
+#pragma unroll 16
+                for (int t = 0; t < 64; t++) {
+                    const float4 v = stage[pb][t];                         // LDS broadcast read
+                    if constexpr (W) {
+                        h += v.w;
+                        c0 = __builtin_fmaf(v.x, v.w, c0); c1 = __builtin_fmaf(v.y, v.w, c1); c2 = __builtin_fmaf(v.z, v.w, c2);
+                    } else {
+                        h += 1.0f;
+                        c0 += v.x; c1 += v.y; c2 += v.z;
+                    }
+                }
+            } else {
+                for (int t = 0; t < cnt; t++) {
+                    const float4 v = stage[pb][t];
+                    if constexpr (W) {
+                        h += v.w;
+                        c0 = __builtin_fmaf(v.x, v.w, c0); c1 = __builtin_fmaf(v.y, v.w, c1); c2 = __builtin_fmaf(v.z, v.w, c2);
+                    } else {
+                        h += 1.0f;
+                        c0 += v.x; c1 += v.y; c2 += v.z;
+                    }
+                }
+            }
+            pb ^= 1;
+        }
+    }
+    if (lane == 0) {
+        if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
+        cent[3 * kidx] = c0; cent[3 * kidx + 1] = c1; cent[3 * kidx + 2] = c2;
+        hassign[kidx] = h;
+        // publish, then take a ticket (agent-scope release -> relaxed counter; guide G16)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == (unsigned)k - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bool mine_empty = false;
+    for (int ci = lane; ci < k; ci += 64)
+        if (__hip_atomic_load(&hassign[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.f) mine_empty = true;
+    const bool any = __ballot(mine_empty) != 0ULL;
+    if (lane == 0) {
+        *ticket = 0u;                                                      // ready for the next iteration's launch
+        if (any) {
+            km_split_clusters(cent, hassign, k, nx, *mt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int j = lane; j < k; j += 64) {
+        const float v0 = __hip_atomic_load(&cent[3 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v1 = __hip_atomic_load(&cent[3 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v2 = __hip_atomic_load(&cent[3 * j + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c4[j] = make_c4(v0, v1, v2);
+    }
 }
 
 // --------------------------------------------------------------------------------------------
+static int chunk_len_for(size_t nx) {
+    size_t c = ceil_div(nx, 4096);                 // at most ~4096 chunks (one wavefront each)
+    c = ceil_div(c, 64) * 64;
+    if (c < 64) c = 64;
+    return (int)c;
+}
+
 void KMeansWork::reserve(size_t nx, int k) {
     sx.reserve(nx); sy.reserve(nx); sz.reserve(nx); sw.reserve(nx);
     assign.reserve(nx); sorted.reserve(nx);
-    int nchunks = (int)ceil_div(nx, kChunk);
+    const int nchunks = (int)ceil_div(nx, (size_t)chunk_len_for(nx));
     table.reserve((size_t)k * (size_t)(nchunks > 0 ? nchunks : 1));
-    rowtot.reserve(k); rowbase.reserve(k + 1);
+    rowtot.reserve(k);
     cent.reserve(3 * (size_t)k); hassign.reserve(k); c4.reserve(k);
     perm.reserve(nx);
     if (!mt.p) mt.reserve(1);
+    if (!ticket.p) { ticket.reserve(1); HIP_CHECK(hipMemset(ticket.p, 0, sizeof(unsigned int))); }
 }
 
 void kmeans_gather(const double *d_planar, size_t N, bool weighted, const int *d_perm, size_t nx, KMeansWork &w, hipStream_t s) {
@@ -328,33 +382,35 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     KmSamples ks{w.sx.p, w.sy.p, w.sz.p, w.sw.p};
     int nbits = 0;
     while ((1 << nbits) < k) nbits++;
-    const int nchunks = (int)ceil_div(nx, kChunk);
+    const int chunk_len = chunk_len_for(nx);
+    const int nchunks = (int)ceil_div(nx, (size_t)chunk_len);
     const int cblocks = (nchunks + 3) / 4;
-    const size_t lds = (size_t)4 * k * sizeof(unsigned int);
+    const size_t lds_cnt = (size_t)8 * k * sizeof(unsigned int);     // k float4 + 4 x k counters
+    const size_t lds_sct = (size_t)5 * k * sizeof(unsigned int);
     static bool attr = false;
     if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_count, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKMeansMaxK * 4));
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKMeansMaxK * 4));
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_count, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
         attr = true;
     }
+    { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (k + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p); }
     for (int it = 0; it < niter; it++) {
-        { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (k + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p); }
-        { KTIME("k_km_assign", s, 16.0 * nx); hipLaunchKernelGGL(k_km_assign, (int)ceil_div(nx, 256), 256, 0, s, ks, nx, w.c4.p, k, w.assign.p); }
-        { KTIME("k_km_count", s, 4.0 * nx); hipLaunchKernelGGL(k_km_count, cblocks, 256, lds, s, w.assign.p, nx, k, nbits, nchunks, w.table.p); }
+        {
+            KTIME("k_km_assign", s, 16.0 * nx);
+            hipLaunchKernelGGL(k_km_assign_count, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p);
+        }
         { KTIME("k_km_rowscan", s, 8.0 * k * nchunks); hipLaunchKernelGGL(k_km_rowscan, k, 256, 0, s, w.table.p, nchunks, w.rowtot.p); }
-        { KTIME("k_km_base", s, 12.0 * k); hipLaunchKernelGGL(k_km_base, 1, 256, 0, s, w.rowtot.p, k, w.rowbase.p); }
         {
             KTIME("k_km_scatter", s, (weighted ? 36.0 : 32.0) * nx);
-            if (weighted) hipLaunchKernelGGL(k_km_scatter<true>, cblocks, 256, lds, s, ks, w.assign.p, nx, k, nbits, nchunks, w.table.p, w.rowbase.p, w.sorted.p);
-            else hipLaunchKernelGGL(k_km_scatter<false>, cblocks, 256, lds, s, ks, w.assign.p, nx, k, nbits, nchunks, w.table.p, w.rowbase.p, w.sorted.p);
+            if (weighted) hipLaunchKernelGGL(k_km_scatter<true>, cblocks, 256, lds_sct, s, ks, w.assign.p, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+            else hipLaunchKernelGGL(k_km_scatter<false>, cblocks, 256, lds_sct, s, ks, w.assign.p, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
         }
         {
             KTIME("k_km_update", s, 16.0 * nx);
-            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 64, 0, s, w.sorted.p, w.rowbase.p, w.cent.p, w.hassign.p);
-            else hipLaunchKernelGGL(k_km_update<false>, k, 64, 0, s, w.sorted.p, w.rowbase.p, w.cent.p, w.hassign.p);
+            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 64, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+            else hipLaunchKernelGGL(k_km_update<false>, k, 64, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
         }
-        { KTIME("k_km_split", s, 16.0 * k); hipLaunchKernelGGL(k_km_split, 1, 64, 0, s, w.cent.p, w.hassign.p, k, (unsigned long long)nx, w.mt.p, (int *)nullptr); }
     }
     HIP_CHECK(hipGetLastError());
 }

@@ -7,6 +7,7 @@
 // of the global quantiser, and the greedy split selection (local.c:347-390) replayed over the
 // candidate tree the GPU evaluates in rounds.
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <memory>
@@ -97,6 +98,8 @@ struct Engine {
     PinBuf<double> h_dbl;
     PinBuf<unsigned char> h_bytes;
     KMeansWork km;
+    DevBuf<int> perm_dev;
+    size_t perm_N = 0, perm_nx = 0;
     patolette_amd__Stats stats{};
     std::string last_error;
 
@@ -216,10 +219,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     hipStream_t s = E.stream;
     const size_t planes = weighted ? 4 : 3;
     E.bufA.reserve(planes * N); E.bufB.reserve(planes * N); E.bkt.reserve(N);
-    const size_t max_nodes = 4 * K + 64;
-    E.nodes.reserve(max_nodes);
+    E.nodes.reserve(4 * K + 64);
     std::vector<HNode> hn;
-    hn.reserve(max_nodes);
+    hn.reserve(4 * K + 64);
     double t0 = now_ms();
 
     // ---------------- global quantiser (global.c:388-443) ----------------
@@ -352,6 +354,8 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
 
     // ---------------- local quantiser (local.c:318-404) ----------------
     std::vector<int> result(base_ids);                          // frontier in the reference's order
+    std::vector<int> leaves(base_ids);                          // candidate-tree nodes with moments but no split yet
+    const double spec_beta = 1.0 / 64;
     size_t count = result.size();
     E.stats.split_evals = 0; E.stats.split_px = 0; E.stats.lq_rounds = 0;
     auto known = [&](const HNode &h) { return h.nosplit || h.n <= 1 || h.split_done; };
@@ -384,24 +388,47 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 continue;
             }
             if (std::max(best >= 0 ? bv : 0.0, max_unknown) < kDelta) break;   // nothing can reach DELTA
-            // blocked: evaluate the splits of every undecided frontier node that could matter
-            const double thr = std::max(kDelta, 0.5 * (best >= 0 ? bv : 0.0));
-            round.clear();
-            for (size_t j = 0; j < count; j++) {
-                HNode &h = hn[result[j]];
-                if (!known(h) && h.dist >= thr) round.push_back(result[j]);
+            // blocked: evaluate, in ONE round, the split of every leaf of the candidate tree that could still
+            // matter -- undecided frontier nodes and, speculatively, the children of decided ones (a node's
+            // split depends only on its members, never on the greedy order).  Leaves whose distortion (an
+            // upper bound of their benefit) is far below the current best benefit are left for later; the
+            // exactness test above catches them if they ever become relevant.
+            const double ref_b = std::max(best >= 0 ? bv : 0.0, max_unknown);
+            double thr = std::max(kDelta, spec_beta * ref_b);
+            {
+                // exact pruning: with R commits left, a leaf whose distortion is below the R-th largest
+                // KNOWN frontier benefit can never be chosen (its own and all its descendants' benefits are
+                // bounded by that distortion, and R better candidates outlast the remaining commits)
+                const size_t R = K - count;
+                std::vector<double> kb;
+                for (size_t j = 0; j < count; j++) if (known(hn[result[j]])) kb.push_back(benefit(hn[result[j]]));
+                if (kb.size() >= R && R > 0) {
+                    std::nth_element(kb.begin(), kb.begin() + (R - 1), kb.end(), std::greater<double>());
+                    thr = std::max(thr, kb[R - 1] * (1.0 - 1e-9));
+                }
             }
-            if (round.empty()) {                                // cannot happen (max_unknown >= bv >= thr/0.5)
-                for (size_t j = 0; j < count; j++) if (!known(hn[result[j]])) round.push_back(result[j]);
+            round.clear();
+            {
+                std::vector<int> keep;
+                for (int id : leaves) {
+                    HNode &h = hn[id];
+                    if (known(h)) continue;                     // n <= 1 / nosplit: never split
+                    if (h.dist >= thr) round.push_back(id); else keep.push_back(id);
+                }
+                leaves.swap(keep);
+            }
+            if (round.empty()) {                                // every blocking node is a leaf with dist >= ref_b >= thr
+                throw HipError("patolette_amd: split loop blocked without candidates");
             }
             // axes on the host (dsyev semantics), children ids, device records
+            HIP_CHECK(hipStreamSynchronize(s));
+            E.nodes.grow(hn.size() + 2 * round.size() + 2, hn.size());
             std::vector<int> todo;
             std::vector<NodeDev> recs;
             std::vector<int> ids;
             for (int id : round) {
                 double ax[3];
                 if (!node_axis(hn[id], ax)) { hn[id].nosplit = true; continue; }
-                if (hn.size() + 2 > max_nodes) throw HipError("patolette_amd: node table overflow");
                 NodeDev d = make_nodedev(hn[id], bnd);
                 for (int j = 0; j < 3; j++) d.axis[j] = ax[j];
                 d.slot = (int)todo.size();
@@ -446,6 +473,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 absorb_moments(c, d);
             }
             for (int id : todo) { hn[id].split_done = true; E.stats.split_evals++; E.stats.split_px += hn[id].n; }
+            for (int id : cids) leaves.push_back(id);
             E.stats.lq_rounds++;
         }
         result.resize(count);
@@ -478,11 +506,17 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
         E.km.reserve(nx, (int)k);
         const int *dperm = nullptr;
         if (sub) {
-            std::vector<int32_t> perm(nx);
-            hm::rand_perm_prefix(N, nx, 1234u, perm.data());                       // random.cpp:184-194, seed 1234
-            HIP_CHECK(hipMemcpyAsync(E.km.perm.p, perm.data(), nx * sizeof(int), hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            dperm = E.km.perm.p;
+            // faiss draws the subsample from rand_perm(N, seed 1234): a pure function of (N, nx), so the
+            // index list is kept on the device between calls (a batch of same-sized images pays once)
+            if (E.perm_N != N || E.perm_nx != nx) {
+                std::vector<int32_t> perm(nx);
+                hm::rand_perm_prefix(N, nx, 1234u, perm.data());                   // random.cpp:184-194
+                E.perm_dev.reserve(nx);
+                HIP_CHECK(hipMemcpyAsync(E.perm_dev.p, perm.data(), nx * sizeof(int), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                E.perm_N = N; E.perm_nx = nx;
+            }
+            dperm = E.perm_dev.p;
         }
         if (nx == k) {                                                             // Clustering.cpp:331-352: centroids = first k input vectors
             std::vector<double> first(3 * k);
