@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -50,11 +51,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.config in ("c4",) and world > 1:
+        pass
 
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
@@ -83,16 +87,26 @@ def main():
             q = L.patolette_amd_malloc(n * 8)
             assert L.patolette_amd_fill_weights(q, n, 100 * rank + i) == 0
             d_wts.append(q)
-    d_map = L.patolette_amd_malloc(n)          # K <= 256 -> u8 index map left in HBM
     import numpy as np
+    pals = np.zeros((args.steps + args.warmup, K, 3), dtype=np.float64)
     pal = np.zeros((K, 3), dtype=np.float64, order="F")
     code = C.c_int(0)
+    if dist is not None:
+        # index maps (u8, K <= 256) of every step stay in HBM in a torch tensor the library writes into
+        # directly, so the final RCCL gather needs no staging copy
+        maps_t = torch.empty((args.steps, n), dtype=torch.uint8, device="cuda")
+        warm_t = torch.empty((n,), dtype=torch.uint8, device="cuda")
+        map_ptr = lambda i: (maps_t[i - args.warmup].data_ptr() if i >= args.warmup else warm_t.data_ptr())
+    else:
+        d_map = L.patolette_amd_malloc(n)      # K <= 256 -> u8 index map left in HBM
+        map_ptr = lambda i: d_map
 
     def step(i):
         L.patolette_amd_device(width, height, d_imgs[i % pool], d_wts[i % pool] if weighted else None, K, C.byref(opts),
-                               pal.ctypes.data_as(_native.dp), d_map, 1, C.byref(code))
+                               pal.ctypes.data_as(_native.dp), map_ptr(i), 1, C.byref(code))
         if code.value != 0:
             raise SystemExit("bench.py: quantisation failed: %s" % _native.last_error())
+        pals[i] = pal
 
     def barrier():
         L.patolette_amd_synchronize()
@@ -109,8 +123,16 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     L.patolette_amd_synchronize()
+    gathered = None
     if dist is not None:
+        # the only collective of the job: final gather of the results to rank 0 over RCCL/xGMI
+        pal_t = torch.from_numpy(pals[args.warmup:]).to("cuda")
+        gl_m = [torch.empty_like(maps_t) for _ in range(world)] if rank == 0 else None
+        gl_p = [torch.empty_like(pal_t) for _ in range(world)] if rank == 0 else None
+        dist.gather(maps_t, gl_m, dst=0)
+        dist.gather(pal_t, gl_p, dst=0)
         torch.cuda.synchronize()
+        gathered = (gl_m, gl_p)
     elapsed = time.perf_counter() - t0
     stats = _native.last_stats()
     prof = _native.profile_results() if not args.no_profile else {}
@@ -170,7 +192,8 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "width": width, "height": height, "palette_size": K, "images_per_step_per_gpu": 1,
                    "input": "uniform random sRGB (splitmix64), planar f64, resident in HBM; index map left in HBM as u8",
-                   "kernel_events_in_timed_region": not args.no_profile},
+                   "kernel_events_in_timed_region": not args.no_profile,
+                   "final_gather": ("RCCL gather of u8 maps + f64 palettes to rank 0, inside the timed region" if dist is not None else "none (1 GPU)")},
         "roofline": roofline, "cpu_baseline": cpu,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
