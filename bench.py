@@ -51,8 +51,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    if args.config in ("c4",) and world > 1:
-        pass
 
     dist = None
     torch = None
