@@ -7,8 +7,13 @@ namespace pamd {
 
 // colours: planar, plane p at d_colors + p*plane_stride, n pixels mapped; palette planar (k,3);
 // output elements of elem_bytes (1, 4 or 8)
+struct NNWork {                        // scratch of the pruned NN map
+    DevBuf<unsigned char> lut;         // per grid cell: 32 candidate slots (u8 or u16), count in the last
+    DevBuf<unsigned long long> keys;   // min/max keys when the caller has no bounds
+};
+// lo/hi: exact per-plane min/max of the colours if known (else nullptr: computed with one more pass)
 void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k,
-                   void *d_out, int elem_bytes, hipStream_t s);
+                   void *d_out, int elem_bytes, const double *lo, const double *hi, NNWork &w, hipStream_t s);
 void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
                    void *d_out, int elem_bytes, hipStream_t s);
 

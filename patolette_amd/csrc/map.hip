@@ -39,15 +39,262 @@ __global__ __launch_bounds__(256) void k_nn_map(const double *__restrict__ c, si
     }
 }
 
-void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k, void *d_out, int elem_bytes, hipStream_t s) {
+// --------------------------------------------------------------------------------------------
+// Exact pruning for the NN map.  Brute force is 256 x 8 f64 flops per 25 algorithmic bytes
+// (~7x over the f64 ridge): to be HBM-bound the kernel may only evaluate a handful of candidates
+// per pixel, and to stay bit-exact the pruning must be provably lossless.
+//
+// A G^3 grid covers the pixels' bounding box.  For a cell C, U(C) = min_k maxdist^2(C, p_k) bounds the
+// nearest distance of every x in C from above, so any entry j with mindist^2(C, p_j) > U(C) is strictly
+// farther than the winner for all x in C and can be dropped.  Cell boxes are widened by 1e-9 of the
+// range (cell index arithmetic rounds) and the test carries a 1e-12 relative margin, 9 orders above
+// the f64 rounding of the distance expression, so the arg-min over the COMPUTED distances --
+// including exact ties, kept in ascending index order -- is unchanged.  Cells whose list overflows
+// fall back to the full scan.  (32^3 grid -> ~3 candidates per pixel.)
+// --------------------------------------------------------------------------------------------
+constexpr int kLutMax = 30;                  // candidates kept per cell: 15 in the primary record, 15 in the secondary
+
+struct NNGrid {
+    double lo[3], cw[3], inv[3];             // cell (i,j,k) spans lo + i*cw .. lo + (i+1)*cw
+    int G;
+};
+
+// Per cell two records of 16 entries: primary = [count, c0..c14], secondary = [c15..c29, unused].
+// count = 255 marks overflow (full scan).  One 16-byte (u8) / 32-byte (u16) load serves almost every pixel.
+template <typename CandT>
+__global__ __launch_bounds__(256) void k_nn_lut_build(const double *__restrict__ pal, int k, NNGrid g, CandT *__restrict__ lut,
+                                                      CandT *__restrict__ lut2) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncell = g.G * g.G * g.G;
+    if (cell >= ncell) return;
+    int idx[3] = {cell % g.G, (cell / g.G) % g.G, cell / (g.G * g.G)};
+    double cl[3], ch[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double m = 1e-9 * (g.cw[a] * g.G) + 1e-300;
+        cl[a] = g.lo[a] + idx[a] * g.cw[a] - m;
+        ch[a] = g.lo[a] + (idx[a] + 1) * g.cw[a] + m;
+    }
+    const double *px = pal, *py = pal + k, *pz = pal + 2 * k;
+    double U = INFINITY;
+    for (int j = 0; j < k; j++) {
+        const double p[3] = {px[j], py[j], pz[j]};
+        double mx = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - cl[a]), fabs(p[a] - ch[a])); mx += d * d; }
+        U = fmin(U, mx);
+    }
+    const double thr = U * (1.0 + 1e-12) + 1e-300;
+    CandT *rec = lut + (size_t)cell * 16, *rec2 = lut2 + (size_t)cell * 16;
+    int cnt = 0;
+    for (int j = 0; j < k; j++) {
+        const double p[3] = {px[j], py[j], pz[j]};
+        double mn = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0); mn += d * d; }
+        if (mn <= thr) {
+            if (cnt < 15) rec[1 + cnt] = (CandT)j;
+            else if (cnt < kLutMax) rec2[cnt - 15] = (CandT)j;
+            cnt++;
+        }
+    }
+    rec[0] = (CandT)(cnt <= kLutMax ? cnt : 255);              // 255 = overflow -> full scan
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// A cell record consumed front to back by shifting (no dynamic register indexing -> no scratch).
+template <typename CandT> struct LutRec;
+template <> struct LutRec<unsigned char> {
+    unsigned long long w0, w1;
+    int left;
+    __device__ __forceinline__ void load(const unsigned char *p) { const uint4 v = *(const uint4 *)p; w0 = ((unsigned long long)v.y << 32) | v.x; w1 = ((unsigned long long)v.w << 32) | v.z; left = 8; }
+    __device__ __forceinline__ int next() {
+        const int r = (int)(w0 & 0xffULL);
+        w0 >>= 8;
+        if (--left == 0) { w0 = w1; left = 8; }
+        return r;
+    }
+};
+template <> struct LutRec<unsigned short> {
+    unsigned long long w0, w1, w2, w3;
+    int left;
+    __device__ __forceinline__ void load(const unsigned short *p) {
+        const uint4 a = *(const uint4 *)p, b = *((const uint4 *)p + 1);
+        w0 = ((unsigned long long)a.y << 32) | a.x; w1 = ((unsigned long long)a.w << 32) | a.z;
+        w2 = ((unsigned long long)b.y << 32) | b.x; w3 = ((unsigned long long)b.w << 32) | b.z;
+        left = 4;
+    }
+    __device__ __forceinline__ int next() {
+        const int r = (int)(w0 & 0xffffULL);
+        w0 >>= 16;
+        if (--left == 0) { w0 = w1; w1 = w2; w2 = w3; left = 4; }
+        return r;
+    }
+};
+
+template <typename CandT>
+__device__ __forceinline__ int nn_eval(const double x, const double y, const double z, LutRec<CandT> rec, const size_t cell,
+                                       const CandT *__restrict__ lut2, const double4 *sp, const int k) {
+    const int cnt = rec.next();                                  // entry 0 = count
+    double bd = INFINITY; int best = 0;
+    if (cnt != 255) {
+        const int n1 = cnt < 15 ? cnt : 15;
+        for (int t = 0; t < n1; t++) {
+            const int j = rec.next();
+            const double4 p = sp[j];
+            const double d0 = x - p.x, d1 = y - p.y, d2 = z - p.z;
+            const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+            if (d < bd) { bd = d; best = j; }                   // ascending j + strict '<' = lowest index on ties
+        }
+        if (cnt > 15) {
+            LutRec<CandT> r2;
+            r2.load(lut2 + cell * 16);
+            for (int t = 15; t < cnt; t++) {
+                const int j = r2.next();
+                const double4 p = sp[j];
+            const double d0 = x - p.x, d1 = y - p.y, d2 = z - p.z;
+                const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+                if (d < bd) { bd = d; best = j; }
+            }
+        }
+    } else {
+        for (int j = 0; j < k; j++) {
+            const double4 p = sp[j];
+            const double d0 = x - p.x, d1 = y - p.y, d2 = z - p.z;
+            const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+            if (d < bd) { bd = d; best = j; }
+        }
+    }
+    return best;
+}
+
+__device__ __forceinline__ size_t nn_cell(const double x, const double y, const double z, const int G, const double lo0, const double lo1,
+                                          const double lo2, const double in0, const double in1, const double in2) {
+    int ix = (int)((x - lo0) * in0), iy = (int)((y - lo1) * in1), iz = (int)((z - lo2) * in2);
+    ix = ix < 0 ? 0 : (ix >= G ? G - 1 : ix);
+    iy = iy < 0 ? 0 : (iy >= G ? G - 1 : iy);
+    iz = iz < 0 ? 0 : (iz >= G ? G - 1 : iz);
+    return (size_t)(iz * G + iy) * G + ix;
+}
+
+template <typename OutT, typename CandT>
+__global__ __launch_bounds__(256) void k_nn_map_lut(const double *__restrict__ c, size_t N, size_t n, const double *__restrict__ pal, int k,
+                                                    NNGrid g, const CandT *__restrict__ lut, const CandT *__restrict__ lut2,
+                                                    OutT *__restrict__ out) {
+    extern __shared__ double4 spal[];                          // [k] {x, y, z, 0}: one ds_read_b128 + one ds_read_b64 per candidate
+    for (int j = threadIdx.x; j < k; j += blockDim.x) spal[j] = make_double4(pal[j], pal[k + j], pal[2 * k + j], 0.0);
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int G = g.G;
+    const double lo0 = g.lo[0], lo1 = g.lo[1], lo2 = g.lo[2], in0 = g.inv[0], in1 = g.inv[1], in2 = g.inv[2];
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 2 * stride) {
+        // two independent pixels per trip: both cell records are in flight before either is consumed
+        const size_t i1 = i0 + stride;
+        const bool ok1 = i1 < n;
+        const size_t j1 = ok1 ? i1 : i0;
+        const double x0 = c[i0], y0 = c[N + i0], z0 = c[2 * N + i0];
+        const double x1 = c[j1], y1 = c[N + j1], z1 = c[2 * N + j1];
+        const size_t c0 = nn_cell(x0, y0, z0, G, lo0, lo1, lo2, in0, in1, in2), c1 = nn_cell(x1, y1, z1, G, lo0, lo1, lo2, in0, in1, in2);
+        LutRec<CandT> r0, r1;
+        r0.load(lut + c0 * 16);
+        r1.load(lut + c1 * 16);
+        const int b0 = nn_eval<CandT>(x0, y0, z0, r0, c0, lut2, spal, k);
+        out[i0] = (OutT)b0;
+        const int b1 = nn_eval<CandT>(x1, y1, z1, r1, c1, lut2, spal, k);
+        if (ok1) out[i1] = (OutT)b1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_minmax3(const double *__restrict__ c, size_t N, size_t n, unsigned long long *keys /* min[3], max[3] */) {
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const double v = c[a * N + i]; mn[a] = fmin(mn[a], v); mx[a] = fmax(mx[a], v); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_down(lo, o, 64)); hi = fmax(hi, __shfl_down(hi, o, 64)); }
+        if ((threadIdx.x & 63) == 0 && lo <= hi) { atomicMin(&keys[a], f64_key(lo)); atomicMax(&keys[3 + a], f64_key(hi)); }
+    }
+}
+
+static int stream_blocks(size_t n, int per_cu) {
     size_t g = ceil_div(n, 256);
-    if (g > 256 * 32) g = 256 * 32;
+    if (g > (size_t)256 * per_cu) g = (size_t)256 * per_cu;
     if (g < 1) g = 1;
-    KTIME("k_nn_map", s, (24.0 + elem_bytes) * n);
-    if (elem_bytes == 1) hipLaunchKernelGGL(k_nn_map<unsigned char>, (int)g, 256, 0, s, d_colors, plane_stride, n, d_pal, k, (unsigned char *)d_out);
-    else if (elem_bytes == 4) hipLaunchKernelGGL(k_nn_map<unsigned int>, (int)g, 256, 0, s, d_colors, plane_stride, n, d_pal, k, (unsigned int *)d_out);
-    else if (elem_bytes == 8) hipLaunchKernelGGL(k_nn_map<unsigned long long>, (int)g, 256, 0, s, d_colors, plane_stride, n, d_pal, k, (unsigned long long *)d_out);
-    else throw HipError("patolette_amd: map element size must be 1, 4 or 8");
+    return (int)g;
+}
+
+template <typename OutT>
+static void launch_nn_brute(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k, OutT *out, hipStream_t s) {
+    KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
+    hipLaunchKernelGGL(k_nn_map<OutT>, stream_blocks(n, 32), 256, 0, s, d_colors, plane_stride, n, d_pal, k, out);
+}
+
+template <typename OutT>
+static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k, OutT *out,
+                          const NNGrid &g, NNWork &w, hipStream_t s) {
+    const int ncell = g.G * g.G * g.G;
+    const size_t lds = (size_t)4 * k * sizeof(double);
+    if (k <= 256) {
+        w.lut.reserve((size_t)ncell * 32);
+        unsigned char *l1 = w.lut.p, *l2 = w.lut.p + (size_t)ncell * 16;
+        { KTIME("k_nn_lut_build", s, 32.0 * ncell); hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, (ncell + 255) / 256, 256, 0, s, d_pal, k, g, l1, l2); }
+        KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
+        hipLaunchKernelGGL((k_nn_map_lut<OutT, unsigned char>), stream_blocks(n, 8), 256, lds, s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned char *)l1, (const unsigned char *)l2, out);
+    } else {
+        w.lut.reserve((size_t)ncell * 64);
+        unsigned short *l16 = (unsigned short *)w.lut.p, *l16b = l16 + (size_t)ncell * 16;
+        { KTIME("k_nn_lut_build", s, 64.0 * ncell); hipLaunchKernelGGL(k_nn_lut_build<unsigned short>, (ncell + 255) / 256, 256, 0, s, d_pal, k, g, l16, l16b); }
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_lut<OutT, unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
+            attr = true;
+        }
+        KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
+        hipLaunchKernelGGL((k_nn_map_lut<OutT, unsigned short>), stream_blocks(n, 8), 256, lds, s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned short *)l16, (const unsigned short *)l16b, out);
+    }
+}
+
+// lo/hi: per-plane bounds of the colours (exact min/max), or nullptr to have them computed here
+void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k, void *d_out, int elem_bytes,
+                   const double *lo, const double *hi, NNWork &w, hipStream_t s) {
+    if (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8) throw HipError("patolette_amd: map element size must be 1, 4 or 8");
+    const bool use_lut = n >= 16384 && k >= 8 && k <= 4096;
+    if (!use_lut) {
+        if (elem_bytes == 1) launch_nn_brute<unsigned char>(d_colors, plane_stride, n, d_pal, k, (unsigned char *)d_out, s);
+        else if (elem_bytes == 4) launch_nn_brute<unsigned int>(d_colors, plane_stride, n, d_pal, k, (unsigned int *)d_out, s);
+        else launch_nn_brute<unsigned long long>(d_colors, plane_stride, n, d_pal, k, (unsigned long long *)d_out, s);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    double blo[3], bhi[3];
+    if (lo && hi) { for (int a = 0; a < 3; a++) { blo[a] = lo[a]; bhi[a] = hi[a]; } }
+    else {
+        w.keys.reserve(6);
+        unsigned long long init[6] = {~0ULL, ~0ULL, ~0ULL, 0ULL, 0ULL, 0ULL}, got[6];
+        HIP_CHECK(hipMemcpyAsync(w.keys.p, init, sizeof init, hipMemcpyHostToDevice, s));
+        { KTIME("k_minmax3", s, 24.0 * n); hipLaunchKernelGGL(k_minmax3, stream_blocks(n, 16), 256, 0, s, d_colors, plane_stride, n, w.keys.p); }
+        HIP_CHECK(hipMemcpyAsync(got, w.keys.p, sizeof got, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (int a = 0; a < 3; a++) { blo[a] = key_f64(got[a]); bhi[a] = key_f64(got[3 + a]); }
+    }
+    NNGrid g;
+    g.G = n >= ((size_t)1 << 22) ? 64 : 32;
+    for (int a = 0; a < 3; a++) {
+        double r = bhi[a] - blo[a];
+        if (!(r > 0) || !std::isfinite(r)) r = 0;
+        g.lo[a] = blo[a];
+        g.cw[a] = r / g.G;
+        g.inv[a] = r > 0 ? g.G / r : 0.0;
+    }
+    if (elem_bytes == 1) launch_nn_lut<unsigned char>(d_colors, plane_stride, n, d_pal, k, (unsigned char *)d_out, g, w, s);
+    else if (elem_bytes == 4) launch_nn_lut<unsigned int>(d_colors, plane_stride, n, d_pal, k, (unsigned int *)d_out, g, w, s);
+    else launch_nn_lut<unsigned long long>(d_colors, plane_stride, n, d_pal, k, (unsigned long long *)d_out, g, w, s);
     HIP_CHECK(hipGetLastError());
 }
 

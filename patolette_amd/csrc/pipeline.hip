@@ -62,16 +62,33 @@ void KernelTimer::reset() { collect(); names.clear(); total_ms.clear(); total_by
 // --------------------------------------------------------------------------------------------
 // node table scatter / gather (host mirror <-> device table) in one copy + one tiny kernel
 // --------------------------------------------------------------------------------------------
-__global__ void k_put_nodes(NodeDev *table, const NodeDev *stage, const int *ids, int n) {
+__global__ void k_put_nodes(NodeDev *table, const NodeIn *stage, const int *ids, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) table[ids[i]] = stage[i];
+    if (i >= n) return;
+    const NodeIn in = stage[i];
+    NodeDev &d = table[ids[i]];
+    d.begin = in.begin; d.n = in.n; d.buf = in.buf; d.slot = in.slot; d.child0 = in.child0; d.nchild = in.nchild;
+    for (int j = 0; j < 3; j++) { d.axis[j] = in.axis[j]; d.mean[j] = in.mean[j]; }
+    d.sw = in.sw; d.klin = in.klin; d.kquad = in.kquad;
+    node_reset_outputs(d);
 }
-__global__ void k_get_nodes(const NodeDev *table, NodeDev *stage, const int *ids, int n) {
+__global__ void k_get_nodes(const NodeDev *table, NodeOut *stage, const int *ids, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) stage[i] = table[ids[i]];
+    if (i >= n) return;
+    const NodeDev &d = table[ids[i]];
+    NodeOut o;
+    o.begin = d.begin; o.n = d.n; o.buf = d.buf; o.degenerate = d.degenerate; o.split = d.split; o.pad = 0;
+    o.sw = d.sw;
+    for (int j = 0; j < 3; j++) o.mean[j] = d.mean[j];
+    for (int q = 0; q < 7; q++) {                          // slot sums are exact (binned parts), any order
+        double s0 = 0, s1 = 0;
+        for (int k = 0; k < kSlots; k++) { s0 += d.acc[k][q][0]; s1 += d.acc[k][q][1]; }
+        o.acc[q][0] = s0; o.acc[q][1] = s1;
+    }
+    stage[i] = o;
 }
 
-struct Bounds { double cmax, range, wmax; int e_lin, e_quad; };
+struct Bounds { double cmax, range, wmax; int e_lin, e_quad; double lo[3], hi[3]; };
 
 static int exp_bound(double v) {                 // smallest E with 2^E > v (v > 0)
     if (!(v > 0) || !std::isfinite(v)) return 1;
@@ -84,7 +101,9 @@ struct Engine {
     hipStream_t stream = nullptr;
     DevBuf<double> src, wsrc, cvt, bufA, bufB, aux;
     DevBuf<unsigned short> bkt;
-    DevBuf<NodeDev> nodes, stage;
+    DevBuf<NodeDev> nodes;
+    DevBuf<NodeIn> stage_in;
+    DevBuf<NodeOut> stage_out;
     DevBuf<int> ids, round_nodes, node_tile0;
     DevBuf<Tile> tilesA, tilesP;
     DevBuf<double> hist, sum6, dpal;
@@ -92,12 +111,14 @@ struct Engine {
     DevBuf<unsigned int> hcount, tilecnt;
     DevBuf<unsigned char> lut, dmap;
     DevBuf<ConvertStats> cstats;
-    PinBuf<NodeDev> h_stage;
+    PinBuf<NodeIn> h_stage_in;
+    PinBuf<NodeOut> h_stage_out;
     PinBuf<int> h_ids;
     PinBuf<Tile> h_tiles;
     PinBuf<double> h_dbl;
     PinBuf<unsigned char> h_bytes;
     KMeansWork km;
+    NNWork nn;
     DevBuf<int> perm_dev;
     size_t perm_N = 0, perm_nx = 0;
     patolette_amd__Stats stats{};
@@ -148,8 +169,8 @@ static void build_tiles(const std::vector<int> &round, const std::vector<HNode> 
     if (tile0) tile0->push_back((int)out.size());
 }
 
-static NodeDev make_nodedev(const HNode &h, const Bounds &b) {
-    NodeDev d;
+static NodeIn make_nodedev(const HNode &h, const Bounds &b) {
+    NodeIn d;
     std::memset(&d, 0, sizeof d);
     d.begin = h.begin; d.n = h.n; d.buf = h.buf; d.slot = -1; d.child0 = -1; d.nchild = 0;
     for (int j = 0; j < 3; j++) d.mean[j] = h.mean[j];
@@ -158,7 +179,6 @@ static NodeDev make_nodedev(const HNode &h, const Bounds &b) {
     while ((1ULL << P) < (h.n > 1 ? h.n : 2)) P++;
     d.klin = make_bink(b.e_lin, P);
     d.kquad = make_bink(b.e_quad, P);
-    d.minkey = ~0ULL; d.maxkey = 0ULL; d.split = -1;
     return d;
 }
 
@@ -171,34 +191,34 @@ static void upload_tiles(Engine &E, const std::vector<Tile> &t, DevBuf<Tile> &ds
     HIP_CHECK(hipStreamSynchronize(E.stream));     // h_tiles is reused right away
 }
 
-static void put_nodes(Engine &E, const std::vector<int> &ids, const std::vector<NodeDev> &recs) {
+static void put_nodes(Engine &E, const std::vector<int> &ids, const std::vector<NodeIn> &recs) {
     const int n = (int)ids.size();
     if (!n) return;
-    E.stage.reserve(n); E.ids.reserve(n); E.h_stage.reserve(n); E.h_ids.reserve(n);
-    std::memcpy(E.h_stage.p, recs.data(), n * sizeof(NodeDev));
+    E.stage_in.reserve(n); E.ids.reserve(n); E.h_stage_in.reserve(n); E.h_ids.reserve(n);
+    std::memcpy(E.h_stage_in.p, recs.data(), n * sizeof(NodeIn));
     std::memcpy(E.h_ids.p, ids.data(), n * sizeof(int));
-    HIP_CHECK(hipMemcpyAsync(E.stage.p, E.h_stage.p, n * sizeof(NodeDev), hipMemcpyHostToDevice, E.stream));
+    HIP_CHECK(hipMemcpyAsync(E.stage_in.p, E.h_stage_in.p, n * sizeof(NodeIn), hipMemcpyHostToDevice, E.stream));
     HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
-    hipLaunchKernelGGL(k_put_nodes, (n + 255) / 256, 256, 0, E.stream, E.nodes.p, E.stage.p, E.ids.p, n);
+    hipLaunchKernelGGL(k_put_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.stage_in.p, E.ids.p, n);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(E.stream));
 }
 
-static void get_nodes(Engine &E, const std::vector<int> &ids, std::vector<NodeDev> &recs) {
+static void get_nodes(Engine &E, const std::vector<int> &ids, std::vector<NodeOut> &recs) {
     const int n = (int)ids.size();
     recs.resize(n);
     if (!n) return;
-    E.stage.reserve(n); E.ids.reserve(n); E.h_stage.reserve(n); E.h_ids.reserve(n);
+    E.stage_out.reserve(n); E.ids.reserve(n); E.h_stage_out.reserve(n); E.h_ids.reserve(n);
     std::memcpy(E.h_ids.p, ids.data(), n * sizeof(int));
     HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
-    hipLaunchKernelGGL(k_get_nodes, (n + 255) / 256, 256, 0, E.stream, E.nodes.p, E.stage.p, E.ids.p, n);
+    hipLaunchKernelGGL(k_get_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.stage_out.p, E.ids.p, n);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(E.h_stage.p, E.stage.p, n * sizeof(NodeDev), hipMemcpyDeviceToHost, E.stream));
+    HIP_CHECK(hipMemcpyAsync(E.h_stage_out.p, E.stage_out.p, n * sizeof(NodeOut), hipMemcpyDeviceToHost, E.stream));
     E.sync();
-    std::memcpy(recs.data(), E.h_stage.p, n * sizeof(NodeDev));
+    std::memcpy(recs.data(), E.h_stage_out.p, n * sizeof(NodeOut));
 }
 
-static void absorb_moments(HNode &h, const NodeDev &d) {
+static void absorb_moments(HNode &h, const NodeOut &d) {
     for (int q = 0; q < 6; q++) h.cov6[q] = d.acc[q][0] + d.acc[q][1];
     h.dist = d.acc[6][0] + d.acc[6][1];
 }
@@ -246,11 +266,11 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     build_tiles(round, hn, kTileA, tA, nullptr);
     upload_tiles(E, tA, E.tilesA);
     {
-        NodeDev d = make_nodedev(hn[0], bnd);
+        NodeIn d = make_nodedev(hn[0], bnd);
         put_nodes(E, {0}, {d});
     }
     launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
-    std::vector<NodeDev> got;
+    std::vector<NodeOut> got;
     get_nodes(E, {0}, got);
     absorb_moments(hn[0], got[0]);
     double axis[3];
@@ -258,7 +278,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
 
     // projection, 512 buckets, cell moments (sort.c, cells.c:53-139)
     {
-        NodeDev d = make_nodedev(hn[0], bnd);
+        NodeIn d = make_nodedev(hn[0], bnd);
         for (int j = 0; j < 3; j++) d.axis[j] = axis[j];
         d.slot = 0;
         put_nodes(E, {0}, {d});
@@ -327,12 +347,12 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         }
     }
     {
-        NodeDev d = make_nodedev(hn[0], bnd);
+        NodeIn d = make_nodedev(hn[0], bnd);
         for (int j = 0; j < 3; j++) d.axis[j] = axis[j];
         d.slot = 0; d.child0 = base_ids[0]; d.nchild = kbase;
         std::vector<int> ids = {0};
-        std::vector<NodeDev> recs = {d};
-        for (int id : base_ids) { ids.push_back(id); NodeDev c = make_nodedev(hn[id], bnd); c.klin = d.klin; c.kquad = d.kquad; recs.push_back(c); }
+        std::vector<NodeIn> recs = {d};
+        for (int id : base_ids) { ids.push_back(id); NodeIn c = make_nodedev(hn[id], bnd); c.klin = d.klin; c.kquad = d.kquad; recs.push_back(c); }
         put_nodes(E, ids, recs);
     }
     HIP_CHECK(hipMemcpyAsync(E.lut.p, lut.data(), kBuckets, hipMemcpyHostToDevice, s));
@@ -344,7 +364,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     HIP_CHECK(hipMemcpyAsync(E.node_tile0.p, tile0.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));
     E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
-    launch_partition(qroot, E.tilesP.p, (int)tP.size(), N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, s);
+    launch_partition(qroot, E.tilesP.p, (int)tP.size(), N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, false, s);
     launch_cov_children(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
     get_nodes(E, base_ids, got);
     for (size_t i = 0; i < base_ids.size(); i++) absorb_moments(hn[base_ids[i]], got[i]);
@@ -424,12 +444,12 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             HIP_CHECK(hipStreamSynchronize(s));
             E.nodes.grow(hn.size() + 2 * round.size() + 2, hn.size());
             std::vector<int> todo;
-            std::vector<NodeDev> recs;
+            std::vector<NodeIn> recs;
             std::vector<int> ids;
             for (int id : round) {
                 double ax[3];
                 if (!node_axis(hn[id], ax)) { hn[id].nosplit = true; continue; }
-                NodeDev d = make_nodedev(hn[id], bnd);
+                NodeIn d = make_nodedev(hn[id], bnd);
                 for (int j = 0; j < 3; j++) d.axis[j] = ax[j];
                 d.slot = (int)todo.size();
                 d.child0 = (int)hn.size(); d.nchild = 2;
@@ -460,14 +480,13 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             launch_minmax(qlq, E.tilesA.p, (int)tA.size(), rpx, E.nodes.p, s);
             launch_hist(qlq, false, E.tilesA.p, (int)tA.size(), rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
             launch_cut(weighted, E.nodes.p, E.round_nodes.p, nr, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s);
-            launch_partition(qlq, E.tilesP.p, (int)tP.size(), rpx, E.round_nodes.p, E.node_tile0.p, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, s);
-            launch_cov_children(qlq, E.tilesA.p, (int)tA.size(), rpx, E.nodes.p, s);
+            launch_partition(qlq, E.tilesP.p, (int)tP.size(), rpx, E.round_nodes.p, E.node_tile0.p, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s);
             std::vector<int> cids;
             for (int id : todo) { cids.push_back(hn[id].left); cids.push_back(hn[id].right); }
             get_nodes(E, cids, got);
             for (size_t i = 0; i < cids.size(); i++) {
                 HNode &c = hn[cids[i]];
-                const NodeDev &d = got[i];
+                const NodeOut &d = got[i];
                 c.begin = d.begin; c.n = d.n; c.buf = d.buf; c.sw = d.sw;
                 for (int j = 0; j < 3; j++) c.mean[j] = d.mean[j];
                 absorb_moments(c, d);
@@ -552,6 +571,7 @@ static Bounds read_bounds(Engine &E, bool weighted) {
     for (int p = 0; p < 3; p++) {
         double mn = key_f64(cs.minkey[p]), mx = key_f64(cs.maxkey[p]);
         if (!(mn <= mx)) { mn = 0; mx = 0; }
+        b.lo[p] = mn; b.hi[p] = mx;
         b.cmax = std::max(b.cmax, std::max(std::fabs(mn), std::fabs(mx)));
         b.range = std::max(b.range, mx - mn);
     }
@@ -616,9 +636,13 @@ static void run_device(Engine &E, size_t width, size_t height, const double *d_d
             palette_rows(pal, len, hm::color::rec2020_to_srgb);
         } else {                                                               // patolette.c:300-324
             const double *pixels = E.cvt.p;
+            const double *blo = bnd.lo, *bhi = bnd.hi;                         // exact min/max of the pixels being mapped
+            Bounds b2;
             if (opt->color_space == patolette__CIELuv) {
                 E.aux.reserve(3 * N);
-                launch_convert(PAMD_CIELUV_TO_ICTCP, E.cvt.p, E.aux.p, N, nullptr, s);
+                launch_convert(PAMD_CIELUV_TO_ICTCP, E.cvt.p, E.aux.p, N, E.cstats.p, s);
+                b2 = read_bounds(E, false);
+                blo = b2.lo; bhi = b2.hi;
                 pixels = E.aux.p;
                 palette_rows(pal, len, hm::color::cieluv_to_rec2020);
                 palette_rows(pal, len, hm::color::rec2020_to_srgb);
@@ -626,7 +650,7 @@ static void run_device(Engine &E, size_t width, size_t height, const double *d_d
             }
             HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
             HIP_CHECK(hipStreamSynchronize(s));
-            launch_nn_map(pixels, N, N, E.dpal.p, (int)len, d_map, map_elem, s);
+            launch_nn_map(pixels, N, N, E.dpal.p, (int)len, d_map, map_elem, blo, bhi, E.nn, s);
             palette_rows(pal, len, hm::color::ictcp_to_rec2020);
             palette_rows(pal, len, hm::color::rec2020_to_srgb);
         }
@@ -840,7 +864,7 @@ int patolette_amd_nn_map(const double *colors, size_t n, const double *palette, 
     E.src.reserve(3 * n); E.dpal.reserve(3 * k); E.dmap.reserve(n * 4);
     HIP_CHECK(hipMemcpy(E.src.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(E.dpal.p, palette, 3 * k * sizeof(double), hipMemcpyHostToDevice));
-    launch_nn_map(E.src.p, n, n, E.dpal.p, (int)k, E.dmap.p, 4, E.stream);
+    launch_nn_map(E.src.p, n, n, E.dpal.p, (int)k, E.dmap.p, 4, nullptr, nullptr, E.nn, E.stream);
     E.sync();
     std::vector<unsigned int> tmp(n);
     HIP_CHECK(hipMemcpy(tmp.data(), E.dmap.p, n * 4, hipMemcpyDeviceToHost));

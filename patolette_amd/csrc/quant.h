@@ -16,6 +16,24 @@ constexpr int kTileP = 2048;           // pixels per block for the stable partit
 constexpr int kNQ_LQ = 4;
 constexpr int kNQ_GQ = 14;
 
+constexpr int kSlots = 16;             // accumulator copies per node: same-address atomics serialise in L2, so tiles
+                                       // of one node spread over kSlots addresses; slots are summed (exactly) on read-out
+
+// host -> device (k_put_nodes)
+struct NodeIn {
+    unsigned long long begin, n;
+    int buf, slot, child0, nchild;
+    double axis[3], mean[3], sw;
+    BinK klin, kquad;
+};
+// device -> host (k_get_nodes)
+struct NodeOut {
+    unsigned long long begin, n;
+    int buf, degenerate, split, pad;
+    double sw, mean[3];
+    double acc[7][2];                  // slot sums: 6 covariance sums (xx,yx,zx,yy,zy,zz) + distortion, 2 binned parts each
+};
+
 struct NodeDev {
     // ---- inputs (host or k_cut writes them)
     unsigned long long begin;          // first pixel slot of the segment
@@ -29,13 +47,24 @@ struct NodeDev {
     double sw;                         // sum of weights (n if unweighted)
     BinK klin, kquad;                  // binned-accumulation constants valid for this node and its children
     // ---- split evaluation outputs
-    unsigned long long minkey, maxkey; // ordered keys of the projection extrema
+    unsigned long long minkey[kSlots], maxkey[kSlots];   // ordered keys of the projection extrema
     int degenerate;                    // max - min < 1e-16 -> round-robin buckets (sort.c:61-79)
     int split;                         // optimal bucket index (local.c:171)
     unsigned long long cbegin[kMaxChildren + 1];   // children segments in the other buffer
-    // ---- moments about `mean` (k_cov): 6 covariance sums (xx,yx,zx,yy,zy,zz) + distortion, 2 parts each
-    double acc[7][2];
+    // ---- moments about `mean` (k_cov / k_scatter): 6 covariance sums + distortion, 2 parts each
+    double acc[kSlots][7][2];
 };
+
+__device__ __forceinline__ void node_reset_outputs(NodeDev &d) {
+    for (int i = 0; i < kSlots; i++) { d.minkey[i] = ~0ULL; d.maxkey[i] = 0ULL; }
+    for (int i = 0; i < kSlots; i++) for (int q = 0; q < 7; q++) { d.acc[i][q][0] = 0; d.acc[i][q][1] = 0; }
+    d.degenerate = 0; d.split = -1;
+}
+__device__ __forceinline__ void node_minmax(const NodeDev &d, double &mn, double &mx) {
+    unsigned long long a = ~0ULL, b = 0ULL;
+    for (int i = 0; i < kSlots; i++) { a = d.minkey[i] < a ? d.minkey[i] : a; b = d.maxkey[i] > b ? d.maxkey[i] : b; }
+    mn = key_f64(a); mx = key_f64(b);
+}
 
 struct Tile {
     unsigned long long start;          // absolute pixel slot
@@ -59,7 +88,7 @@ void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int n
                 const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s);
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
-                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, hipStream_t s);
+                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s);
 void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s);
 void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
                       NodeDev *d_nodes, hipStream_t s);

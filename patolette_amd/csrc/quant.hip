@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__r
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_down(mn, o, 64)); mx = fmax(mx, __shfl_down(mx, o, 64)); }
     if ((threadIdx.x & 63) == 0 && mn <= mx) {
-        atomicMin(&nd.minkey, f64_key(mn));
-        atomicMax(&nd.maxkey, f64_key(mx));
+        atomicMin(&nd.minkey[blockIdx.x & (kSlots - 1)], f64_key(mn));
+        atomicMax(&nd.maxkey[blockIdx.x & (kSlots - 1)], f64_key(mx));
     }
 }
 
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
     const Tile t = tiles[blockIdx.x];
     NodeDev &nd = nodes[t.node];
     const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
-    const double mn = key_f64(nd.minkey), mx = key_f64(nd.maxkey);
+    double mn, mx;
+    node_minmax(nd, mn, mx);
     const bool degenerate = (mx - mn < kDelta);
     const double sc = 1 / (mx - mn);
     const BinK klin = nd.klin, kquad = nd.kquad;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
             ch.buf = 1 - nd.buf;
             ch.slot = -1; ch.child0 = -1; ch.nchild = 0;
             ch.klin = nd.klin; ch.kquad = nd.kquad;
-            ch.minkey = ~0ULL; ch.maxkey = 0ULL; ch.degenerate = 0; ch.split = -1;
+            node_reset_outputs(ch);
             double s0[NQ], s1[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
@@ -254,7 +255,6 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
             ch.sw = sw;
             const double inv = 1 / sw;                                     // matrix2D.c:229-231: mean *= 1/sum(w)
             for (int j = 0; j < 3; j++) ch.mean[j] = (s0[j] + s1[j]) * inv;
-            for (int q = 0; q < 7; q++) { ch.acc[q][0] = 0; ch.acc[q][1] = 0; }
             ch.axis[0] = ch.axis[1] = ch.axis[2] = 0;
         }
     }
@@ -311,11 +311,12 @@ __global__ __launch_bounds__(256) void k_scan(const int *__restrict__ round_node
     if (threadIdx.x == 0) nd.cbegin[nd.nchild] = base;
 }
 
-template <bool W>
-__global__ __launch_bounds__(256) void k_scatter(QuantBuffers qb, const Tile *__restrict__ tiles, const NodeDev *__restrict__ nodes,
+template <bool W, bool COV>
+__global__ __launch_bounds__(256) void k_scatter(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes,
                                                  const unsigned char *__restrict__ lut, const unsigned long long *__restrict__ tileoff) {
     constexpr int R = kTileP / 256;
     __shared__ unsigned long long off[R][4][kMaxChildren];
+    __shared__ double sm[28 * 4];
     const Tile t = tiles[blockIdx.x];
     const NodeDev &nd = nodes[t.node];
     const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
@@ -343,13 +344,54 @@ __global__ __launch_bounds__(256) void k_scatter(QuantBuffers qb, const Tile *__
     __syncthreads();
     const double *sx = qb.buf[nd.buf], *sy = sx + qb.N, *sz = sy + qb.N, *sw = sz + qb.N;
     double *dx = qb.buf[1 - nd.buf], *dy = dx + qb.N, *dz = dy + qb.N, *dw = dz + qb.N;
+    // COV (binary splits only): the children's centred moments are accumulated while their pixels pass through
+    // registers -- pca.c:62-101 / cluster.c:111-152 about the child means k_cut already wrote
+    double a[28];
+    double m0[2], m1[2], m2[2];
+    BinK kq;
+    if constexpr (COV) {
+#pragma unroll
+        for (int i = 0; i < 28; i++) a[i] = 0;
+        const NodeDev &c0 = nodes[nd.child0], &c1 = nodes[nd.child0 + 1];
+        m0[0] = c0.mean[0]; m1[0] = c0.mean[1]; m2[0] = c0.mean[2];
+        m0[1] = c1.mean[0]; m1[1] = c1.mean[1]; m2[1] = c1.mean[2];
+        kq = nd.kquad;
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         if (child[r] != 255) {
-            size_t src = t.start + r * 256 + threadIdx.x;
-            size_t dst = off[r][wid][child[r]] + rank[r];
-            dx[dst] = sx[src]; dy[dst] = sy[src]; dz[dst] = sz[src];
-            if constexpr (W) dw[dst] = sw[src];
+            const size_t src = t.start + r * 256 + threadIdx.x;
+            const size_t dst = off[r][wid][child[r]] + rank[r];
+            const double x = sx[src], y = sy[src], z = sz[src];
+            double w = 1.0;
+            if constexpr (W) w = sw[src];
+            dx[dst] = x; dy[dst] = y; dz[dst] = z;
+            if constexpr (W) dw[dst] = w;
+            if constexpr (COV) {
+                const bool right = child[r] != 0;
+                const double ex = x - (right ? m0[1] : m0[0]), ey = y - (right ? m1[1] : m1[0]), ez = z - (right ? m2[1] : m2[0]);
+                const double wx = w * ex, wy = w * ey, wz = w * ez;
+                const double q[7] = {wx * ex, wy * ex, wz * ex, wy * ey, wz * ey, wz * ez, ((ex * ex + ey * ey) + ez * ez) * w};
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    double v0, v1;
+                    bin_split(q[i], kq, v0, v1);
+                    a[2 * i] += right ? 0.0 : v0;      a[2 * i + 1] += right ? 0.0 : v1;
+                    a[14 + 2 * i] += right ? v0 : 0.0; a[14 + 2 * i + 1] += right ? v1 : 0.0;
+                }
+            }
+        }
+    }
+    if constexpr (COV) {
+        block_sum<28>(a, sm);
+        if (threadIdx.x == 0) {
+            for (int side = 0; side < 2; side++) {
+                NodeDev &ch = nodes[nd.child0 + side];
+                for (int i = 0; i < 7; i++) {
+                    if (a[14 * side + 2 * i] != 0.0) unsafeAtomicAdd(&ch.acc[blockIdx.x & (kSlots - 1)][i][0], a[14 * side + 2 * i]);
+                    if (a[14 * side + 2 * i + 1] != 0.0) unsafeAtomicAdd(&ch.acc[blockIdx.x & (kSlots - 1)][i][1], a[14 * side + 2 * i + 1]);
+                }
+            }
         }
     }
 }
@@ -396,7 +438,7 @@ __global__ __launch_bounds__(256) void k_cov_children(QuantBuffers qb, const Til
         cov_accumulate<W>(px, py, pz, pw, lo, hi, ch.mean[0], ch.mean[1], ch.mean[2], nd.kquad, a);
         block_sum<14>(a, sm);
         if (threadIdx.x == 0)
-            for (int q = 0; q < 7; q++) { unsafeAtomicAdd(&ch.acc[q][0], a[2 * q]); unsafeAtomicAdd(&ch.acc[q][1], a[2 * q + 1]); }
+            for (int q = 0; q < 7; q++) { unsafeAtomicAdd(&ch.acc[blockIdx.x & (kSlots - 1)][q][0], a[2 * q]); unsafeAtomicAdd(&ch.acc[blockIdx.x & (kSlots - 1)][q][1], a[2 * q + 1]); }
     }
 }
 
@@ -413,7 +455,7 @@ __global__ __launch_bounds__(256) void k_cov_nodes(QuantBuffers qb, const double
     cov_accumulate<W>(px, py, pz, pw, t.start, t.start + t.count, nd.mean[0], nd.mean[1], nd.mean[2], nd.kquad, a);
     block_sum<14>(a, sm);
     if (threadIdx.x == 0)
-        for (int q = 0; q < 7; q++) { unsafeAtomicAdd(&nd.acc[q][0], a[2 * q]); unsafeAtomicAdd(&nd.acc[q][1], a[2 * q + 1]); }
+        for (int q = 0; q < 7; q++) { unsafeAtomicAdd(&nd.acc[blockIdx.x & (kSlots - 1)][q][0], a[2 * q]); unsafeAtomicAdd(&nd.acc[blockIdx.x & (kSlots - 1)][q][1], a[2 * q + 1]); }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -473,14 +515,19 @@ void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int n
 
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
-                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, hipStream_t s) {
+                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s) {
     if (!nptiles) return;
     { KTIME("k_count", s, 2.0 * px); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt); }
     { KTIME("k_scan", s, 12.0 * kMaxChildren * nptiles); hipLaunchKernelGGL(k_scan, nround, 256, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff); }
     {
-        KTIME("k_scatter", s, (qb.weighted ? 66.0 : 50.0) * px);
-        if (qb.weighted) hipLaunchKernelGGL(k_scatter<true>, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
-        else hipLaunchKernelGGL(k_scatter<false>, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+        KTIME(fuse_cov ? "k_scatter_cov" : "k_scatter", s, (qb.weighted ? 66.0 : 50.0) * px);
+        if (fuse_cov) {
+            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true>), nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+            else hipLaunchKernelGGL((k_scatter<false, true>), nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+        } else {
+            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, false>), nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+            else hipLaunchKernelGGL((k_scatter<false, false>), nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+        }
     }
     HIP_CHECK(hipGetLastError());
 }

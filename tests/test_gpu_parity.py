@@ -120,6 +120,31 @@ def test_nn_map_bit_exact(gpu, ob):
         assert not np.any(got == 3) or k <= 4
 
 
+def test_nn_map_pruned_path_edge_cases(gpu, ob):
+    """The grid-pruned kernel must stay bit-exact: crowded palettes (list overflow -> full scan),
+    a degenerate axis, duplicate entries, palette entries far outside the pixel box."""
+    n = 200000
+    base = ob.convert("srgb_to_ictcp", ob.image(n, 12))
+    cases = []
+    k = 256
+    crowded = np.tile(np.array([[0.3, 0.01, -0.02]]), (k, 1)) + 1e-6 * ob.image(k, 5).reshape(3, k).T   # all within 1e-6
+    cases.append((base, crowded))
+    flat2 = base.copy(); flat2[n:2 * n] = 0.0125                                   # constant plane
+    cases.append((flat2, ob.convert("srgb_to_ictcp", ob.image(k, 6)).reshape(3, k).T.copy()))
+    far = ob.convert("srgb_to_ictcp", ob.image(64, 7)).reshape(3, 64).T.copy()
+    far[::2] += 5.0                                                                 # half the palette far away
+    far[10] = far[12]
+    cases.append((base, far))
+    small_k = ob.convert("srgb_to_ictcp", ob.image(9, 8)).reshape(3, 9).T.copy()
+    cases.append((base, small_k))
+    for flat, pal in cases:
+        kk = pal.shape[0]
+        want = ob.nn_map(flat, n, pal)
+        got = np.zeros(n, dtype=np.uintp)
+        assert gpu.patolette_amd_nn_map(_d(flat), n, _d(np.ascontiguousarray(pal.T).reshape(-1)), kk, got.ctypes.data_as(zp)) == 0
+        assert np.array_equal(got, want), int(np.sum(got != want))
+
+
 @pytest.mark.parametrize("wh", [(64, 64), (37, 23), (5, 40), (1, 9), (130, 70), (256, 3)])
 def test_dither_bit_exact(gpu, ob, wh):
     w, h = wh
