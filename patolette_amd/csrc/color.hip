@@ -27,16 +27,23 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ src,
         for (int p = 0; p < 3; p++) { mn[p] = fmin(mn[p], c[p]); mx[p] = fmax(mx[p], c[p]); }
     }
     if (stats) {
+        __shared__ double smn[4][3], smx[4][3];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             double a = mn[p], b = mx[p];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { a = fmin(a, __shfl_down(a, o, 64)); b = fmax(b, __shfl_down(b, o, 64)); }
-            if ((threadIdx.x & 63) == 0) {
-                if (a <= b) {   // skip waves that saw no pixel (and NaNs)
-                    atomicMin(&stats->minkey[p], f64_key(a));
-                    atomicMax(&stats->maxkey[p], f64_key(b));
-                }
+            if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6][p] = a; smx[threadIdx.x >> 6][p] = b; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int p = threadIdx.x;
+            double a = smn[0][p], b = smx[0][p];
+            for (int w = 1; w < 4; w++) { a = fmin(a, smn[w][p]); b = fmax(b, smx[w][p]); }
+            if (a <= b) {   // skip blocks that saw no pixel (and NaNs)
+                const int slot = blockIdx.x & (kStatSlots - 1);
+                atomicMin(&stats->minkey[slot][p], f64_key(a));
+                atomicMax(&stats->maxkey[slot][p], f64_key(b));
             }
         }
     }
@@ -48,13 +55,13 @@ __global__ __launch_bounds__(256) void k_weight_stats(const double *__restrict__
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) mx = fmax(mx, fabs(w[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&stats->wmaxkey, f64_key(mx));
+    if ((threadIdx.x & 63) == 0) atomicMax(&stats->wmaxkey[blockIdx.x & (kStatSlots - 1)], f64_key(mx));
 }
 
 __global__ void k_init_stats(ConvertStats *s) {
-    if (threadIdx.x == 0) {
-        for (int p = 0; p < 3; p++) { s->minkey[p] = ~0ULL; s->maxkey[p] = 0ULL; }
-        s->wmaxkey = f64_key(0.0);
+    if (threadIdx.x < kStatSlots) {
+        for (int p = 0; p < 3; p++) { s->minkey[threadIdx.x][p] = ~0ULL; s->maxkey[threadIdx.x][p] = 0ULL; }
+        s->wmaxkey[threadIdx.x] = f64_key(0.0);
     }
 }
 

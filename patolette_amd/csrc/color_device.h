@@ -10,8 +10,9 @@ namespace pamd {
 
 constexpr int PAMD_COPY = 100;       // internal: no conversion (colour space sRGB)
 
-struct ConvertStats {                // filled by k_convert / k_weight_stats (ordered-key min/max)
-    unsigned long long minkey[3], maxkey[3], wmaxkey;
+constexpr int kStatSlots = 32;       // same-address atomics serialise in L2: blocks spread over slots
+struct ConvertStats {                // filled by k_convert / k_weight_stats (ordered-key min/max per slot)
+    unsigned long long minkey[kStatSlots][3], maxkey[kStatSlots][3], wmaxkey[kStatSlots];
 };
 
 namespace dc {

@@ -114,7 +114,8 @@ struct Engine {
     PinBuf<NodeIn> h_stage_in;
     PinBuf<NodeOut> h_stage_out;
     PinBuf<int> h_ids;
-    PinBuf<Tile> h_tiles;
+    PinBuf<Tile> h_tilesA, h_tilesP;
+    PinBuf<int> h_round, h_tile0;
     PinBuf<double> h_dbl;
     PinBuf<unsigned char> h_bytes;
     KMeansWork km;
@@ -182,13 +183,21 @@ static NodeIn make_nodedev(const HNode &h, const Bounds &b) {
     return d;
 }
 
-static void upload_tiles(Engine &E, const std::vector<Tile> &t, DevBuf<Tile> &dst) {
+// Host staging buffers are pinned and one per purpose; every round ends with a stream sync (get_nodes), so a
+// buffer is never rewritten while an earlier async copy from it is still in flight.
+static void upload_tiles(Engine &E, const std::vector<Tile> &t, DevBuf<Tile> &dst, PinBuf<Tile> &stage) {
     if (t.empty()) return;
     dst.reserve(t.size());
-    E.h_tiles.reserve(t.size());
-    std::memcpy(E.h_tiles.p, t.data(), t.size() * sizeof(Tile));
-    HIP_CHECK(hipMemcpyAsync(dst.p, E.h_tiles.p, t.size() * sizeof(Tile), hipMemcpyHostToDevice, E.stream));
-    HIP_CHECK(hipStreamSynchronize(E.stream));     // h_tiles is reused right away
+    stage.reserve(t.size());
+    std::memcpy(stage.p, t.data(), t.size() * sizeof(Tile));
+    HIP_CHECK(hipMemcpyAsync(dst.p, stage.p, t.size() * sizeof(Tile), hipMemcpyHostToDevice, E.stream));
+}
+static void upload_ints(Engine &E, const std::vector<int> &v, DevBuf<int> &dst, PinBuf<int> &stage) {
+    if (v.empty()) return;
+    dst.reserve(v.size());
+    stage.reserve(v.size());
+    std::memcpy(stage.p, v.data(), v.size() * sizeof(int));
+    HIP_CHECK(hipMemcpyAsync(dst.p, stage.p, v.size() * sizeof(int), hipMemcpyHostToDevice, E.stream));
 }
 
 static void put_nodes(Engine &E, const std::vector<int> &ids, const std::vector<NodeIn> &recs) {
@@ -201,7 +210,7 @@ static void put_nodes(Engine &E, const std::vector<int> &ids, const std::vector<
     HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
     hipLaunchKernelGGL(k_put_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.stage_in.p, E.ids.p, n);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(E.stream));
+    HIP_CHECK(hipStreamSynchronize(E.stream));     // h_stage_in / h_ids are shared with get_nodes
 }
 
 static void get_nodes(Engine &E, const std::vector<int> &ids, std::vector<NodeOut> &recs) {
@@ -264,7 +273,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     std::vector<Tile> tA, tP;
     std::vector<int> tile0;
     build_tiles(round, hn, kTileA, tA, nullptr);
-    upload_tiles(E, tA, E.tilesA);
+    upload_tiles(E, tA, E.tilesA, E.h_tilesA);
     {
         NodeIn d = make_nodedev(hn[0], bnd);
         put_nodes(E, {0}, {d});
@@ -358,11 +367,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     HIP_CHECK(hipMemcpyAsync(E.lut.p, lut.data(), kBuckets, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));
     build_tiles(round, hn, kTileP, tP, &tile0);
-    upload_tiles(E, tP, E.tilesP);
-    E.round_nodes.reserve(1); E.node_tile0.reserve(2);
-    HIP_CHECK(hipMemcpyAsync(E.round_nodes.p, round.data(), sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(E.node_tile0.p, tile0.data(), 2 * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    upload_tiles(E, tP, E.tilesP, E.h_tilesP);
+    upload_ints(E, round, E.round_nodes, E.h_round);
+    upload_ints(E, tile0, E.node_tile0, E.h_tile0);
     E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
     launch_partition(qroot, E.tilesP.p, (int)tP.size(), N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, false, s);
     launch_cov_children(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
@@ -464,12 +471,10 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             put_nodes(E, ids, recs);
             build_tiles(todo, hn, kTileA, tA, nullptr);
             build_tiles(todo, hn, kTileP, tP, &tile0);
-            upload_tiles(E, tA, E.tilesA);
-            upload_tiles(E, tP, E.tilesP);
-            E.round_nodes.reserve(nr); E.node_tile0.reserve(nr + 1);
-            HIP_CHECK(hipMemcpyAsync(E.round_nodes.p, todo.data(), nr * sizeof(int), hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipMemcpyAsync(E.node_tile0.p, tile0.data(), (nr + 1) * sizeof(int), hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            upload_tiles(E, tA, E.tilesA, E.h_tilesA);
+            upload_tiles(E, tP, E.tilesP, E.h_tilesP);
+            upload_ints(E, todo, E.round_nodes, E.h_round);
+            upload_ints(E, tile0, E.node_tile0, E.h_tile0);
             const size_t lqs = (size_t)kNQ_LQ * 2 * kBuckets;
             E.hist.reserve(std::max(hs, lqs * nr)); E.hsize.reserve((size_t)nr * kBuckets); E.hcount.reserve((size_t)nr * kBuckets);
             E.lut.reserve((size_t)nr * kBuckets);
@@ -569,13 +574,17 @@ static Bounds read_bounds(Engine &E, bool weighted) {
     Bounds b;
     b.cmax = 0; b.range = 0;
     for (int p = 0; p < 3; p++) {
-        double mn = key_f64(cs.minkey[p]), mx = key_f64(cs.maxkey[p]);
+        unsigned long long ka = ~0ULL, kb = 0ULL;
+        for (int t = 0; t < kStatSlots; t++) { ka = std::min(ka, cs.minkey[t][p]); kb = std::max(kb, cs.maxkey[t][p]); }
+        double mn = key_f64(ka), mx = key_f64(kb);
         if (!(mn <= mx)) { mn = 0; mx = 0; }
         b.lo[p] = mn; b.hi[p] = mx;
         b.cmax = std::max(b.cmax, std::max(std::fabs(mn), std::fabs(mx)));
         b.range = std::max(b.range, mx - mn);
     }
-    b.wmax = weighted ? std::max(1.0, key_f64(cs.wmaxkey)) : 1.0;
+    unsigned long long kw = 0ULL;
+    for (int t = 0; t < kStatSlots; t++) kw = std::max(kw, cs.wmaxkey[t]);
+    b.wmax = weighted ? std::max(1.0, key_f64(kw)) : 1.0;
     const double lin = b.wmax * std::max(b.cmax, 1.0);
     const double quad = 3.0 * b.wmax * std::max(std::max(b.range, b.cmax), 1e-300) * std::max(std::max(b.range, b.cmax), 1e-300);
     b.e_lin = exp_bound(lin);

@@ -83,9 +83,15 @@ __global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__r
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_down(mn, o, 64)); mx = fmax(mx, __shfl_down(mx, o, 64)); }
-    if ((threadIdx.x & 63) == 0 && mn <= mx) {
-        atomicMin(&nd.minkey[blockIdx.x & (kSlots - 1)], f64_key(mn));
-        atomicMax(&nd.maxkey[blockIdx.x & (kSlots - 1)], f64_key(mx));
+    __shared__ double smn[4], smx[4];
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { mn = fmin(mn, smn[w]); mx = fmax(mx, smx[w]); }
+        if (mn <= mx) {
+            atomicMin(&nd.minkey[blockIdx.x & (kSlots - 1)], f64_key(mn));
+            atomicMax(&nd.maxkey[blockIdx.x & (kSlots - 1)], f64_key(mx));
+        }
     }
 }
 
