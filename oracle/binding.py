@@ -72,6 +72,8 @@ def lib():
         L.orc_nn_map.restype = None
         L.orc_dither_riemersma.argtypes = [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp]
         L.orc_dither_riemersma.restype = None
+        L.orc_dither_riemersma_prefix.argtypes = [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp, C.c_size_t]
+        L.orc_dither_riemersma_prefix.restype = None
         L.orc_hilbert_order.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]
         L.orc_hilbert_order.restype = C.c_size_t
         L.orc_patolette.argtypes = [C.c_size_t, C.c_size_t, dp, dp, C.c_size_t, C.POINTER(Options),
@@ -161,6 +163,14 @@ def dither(flat, width, height, palette, init=None):
     p = planar(palette)
     out = np.zeros(width * height, dtype=np.uintp) if init is None else init.astype(np.uintp).copy()
     lib().orc_dither_riemersma(_d(flat), width, height, _d(p), k, out.ctypes.data_as(zp))
+    return out
+
+
+def dither_prefix(flat, width, height, palette, max_visits, fill=0xFFFF):
+    k = palette.shape[0]
+    p = planar(palette)
+    out = np.full(width * height, fill, dtype=np.uintp)
+    lib().orc_dither_riemersma_prefix(_d(flat), width, height, _d(p), k, out.ctypes.data_as(zp), max_visits)
     return out
 
 

@@ -1212,7 +1212,7 @@ enum { DIR_NONE, DIR_UP, DIR_LEFT, DIR_RIGHT, DIR_DOWN };
 typedef struct {
     size_t x, y, width, height;
     /* mode 0: dither; mode 1: record order */
-    int mode; uint64_t *order; size_t norder;
+    int mode; uint64_t *order; size_t norder; size_t max_visits, visits;
     const double *img; size_t n;                             /* planar (n,3) */
     const double *pal; size_t k; double *pal_w;              /* palette planar (k,3); pal_w interleaved scaled */
     double q[16][3]; double qw[16];
@@ -1240,8 +1240,11 @@ static void dither_pixel(Dither *s) {                         /* riemersma.c:275
 }
 static void d_move(Dither *s, int dir) {                      /* riemersma.c:146-174 */
     if (s->x < s->width && s->y < s->height) {
-        if (s->mode == 0) dither_pixel(s);
-        else s->order[s->norder++] = (uint64_t)(s->y * s->width + s->x);
+        if (s->max_visits == 0 || s->visits < s->max_visits) {
+            if (s->mode == 0) dither_pixel(s);
+            else s->order[s->norder++] = (uint64_t)(s->y * s->width + s->x);
+        }
+        s->visits++;
     }
     switch (dir) {
         case DIR_LEFT: s->x--; break;
@@ -1293,9 +1296,20 @@ static int d_level(size_t width, size_t height) {             /* riemersma.c:124
     if (((size_t)1 << level) < mx) level++;
     return level;
 }
+static void dither_run(const double *colors, size_t width, size_t height, const double *palette, size_t k, size_t *map, size_t max_visits);
 void orc_dither_riemersma(const double *colors, size_t width, size_t height,
                           const double *palette, size_t k, size_t *map) {
+    dither_run(colors, width, height, palette, k, map, 0);
+}
+/* test helper: only the first max_visits in-image steps of the walk are dithered (the chain is causal,
+ * so they equal the first max_visits steps of the full run) */
+void orc_dither_riemersma_prefix(const double *colors, size_t width, size_t height,
+                                 const double *palette, size_t k, size_t *map, size_t max_visits) {
+    dither_run(colors, width, height, palette, k, map, max_visits);
+}
+static void dither_run(const double *colors, size_t width, size_t height, const double *palette, size_t k, size_t *map, size_t max_visits) {
     Dither s; memset(&s, 0, sizeof s);
+    s.max_visits = max_visits;
     s.width = width; s.height = height; s.img = colors; s.n = width * height; s.pal = palette; s.k = k; s.map = map;
     /* riemersma.c:360-373 */
     double m = exp(log(16.0) / (16.0 - 1)), v = 1;

@@ -88,6 +88,8 @@ void orc_nn_map(const double *colors, size_t n, const double *palette, size_t k,
  * Rec2020.  Pixels never visited (1x1 image) leave map untouched. */
 void orc_dither_riemersma(const double *colors, size_t width, size_t height,
                           const double *palette, size_t k, size_t *map);
+void orc_dither_riemersma_prefix(const double *colors, size_t width, size_t height,
+                                 const double *palette, size_t k, size_t *map, size_t max_visits);
 /* Hilbert visiting order used by the dither: writes the in-bounds (y*width+x) sequence,
  * returns its length (== width*height unless the image is 1x1). */
 size_t orc_hilbert_order(size_t width, size_t height, uint64_t *order);

@@ -1,0 +1,148 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes (configs[1..3]),
+where the CPU oracle would take minutes.  Needs a real MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+dp = C.POINTER(C.c_double)
+
+
+class Dev:
+    """A synthetic image resident in HBM (splitmix64 generator)."""
+
+    def __init__(self, L, n, seed, weighted=False):
+        self.L, self.n = L, n
+        self.img = L.patolette_amd_malloc(3 * n * 8)
+        assert self.img and L.patolette_amd_fill_image(self.img, n, seed) == 0
+        self.w = None
+        if weighted:
+            self.w = L.patolette_amd_malloc(n * 8)
+            assert self.w and L.patolette_amd_fill_weights(self.w, n, seed) == 0
+        self.map = L.patolette_amd_malloc(n)
+
+    def free(self):
+        for p in (self.img, self.w, self.map):
+            if p:
+                self.L.patolette_amd_free(p)
+
+    def host_image(self):
+        out = np.empty(3 * self.n)
+        assert self.L.patolette_amd_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.img, out.nbytes) == 0
+        return out
+
+    def host_map(self):
+        out = np.empty(self.n, dtype=np.uint8)
+        assert self.L.patolette_amd_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.map, out.nbytes) == 0
+        return out
+
+
+def run(native, d, width, height, K, **kw):
+    L = native.lib()
+    opts = native.QuantizationOptions(kw.get("dither", False), False, kw.get("color_space", 2), kw.get("kmeans_niter", 0),
+                                      kw.get("kmeans_max_samples", 512 ** 2), False)
+    pal = np.zeros((K, 3), dtype=np.float64, order="F")
+    code = C.c_int(9)
+    L.patolette_amd_device(width, height, d.img, d.w, K, C.byref(opts), pal.ctypes.data_as(dp), d.map, 1, C.byref(code))
+    assert code.value == 0, native.last_error()
+    return pal, d.host_map(), native.last_stats()
+
+
+def check_map_is_nearest(ob, img_flat, n, pal_srgb, pmap, sample=200000, seed=0):
+    """The map must send every pixel to its nearest palette colour in ICtCp (patolette.c:300-324).
+    Verified exactly on a random sample with the oracle's conversion + brute-force NN."""
+    rng = np.random.default_rng(seed)
+    idx = np.sort(rng.choice(n, size=min(sample, n), replace=False))
+    sub = np.concatenate([img_flat[idx], img_flat[n + idx], img_flat[2 * n + idx]])
+    sub_ict = ob.convert("srgb_to_ictcp", sub)
+    k = pal_srgb.shape[0]
+    pal_ict = ob.convert("srgb_to_ictcp", np.ascontiguousarray(pal_srgb.T).reshape(-1)).reshape(3, k).T
+    want = ob.nn_map(sub_ict, len(idx), pal_ict)
+    # the returned sRGB palette went ICtCp -> Rec2020 -> sRGB once (round trip ~1e-12): allow ties within that
+    got = pmap[idx].astype(np.int64)
+    diff = got != want
+    if diff.any():
+        px = sub_ict.reshape(3, -1).T[diff]
+        d_got = np.sum((px - pal_ict[got[diff]]) ** 2, axis=1)
+        d_want = np.sum((px - pal_ict[want[diff]]) ** 2, axis=1)
+        assert np.all(np.abs(d_got - d_want) <= 1e-9 * (1e-6 + d_want)), int(diff.sum())
+    return int(diff.sum())
+
+
+@pytest.mark.parametrize("cfg", [("c2", 1920, 1080, 0), ("c3", 4096, 4096, 32)], ids=lambda c: c[0])
+def test_full_size_ictcp(gpu, native, ob, cfg):
+    name, w, h, niter = cfg
+    n, K = w * h, 256
+    d = Dev(gpu, n, 3)
+    try:
+        pal, pmap, st = run(native, d, w, h, K, kmeans_niter=niter)
+        pal2, pmap2, _ = run(native, d, w, h, K, kmeans_niter=niter)
+        # 1. bit-reproducible run to run (binned sums make float atomics order-independent)
+        assert np.array_equal(pal, pal2) and np.array_equal(pmap, pmap2)
+        # 2. a full palette of distinct, in-gamut colours; every entry used by uniform noise
+        assert st["n_clusters"] == K and np.all(pal >= 0) and np.all(pal <= 1)
+        assert len(np.unique(np.round(pal, 12), axis=0)) == K
+        assert np.array_equal(np.unique(pmap), np.arange(K))
+        # 3. the split loop did the reference's amount of work: D_eff ~ log2(K) (8.07)
+        assert 7.0 < st["split_px"] / n < 9.5 and st["n_base_clusters"] == 2
+        # 4. the map is the exact nearest-colour assignment
+        check_map_is_nearest(ob, d.host_image(), n, pal, pmap)
+        # 5. quantisation quality: mean squared ICtCp error of 256 colours on uniform noise
+        if niter:
+            assert st["kmeans_samples"] == 512 ** 2
+    finally:
+        d.free()
+
+
+def test_kmeans_lowers_distortion_at_full_size(gpu, native, ob):
+    w = h = 2048
+    n, K = w * h, 64
+    d = Dev(gpu, n, 5)
+    try:
+        img = d.host_image()
+        rng = np.random.default_rng(1)
+        idx = rng.choice(n, 100000, replace=False)
+        sub = ob.convert("srgb_to_ictcp", np.concatenate([img[idx], img[n + idx], img[2 * n + idx]])).reshape(3, -1).T
+
+        def distortion(pal):
+            p = ob.convert("srgb_to_ictcp", np.ascontiguousarray(pal.T).reshape(-1)).reshape(3, K).T
+            dd = ((sub[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+            return dd.min(1).mean()
+        pal0, _, _ = run(native, d, w, h, K, kmeans_niter=0)
+        pal1, _, _ = run(native, d, w, h, K, kmeans_niter=16)
+        assert distortion(pal1) < distortion(pal0)
+    finally:
+        d.free()
+
+
+def test_full_size_cieluv_weighted_map(gpu, native, ob):
+    """configs[3] geometry (8192x8192, CIELuv, weights) on the NN-map branch."""
+    w = h = 8192
+    n, K = w * h, 256
+    d = Dev(gpu, n, 7, weighted=True)
+    try:
+        pal, pmap, st = run(native, d, w, h, K, color_space=1)
+        assert st["n_clusters"] == K and np.all(pal >= 0) and np.all(pal <= 1)
+        check_map_is_nearest(ob, d.host_image(), n, pal, pmap, sample=100000)
+    finally:
+        d.free()
+
+
+def test_dither_full_size_prefix_matches_oracle(gpu, ob):
+    """4096x4096 Riemersma chain on the GPU (16.8 M serial steps); the walk is causal, so its first
+    300 000 steps must equal the oracle's run truncated after 300 000 steps, bit for bit."""
+    w = h = 4096
+    n, k, steps = w * h, 256, 300000
+    flat = ob.image(n, 13)                                   # used as linear Rec2020 values directly
+    pal = ob.image(k, 14).reshape(3, k).T.copy()
+    want = ob.dither_prefix(flat, w, h, pal, steps)
+    got = np.zeros(n, dtype=np.uintp)
+    zp = C.POINTER(C.c_size_t)
+    assert gpu.patolette_amd_dither(flat.ctypes.data_as(dp), w, h, np.ascontiguousarray(pal.T).reshape(-1).ctypes.data_as(dp), k,
+                                    got.ctypes.data_as(zp)) == 0
+    visited = want != 0xFFFF
+    assert int(visited.sum()) == steps
+    assert np.array_equal(got[visited], want[visited])
+    assert got.max() < k
