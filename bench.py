@@ -3,21 +3,24 @@
 
 A "step" = one full quantisation (convert -> GQ -> LQ -> KMeans -> palette map) of one synthetic
 image whose f64 planar pixels are ALREADY RESIDENT IN HBM when the timed region starts
-(patolette_amd_device; the PCIe-inclusive host-to-host rate is in DESIGN.md, never `value`).
-Default workload = the configuration the metric is quoted on ("256-color ICtCp + KMeans"):
-BASELINE.json configs[2], 4096x4096, K=256, ICtCp, KMeans 32 it / 512^2 samples, dither off.
+(patolette_amd_device; the PCIe-inclusive host-to-host rate is in DESIGN.md / profiles/, never
+`value`).  Default workload = the configuration the metric is quoted on ("256-color ICtCp +
+KMeans"): BASELINE.json configs[2], 4096x4096, K=256, ICtCp, KMeans 32 it / 512^2 samples, dither off.
 
-  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c3full] [--no-cpu-baseline]
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3full|c4|c4map] [--no-cpu-baseline]
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); images are independent,
-so ranks shard the batch with NO data-path collective ("scaling": "weak": every rank quantises
-its own image per step); barrier + max-over-ranks timing; rank 0 prints one JSON line.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); images are independent, so the
+ranks shard the batch with NO data-path collective ("scaling": "weak": every rank quantises its own
+image per step); barrier + max-over-ranks timing; the only collective is the final gather of the
+index maps (u8) and palettes to rank 0, inside the timed region; rank 0 prints one JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import queue
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,21 +38,84 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+class Runner:
+    """S concurrent images per step: one persistent host thread (own engine = HIP stream + workspace) each;
+    ctypes drops the GIL during the call, so one image's host-side split-loop work overlaps another's kernels."""
+
+    def __init__(self, L, native, cfg, S, local_rank, d_imgs, d_wts, map_ptr, pals):
+        self.L, self.native, self.cfg, self.S = L, native, cfg, S
+        self.d_imgs, self.d_wts, self.map_ptr, self.pals = d_imgs, d_wts, map_ptr, pals
+        width, height, K, cs, niter, max_samples, dither, weighted, _ = cfg
+        self.opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+        self.qs = [queue.Queue() for _ in range(S)]
+        self.done = queue.Queue()
+        self.threads = []
+        if S > 1:
+            for j in range(S):
+                t = threading.Thread(target=self._worker, args=(j, local_rank), daemon=True)
+                t.start()
+                self.threads.append(t)
+
+    def one(self, i, j):
+        import numpy as np
+        width, height, K, cs, niter, max_samples, dither, weighted, _ = self.cfg
+        pal = np.zeros((K, 3), dtype=np.float64, order="F")
+        code = C.c_int(0)
+        src = (i * self.S + j) % len(self.d_imgs)
+        self.L.patolette_amd_device(width, height, self.d_imgs[src], self.d_wts[src] if weighted else None, K,
+                                    C.byref(self.opts), pal.ctypes.data_as(self.native.dp), self.map_ptr(i, j), 1, C.byref(code))
+        if code.value != 0:
+            raise RuntimeError("bench.py: quantisation failed: %s" % self.native.last_error())
+        if self.pals is not None:
+            self.pals[i * self.S + j] = pal
+
+    def _worker(self, j, local_rank):
+        self.L.patolette_amd_set_device(local_rank)
+        while True:
+            i = self.qs[j].get()
+            if i is None:
+                return
+            try:
+                self.one(i, j)
+                self.done.put(None)
+            except BaseException as e:      # noqa
+                self.done.put(e)
+
+    def step(self, i):
+        if self.S == 1:
+            self.one(i, 0)
+            return
+        for j in range(self.S):
+            self.qs[j].put(i)
+        for j in range(self.S):
+            e = self.done.get()
+            if e is not None:
+                raise e
+
+    def close(self):
+        for q in self.qs[:len(self.threads)]:
+            q.put(None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even with one rank")
+    ap.add_argument("--streams", type=int, default=1, help="images quantised concurrently per GPU and step in the timed region")
+    ap.add_argument("--extra-streams", type=int, default=3,
+                    help="after the timed region also measure throughput with this many concurrent images per GPU; reported "
+                         "separately as throughput_concurrent, never as `value` (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world > 1:
         args.gpus = world
 
     dist = None
@@ -63,6 +129,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
+    import numpy as np
     from patolette_amd import _native
     L = _native.lib()
     if L.patolette_amd_device_count() <= 0:
@@ -70,10 +137,14 @@ def main():
     if L.patolette_amd_set_device(local_rank) != 0:
         raise SystemExit("bench.py: cannot select device %d" % local_rank)
 
-    width, height, K, cs, niter, max_samples, dither, weighted, desc = CONFIGS[args.config]
+    cfg = CONFIGS[args.config]
+    width, height, K, cs, niter, max_samples, dither, weighted, desc = cfg
     n = width * height
-    opts = _native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
-    pool = max(1, min(3, args.steps))
+    S = max(1, args.streams)
+    S2 = max(0, args.extra_streams)
+    if dither and n > (1 << 24):
+        S2 = 0                                  # the serial dither chain of a 67 MP image takes tens of seconds
+    pool = max(S, S2, min(3, args.steps))
     d_imgs, d_wts = [], []
     for i in range(pool):
         p = L.patolette_amd_malloc(3 * n * 8)
@@ -85,26 +156,18 @@ def main():
             q = L.patolette_amd_malloc(n * 8)
             assert L.patolette_amd_fill_weights(q, n, 100 * rank + i) == 0
             d_wts.append(q)
-    import numpy as np
-    pals = np.zeros((args.steps + args.warmup, K, 3), dtype=np.float64)
-    pal = np.zeros((K, 3), dtype=np.float64, order="F")
-    code = C.c_int(0)
+    pals = np.zeros(((args.steps + args.warmup) * S, K, 3), dtype=np.float64)
     if dist is not None:
         # index maps (u8, K <= 256) of every step stay in HBM in a torch tensor the library writes into
         # directly, so the final RCCL gather needs no staging copy
-        maps_t = torch.empty((args.steps, n), dtype=torch.uint8, device="cuda")
-        warm_t = torch.empty((n,), dtype=torch.uint8, device="cuda")
-        map_ptr = lambda i: (maps_t[i - args.warmup].data_ptr() if i >= args.warmup else warm_t.data_ptr())
+        maps_t = torch.empty((args.steps * S, n), dtype=torch.uint8, device="cuda")
+        warm_t = torch.empty((max(S, S2, 1), n), dtype=torch.uint8, device="cuda")
+        map_ptr = lambda i, j: (maps_t[(i - args.warmup) * S + j].data_ptr() if i >= args.warmup else warm_t[j].data_ptr())
+        map_ptr2 = lambda i, j: warm_t[j].data_ptr()
     else:
-        d_map = L.patolette_amd_malloc(n)      # K <= 256 -> u8 index map left in HBM
-        map_ptr = lambda i: d_map
-
-    def step(i):
-        L.patolette_amd_device(width, height, d_imgs[i % pool], d_wts[i % pool] if weighted else None, K, C.byref(opts),
-                               pal.ctypes.data_as(_native.dp), map_ptr(i), 1, C.byref(code))
-        if code.value != 0:
-            raise SystemExit("bench.py: quantisation failed: %s" % _native.last_error())
-        pals[i] = pal
+        d_maps = [L.patolette_amd_malloc(n) for _ in range(max(S, S2, 1))]      # K <= 256 -> u8 index map left in HBM
+        map_ptr = lambda i, j: d_maps[j]
+        map_ptr2 = map_ptr
 
     def barrier():
         L.patolette_amd_synchronize()
@@ -112,33 +175,54 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    run = Runner(L, _native, cfg, S, local_rank, d_imgs, d_wts, map_ptr, pals)
     for i in range(args.warmup):
-        step(i)
+        run.step(i)
     barrier()
     if not args.no_profile:
         _native.profile(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        run.step(args.warmup + i)
     L.patolette_amd_synchronize()
-    gathered = None
     if dist is not None:
         # the only collective of the job: final gather of the results to rank 0 over RCCL/xGMI
-        pal_t = torch.from_numpy(pals[args.warmup:]).to("cuda")
+        pal_t = torch.from_numpy(pals[args.warmup * S:]).to("cuda")
         gl_m = [torch.empty_like(maps_t) for _ in range(world)] if rank == 0 else None
         gl_p = [torch.empty_like(pal_t) for _ in range(world)] if rank == 0 else None
         dist.gather(maps_t, gl_m, dst=0)
         dist.gather(pal_t, gl_p, dst=0)
         torch.cuda.synchronize()
-        gathered = (gl_m, gl_p)
     elapsed = time.perf_counter() - t0
     stats = _native.last_stats()
     prof = _native.profile_results() if not args.no_profile else {}
     _native.profile(False)
+    run.close()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- extra, separately reported: throughput with several images in flight per GPU (no kernel events) ----
+    conc = None
+    if S2 > 1:
+        run2 = Runner(L, _native, cfg, S2, local_rank, d_imgs, d_wts, map_ptr2, None)
+        run2.step(0)
+        barrier()
+        k2 = max(2, args.steps // 2)
+        t1 = time.perf_counter()
+        for i in range(k2):
+            run2.step(i)
+        L.patolette_amd_synchronize()
+        e2 = time.perf_counter() - t1
+        run2.close()
+        if dist is not None:
+            t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        conc = {"images_in_flight_per_gpu": S2, "value": round(float(n) * k2 * S2 * world / e2 / 1e6, 3), "unit": "Mpx/s",
+                "steps": k2, "note": "one host thread + HIP stream per image; host-side split-loop work of one image overlaps kernels of another"}
+    if dist is not None:
         dist.barrier()
 
     if rank != 0:
@@ -146,7 +230,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    total_px = float(n) * args.steps * world
+    total_px = float(n) * args.steps * world * S
     value = total_px / elapsed / 1e6
     # ---- roofline of the dominant kernel (most accumulated time in the timed region) ----
     roofline = None
@@ -159,8 +243,14 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["total_ms"])
         r = prof[dom]
         achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        if os.path.exists(tpath):       # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+            tj = json.load(open(tpath))
+            if dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 3),
                     "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"], 1),
                     "time_share": round(r["total_ms"] / max(1e-9, sum(v["total_ms"] for v in prof.values())), 3)}
@@ -188,11 +278,11 @@ def main():
         "value": round(value, 3), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": desc, "width": width, "height": height, "palette_size": K, "images_per_step_per_gpu": 1,
+        "config": {"workload": desc, "width": width, "height": height, "palette_size": K, "images_per_step_per_gpu": S,
                    "input": "uniform random sRGB (splitmix64), planar f64, resident in HBM; index map left in HBM as u8",
                    "kernel_events_in_timed_region": not args.no_profile,
                    "final_gather": ("RCCL gather of u8 maps + f64 palettes to rank 0, inside the timed region" if dist is not None else "none (1 GPU)")},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -324,41 +324,72 @@ struct DitherWeights { double w[16]; };
 
 constexpr double kRw = 0.51254268114958, kGw = 0.8234075540095561, kBw = 0.2435159132377184;   // riemersma.c:38-42
 
-template <typename OutT>
+// ---- wave-level helpers for the serial chain (DPP: a few cycles per step, vs ~100 for ds_bpermute) ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// minimum over the 64 lanes, returned in every lane (v must not be NaN)
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = fmin(v, dpp_f64<0xB1>(v));            // quad_perm [1,0,3,2]
+    v = fmin(v, dpp_f64<0x4E>(v));            // quad_perm [2,3,0,1]
+    v = fmin(v, dpp_f64<0x124>(v));           // row_ror:4
+    v = fmin(v, dpp_f64<0x128>(v));           // row_ror:8  -> every lane holds its 16-lane row minimum
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return fmin(fmin(r0, r1), fmin(r2, r3));
+}
+
+// One wavefront walks one image.  Lanes 0..2 carry the R,G,B error queues (the 16-term weighted sum is a
+// 16-deep chain per channel, evaluated for the three channels at once); all 64 lanes share the palette for
+// the nearest-colour search: lane L owns the contiguous entries [L*PER, (L+1)*PER), so on equal distance the
+// lowest palette index is simply the lowest lane (first set bit of a ballot).
+template <typename OutT, int PER>
 __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, size_t plane_stride, unsigned width, unsigned height,
                                                const double *__restrict__ pal /* planar (k,3), linear Rec2020 */, int k,
                                                OutT *__restrict__ out, DitherWeights wts) {
     extern __shared__ double lds[];
-    double *pwx = lds, *pwy = lds + k, *pwz = lds + 2 * k;          // palette scaled by (float)-cast weights (riemersma.c:419-425)
-    double *prx = lds + 3 * k, *pry = lds + 4 * k, *prz = lds + 5 * k;  // raw palette
+    double *praw = lds;                                              // [3][k] raw palette
+    double *pwt = lds + 3 * k;                                       // [3][k] palette scaled by (float)-cast weights (riemersma.c:419-425)
     const int lane = threadIdx.x;
-    const double fx = (double)(float)kRw, fy = (double)(float)kGw, fz = (double)(float)kBw;
-    for (int j = lane; j < k; j += 64) {
-        const double a = pal[j], b = pal[k + j], c = pal[2 * k + j];
-        prx[j] = a; pry[j] = b; prz[j] = c;
-        pwx[j] = a * fx; pwy[j] = b * fy; pwz[j] = c * fz;
-    }
+    const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
+    for (int j = lane; j < k; j += 64)
+        for (int c = 0; c < 3; c++) { const double a = pal[c * k + j]; praw[c * k + j] = a; pwt[c * k + j] = a * fw[c]; }
     __syncthreads();
-    // level = ceil(log2(max(w,h)))  (riemersma.c:124-144); level 0 visits nothing
-    const unsigned mx = width > height ? width : height;
+    const int per = PER > 0 ? PER : (k + 63) / 64;
+    // own entries in registers when they fit (PER <= 4)
+    double ex[PER > 0 ? PER : 1], ey[PER > 0 ? PER : 1], ez[PER > 0 ? PER : 1];
+    if constexpr (PER > 0) {
+#pragma unroll
+        for (int m = 0; m < PER; m++) {
+            const int j = lane * PER + m;
+            ex[m] = j < k ? pwt[j] : 1e300; ey[m] = j < k ? pwt[k + j] : 1e300; ez[m] = j < k ? pwt[2 * k + j] : 1e300;
+        }
+    }
+    const unsigned mxd = width > height ? width : height;
     int L = 0;
-    while ((1u << L) < mx) L++;
-    if (L == 0) return;
-    // queue weights w_i = m^i / 16, m = exp(ln 16 / 15)  (riemersma.c:360-373)
-    // (computed on the host with libm like the reference; passed in so no device exp/log ulp leaks in)
+    while ((1u << L) < mxd) L++;
+    if (L == 0) return;                                              // riemersma.c:452-456
     double qw[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) qw[i] = wts.w[i];
-    double qr[16], qg[16], qb[16];
+    for (int i = 0; i < 16; i++) qw[i] = wts.w[i];                    // w_i = m^i/16 (host libm, riemersma.c:360-373)
+    double q[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { qr[i] = 0; qg[i] = 0; qb[i] = 0; }
+    for (int i = 0; i < 16; i++) q[i] = 0;
+    const double Wc = lane == 0 ? kRw : (lane == 1 ? kGw : kBw);     // query weights are the DOUBLE constants (riemersma.c:305-311)
+    const int ch = lane < 3 ? lane : 0;
 
     const unsigned long long total = 1ULL << (2 * L);
     const double *pr = img, *pg = img + plane_stride, *pb = img + 2 * plane_stride;
     unsigned long long d0 = 0;
     while (d0 < total) {
-        // skip whole out-of-image sub-squares: a 4^j-aligned run of 4^j steps stays inside one aligned 2^j square
-        if (L >= 3) {
+        if (L >= 3) {                                                // skip whole out-of-image aligned sub-squares
             bool skipped = false;
             for (int j = L; j >= 3; j--) {
                 const unsigned long long span = 1ULL << (2 * j);
@@ -370,7 +401,6 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
             }
             if (skipped) continue;
         }
-        // the lanes decode 64 (or 4^L if smaller) consecutive steps and prefetch their pixels
         const unsigned long long dl = d0 + (unsigned long long)lane;
         unsigned x = 0, y = 0;
         bool inb = false;
@@ -384,31 +414,60 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
         int myidx = 0;
         for (int t = 0; t < 64; t++) {
             if (!((mask >> t) & 1ULL)) continue;                       // wave-uniform
-            const double pR = __shfl(R, t, 64), pG = __shfl(G, t, 64), pB = __shfl(B, t, 64);
-            double eR = 0, eG = 0, eB = 0;                            // riemersma.c:286-296
+            // pixel t: its channel `lane` lands in lanes 0..2
+            const double pR = readlane_f64(R, t), pG = readlane_f64(G, t), pB = readlane_f64(B, t);
+            const double pc = lane == 0 ? pR : (lane == 1 ? pG : pB);
+            double e = q[0] * qw[0];                                   // riemersma.c:286-296 (0 + x == x)
 #pragma unroll
-            for (int i = 0; i < 16; i++) { eR += qr[i] * qw[i]; eG += qg[i] * qw[i]; eB += qb[i] * qw[i]; }
-            const double cR = pR + eR, cG = pG + eG, cB = pB + eB;
-            const double qx = kRw * cR, qy = kGw * cG, qz = kBw * cB;
-            double bd = INFINITY; int bi = 0x7fffffff;
-            for (int j = lane; j < k; j += 64) {
-                const double e0 = qx - pwx[j], e1 = qy - pwy[j], e2 = qz - pwz[j];
-                const double dd = (e0 * e0 + e1 * e1) + e2 * e2;
-                if (dd < bd) { bd = dd; bi = j; }
-            }
+            for (int i = 1; i < 16; i++) e = e + q[i] * qw[i];
+            const double qv = Wc * (pc + e);
+            const double qx = readlane_f64(qv, 0), qy = readlane_f64(qv, 1), qz = readlane_f64(qv, 2);
+            double bd = INFINITY; int bj = 0;
+            if constexpr (PER > 0) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double od = __shfl_xor(bd, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                for (int m = 0; m < PER; m++) {
+                    const double e0 = qx - ex[m], e1 = qy - ey[m], e2 = qz - ez[m];
+                    const double dd = (e0 * e0 + e1 * e1) + e2 * e2;
+                    if (dd < bd) { bd = dd; bj = lane * PER + m; }
+                }
+            } else {
+                for (int m = 0; m < per; m++) {
+                    const int j = lane * per + m;
+                    if (j < k) {
+                        const double e0 = qx - pwt[j], e1 = qy - pwt[k + j], e2 = qz - pwt[2 * k + j];
+                        const double dd = (e0 * e0 + e1 * e1) + e2 * e2;
+                        if (dd < bd) { bd = dd; bj = j; }
+                    }
+                }
             }
+            const double md = wave_min_f64(bd);
+            const unsigned long long win = __ballot(bd == md);
+            const int wl = __builtin_ctzll(win);                       // lowest lane = lowest palette index among ties
+            const int bi = __builtin_amdgcn_readlane(bj, wl);
             if (lane == t) myidx = bi;
+            const double chosen = praw[ch * k + bi];
 #pragma unroll
-            for (int i = 0; i < 15; i++) { qr[i] = qr[i + 1]; qg[i] = qg[i + 1]; qb[i] = qb[i + 1]; }
-            qr[15] = pR - prx[bi]; qg[15] = pG - pry[bi]; qb[15] = pB - prz[bi];   // original pixel - chosen colour
+            for (int i = 0; i < 15; i++) q[i] = q[i + 1];
+            q[15] = pc - chosen;                                       // original pixel - chosen colour (riemersma.c:333-340)
         }
         if (inb) out[(size_t)y * width + x] = (OutT)myidx;
         d0 += 64;
     }
+}
+
+template <typename OutT>
+static void launch_dither_t(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k, OutT *out,
+                            const DitherWeights &wts, size_t lds, hipStream_t s) {
+#define PAMD_DITHER(PER)                                                                                                       \
+    do {                                                                                                                       \
+        HIP_CHECK(hipFuncSetAttribute((const void *)(k_dither<OutT, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_dither<OutT, PER>), 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts); \
+    } while (0)
+    if (k <= 64) PAMD_DITHER(1);
+    else if (k <= 128) PAMD_DITHER(2);
+    else if (k <= 256) PAMD_DITHER(4);
+    else PAMD_DITHER(0);
+#undef PAMD_DITHER
 }
 
 void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
@@ -422,16 +481,10 @@ void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_
         for (int i = 0; i < 16; i++) { wts.w[i] = v / 16.0; v *= m; }
     }
     KTIME("k_dither", s, (24.0 + elem_bytes) * width * height);
-    if (elem_bytes == 1) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_dither<unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_dither<unsigned char>, 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, (unsigned char *)d_out, wts);
-    } else if (elem_bytes == 4) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_dither<unsigned int>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_dither<unsigned int>, 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, (unsigned int *)d_out, wts);
-    } else if (elem_bytes == 8) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_dither<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_dither<unsigned long long>, 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, (unsigned long long *)d_out, wts);
-    } else throw HipError("patolette_amd: map element size must be 1, 4 or 8");
+    if (elem_bytes == 1) launch_dither_t<unsigned char>(d_img, plane_stride, width, height, d_pal, k, (unsigned char *)d_out, wts, lds, s);
+    else if (elem_bytes == 4) launch_dither_t<unsigned int>(d_img, plane_stride, width, height, d_pal, k, (unsigned int *)d_out, wts, lds, s);
+    else if (elem_bytes == 8) launch_dither_t<unsigned long long>(d_img, plane_stride, width, height, d_pal, k, (unsigned long long *)d_out, wts, lds, s);
+    else throw HipError("patolette_amd: map element size must be 1, 4 or 8");
     HIP_CHECK(hipGetLastError());
 }
 
