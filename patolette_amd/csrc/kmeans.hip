@@ -25,6 +25,9 @@
 
 namespace pamd {
 
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
 // ---- sample extraction: f64 planar -> f32 SoA (refine.c:127-163), optional subsample gather ----
 template <bool W>
 __global__ __launch_bounds__(256) void k_km_gather(const double *__restrict__ planar, size_t N, const int *__restrict__ perm,
@@ -255,6 +258,7 @@ template <bool W>
 __global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sorted, const unsigned int *__restrict__ rowtot, int k,
                                                   unsigned long long nx, float *cent, float *hassign, float4 *c4,
                                                   unsigned int *ticket, DevMT *mt) {
+    constexpr int D = 8;                                                   // 1-KiB LDS-DMA loads kept in flight
     __shared__ float4 stage[2][64];
     __shared__ int s_last;
     const int kidx = blockIdx.x, lane = threadIdx.x;
@@ -265,13 +269,14 @@ __global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sor
     pre = __shfl(pre, 0, 64);
     const size_t lo = pre, hi = lo + rowtot[kidx];
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, h = 0.f;
-    constexpr int D = 8;                                                   // 1-KiB loads kept in flight
+    const long nblk = (long)((hi - lo + 63) / 64);
     float4 ring[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         ring[d] = make_float4(0, 0, 0, 0);
         if (lo + (size_t)d * 64 + lane < hi) ring[d] = sorted[lo + (size_t)d * 64 + lane];
     }
+    (void)nblk;
     int pb = 0;
     for (size_t sbase = lo; sbase < hi; sbase += (size_t)D * 64) {
 #pragma unroll
@@ -315,30 +320,33 @@ __global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sor
     }
     if (lane == 0) {
         if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
-        cent[3 * kidx] = c0; cent[3 * kidx + 1] = c1; cent[3 * kidx + 2] = c2;
-        hassign[kidx] = h;
-        // publish, then take a ticket (agent-scope release -> relaxed counter; guide G16)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // publish with write-through (sc1) stores + drained counter: no per-wave L2 write-back fence
+        // (256 release fences, each flushing the XCD's dirty lines, cost more than the chains themselves)
+        __hip_atomic_store(&cent[3 * kidx], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cent[3 * kidx + 1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cent[3 * kidx + 2], c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hassign[kidx], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (tk == (unsigned)k - 1u) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // last wavefront: every centroid was published with sc1 stores; read them back with sc1 (L1-bypassing) loads
     bool mine_empty = false;
     for (int ci = lane; ci < k; ci += 64)
         if (__hip_atomic_load(&hassign[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.f) mine_empty = true;
     const bool any = __ballot(mine_empty) != 0ULL;
     if (lane == 0) {
-        *ticket = 0u;                                                      // ready for the next iteration's launch
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next iteration's launch
         if (any) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // the split code uses plain accesses
             km_split_clusters(cent, hassign, k, nx, *mt);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int j = lane; j < k; j += 64) {
         const float v0 = __hip_atomic_load(&cent[3 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float v1 = __hip_atomic_load(&cent[3 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
