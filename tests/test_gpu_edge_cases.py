@@ -1,0 +1,140 @@
+"""Edge cases of the drop-in call on the GPU vs the CPU oracle: degenerate images, tiny sizes,
+K larger than the number of pixels / colours, every colour-space x mapping branch,
+palette_only, extreme weights."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import match_rows_up_to_permutation
+
+pytestmark = pytest.mark.gpu
+dp = C.POINTER(C.c_double)
+zp = C.POINTER(C.c_size_t)
+
+
+def _d(a):
+    return a.ctypes.data_as(dp) if a is not None else None
+
+
+def run_both(native, ob, w, h, flat, wt, K, **kw):
+    L = native.lib()
+    opts = native.QuantizationOptions(kw.get("dither", False), kw.get("palette_only", False), kw.get("color_space", 2),
+                                      kw.get("kmeans_niter", 0), kw.get("kmeans_max_samples", 512 ** 2), False)
+    pal = np.zeros((K, 3), dtype=np.float64, order="F")
+    n = w * h
+    pmap = np.full(n, 12345, dtype=np.uintp)
+    code = C.c_int(99)
+    L.patolette(w, h, _d(flat), _d(wt), K, C.byref(opts), pal.ctypes.data_as(dp),
+                None if kw.get("palette_only", False) else pmap.ctypes.data_as(zp), C.byref(code))
+    ec, pal_o, map_o = ob.patolette(w, h, flat, wt, K, dither=kw.get("dither", False), palette_only=kw.get("palette_only", False),
+                                    color_space=kw.get("color_space", 2), kmeans_niter=kw.get("kmeans_niter", 0),
+                                    kmeans_max_samples=kw.get("kmeans_max_samples", 512 ** 2))
+    return (code.value, pal, pmap), (ec, np.asarray(pal_o), map_o)
+
+
+def assert_same(got, want, ordered=True, tol=1e-9, check_map=True):
+    (ec, pal, pmap), (ec_o, pal_o, map_o) = got, want
+    assert ec == ec_o == 0
+    assert np.array_equal(pal == -1, pal_o == -1)
+    if ordered:
+        assert np.allclose(pal, pal_o, rtol=0, atol=tol, equal_nan=True), float(np.nanmax(np.abs(pal - pal_o)))
+        if check_map and map_o is not None:
+            assert np.array_equal(pmap, map_o), int(np.sum(pmap != map_o))
+    else:
+        perm = match_rows_up_to_permutation(pal, pal_o, tol)
+        assert perm is not None
+        if check_map and map_o is not None:
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(len(perm))
+            assert np.array_equal(inv[pmap.astype(np.int64)], map_o.astype(np.int64))
+
+
+@pytest.mark.parametrize("cs", [0, 1, 2])
+@pytest.mark.parametrize("dither", [False, True])
+def test_every_colour_space_and_mapping_branch(gpu, native, ob, cs, dither):
+    w, h, K = 61, 47, 20
+    flat = ob.image(w * h, 30 + cs)
+    got, want = run_both(native, ob, w, h, flat, None, K, color_space=cs, dither=dither)
+    if cs == 0 and not dither:
+        # reference quirk: sRGB + NN pushes an sRGB palette through ICtCp->sRGB; garbage in, same garbage out
+        assert_same(got, want, tol=1e-6)
+    else:
+        assert_same(got, want)
+
+
+def test_palette_only_returns_quantisation_space_palette(gpu, native, ob):
+    w, h, K = 50, 40, 16
+    flat = ob.image(w * h, 41)
+    for cs in (1, 2):
+        got, want = run_both(native, ob, w, h, flat, None, K, color_space=cs, palette_only=True)
+        assert got[0] == want[0] == 0
+        assert np.allclose(got[1], want[1], rtol=0, atol=1e-9 * max(1.0, float(np.max(np.abs(want[1])))))
+        assert np.all(got[2] == 12345)                       # map untouched (NULL passed)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 1), (1, 3), (2, 2), (3, 5), (7, 1)])
+def test_tiny_images(gpu, native, ob, shape):
+    w, h = shape
+    flat = ob.image(w * h, 50 + w + 10 * h)
+    for K in (1, 2, 4, 64):
+        got, want = run_both(native, ob, w, h, flat, None, K)
+        # clusters of two pixels are exactly collinear: order ambiguous (tests/util.py)
+        assert_same(got, want, ordered=False)
+
+
+def test_constant_image_and_two_colour_image(gpu, native, ob):
+    w, h = 40, 30
+    n = w * h
+    const = np.concatenate([np.full(n, 0.25), np.full(n, 0.5), np.full(n, 0.75)])
+    for K in (1, 5):
+        got, want = run_both(native, ob, w, h, const, None, K)
+        assert_same(got, want, ordered=False)
+        assert int((got[1][:, 0] != -1).sum()) == 1          # a single colour -> a single palette row
+    two = const.copy()
+    two[:n // 3] = 0.9                                       # red channel differs on a third of the pixels
+    got, want = run_both(native, ob, w, h, two, None, 8)
+    assert_same(got, want, ordered=False)
+    assert int((got[1][:, 0] != -1).sum()) == 2
+
+
+def test_more_colours_requested_than_pixels(gpu, native, ob):
+    w, h, K = 6, 5, 100
+    flat = ob.image(w * h, 60)
+    got, want = run_both(native, ob, w, h, flat, None, K)
+    assert int((want[1][:, 0] != -1).sum()) <= w * h
+    assert_same(got, want, ordered=False)
+
+
+def test_extreme_weights(gpu, native, ob):
+    w, h, K = 64, 48, 24
+    n = w * h
+    flat = ob.image(n, 70)
+    wt = 1.0 + 255.0 * ob.weights(n, 70) ** 4 / 256.0        # saliency-like: most ~1, a few up to ~250
+    wt[::97] = 1000.0
+    for cs, dither in ((1, True), (2, False)):
+        got, want = run_both(native, ob, w, h, flat, wt, K, color_space=cs, dither=dither)
+        assert_same(got, want)
+
+
+def test_kmeans_with_fewer_samples_than_min_and_k_not_multiple_of_8(gpu, native, ob):
+    w, h, K = 33, 31, 13
+    flat = ob.image(w * h, 80)
+    got, want = run_both(native, ob, w, h, flat, None, K, kmeans_niter=5, kmeans_max_samples=100)
+    assert_same(got, want, tol=1e-6)
+    # n == k corner case of faiss (centroids = first k samples): 4x4 image, 16 colours requested and reached
+    flat = ob.image(16, 81)
+    got, want = run_both(native, ob, 4, 4, flat, None, 16, kmeans_niter=3)
+    assert got[0] == want[0] == 0
+
+
+def test_kmeans_beyond_supported_palette_size_fails_loudly(gpu, native, ob):
+    w, h, K = 128, 128, 5000
+    flat = ob.image(w * h, 90)
+    L = native.lib()
+    opts = native.QuantizationOptions(False, False, 2, 2, 512 ** 2, False)
+    pal = np.zeros((K, 3), dtype=np.float64, order="F")
+    pmap = np.zeros(w * h, dtype=np.uintp)
+    code = C.c_int(0)
+    L.patolette(w, h, _d(flat), None, K, C.byref(opts), pal.ctypes.data_as(dp), pmap.ctypes.data_as(zp), C.byref(code))
+    assert code.value == -1 and "4096" in native.last_error()
