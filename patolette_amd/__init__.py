@@ -87,18 +87,43 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
     return (success, palette, palette_map, message)
 
 
-def quantize_batch(width, height, images, palette_size, weights=None, **kwargs):
-    """Quantise a list of independent images of identical size on the current GPU.
-
-    Per-image results are identical to separate `quantize` calls (batch
-    extension).  `weights` is None or a list with one entry (array or None) per image.
-    Returns a list of `quantize` tuples.
-    """
-    kwargs.setdefault("tile_size", 0)
+def quantize_batch(width, height, images, palette_size, weights=None, dither=True, palette_only=False,
+                   color_space=ColorSpace_ICtCp, kmeans_niter=32, kmeans_max_samples=512 ** 2, verbose=False):
+    """Quantise a list of independent images of identical size on the current GPU through
+    `patolette_amd_batch` (up to three images in flight: uploads and host-side work of one image
+    overlap kernels of another).  Per-image results are identical to separate `quantize` calls
+    (batch extension).  `weights`: None or one entry (array or None) per image.
+    Returns a list of `quantize` tuples."""
+    count = len(images)
+    n = width * height
+    datas = [np.asfortranarray(np.asarray(im), dtype=np.float64) for im in images]
+    for d in datas:
+        if d.ndim != 2 or d.shape[1] != 3:
+            raise ValueError(bad_channel_count.format(d.shape[1] if d.ndim == 2 else "?"))
+        if d.shape[0] != n:
+            raise ValueError(color_mismatch)
+    ws = [None] * count if weights is None else [None if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+                                                  for w in weights]
+    opts = _native.QuantizationOptions(bool(dither), bool(palette_only), int(color_space), int(kmeans_niter),
+                                       int(kmeans_max_samples), bool(verbose))
+    pals = [np.zeros((palette_size, 3), dtype=np.float64, order='F') for _ in range(count)]
+    maps = [None if palette_only else np.zeros(n, dtype=np.uintp) for _ in range(count)]
+    PD = _native.dp * count
+    PZ = _native.zp * count
+    d_arr = PD(*[_dp(d) for d in datas])
+    w_arr = None if weights is None else PD(*[_dp(w) if w is not None else _native.dp() for w in ws])
+    p_arr = PD(*[_dp(p) for p in pals])
+    m_arr = None if palette_only else PZ(*[m.ctypes.data_as(_native.zp) for m in maps])
+    codes = (C.c_int * count)()
+    L = _native.lib()
+    L.patolette_amd_batch(count, width, height, d_arr, w_arr, palette_size, C.byref(opts), p_arr, m_arr, codes)
     out = []
-    for i, img in enumerate(images):
-        w = None if weights is None else weights[i]
-        out.append(quantize(width, height, img, palette_size, weights=w, **kwargs))
+    for i in range(count):
+        msg = L.get_patolette_exit_code_info_message(codes[i]).decode('UTF-8')
+        if codes[i] != 0:
+            out.append((False, None, None, msg))
+        else:
+            out.append((True, pals[i], maps[i], msg))
     return out
 
 

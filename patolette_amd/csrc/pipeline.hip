@@ -10,7 +10,10 @@
 #include <functional>
 #include <chrono>
 #include <cmath>
+#include <atomic>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "color_device.h"
 #include "common.h"
@@ -809,12 +812,63 @@ void patolette_amd_device(size_t width, size_t height, const double *d_data, con
     }
 }
 
+// Independent images: up to three are in flight at once, each on its own engine (HIP stream + workspace) driven by
+// its own host thread, so the upload / host-side split-loop work of one image overlaps the kernels of another.
+// Engines are pooled per device and reused across calls.
+namespace {
+std::mutex g_pool_mu;
+std::vector<Engine *> g_pool;
+Engine *pool_acquire(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i]->device == device) { Engine *e = g_pool[i]; g_pool.erase(g_pool.begin() + i); return e; }
+    }
+    Engine *e = new Engine;
+    e->device = device;
+    return e;
+}
+void pool_release(Engine *e) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool.push_back(e); }
+}  // namespace
+
 void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
                          size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
                          size_t *const *palette_maps, int *exit_codes) {
-    for (size_t i = 0; i < count; i++)
-        patolette(width, height, data[i], weights ? weights[i] : nullptr, palette_size, options, palettes[i],
-                  palette_maps ? palette_maps[i] : nullptr, &exit_codes[i]);
+    const int v = validate(width, height, palette_size);
+    if (v != 0) { for (size_t i = 0; i < count; i++) exit_codes[i] = v; return; }
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { for (size_t i = 0; i < count; i++) exit_codes[i] = -1; return; }
+    if (engine().device >= 0) device = engine().device;
+    const size_t workers = std::min<size_t>(count, 3);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        Engine *E = nullptr;
+        try {
+            (void)hipSetDevice(device);
+            E = pool_acquire(device);
+            E->init();
+        } catch (const std::exception &ex) {
+            fprintf(stderr, "patolette: %s\n", ex.what());
+            for (size_t i; (i = next.fetch_add(1)) < count;) exit_codes[i] = -1;
+            if (E) pool_release(E);
+            return;
+        }
+        for (size_t i; (i = next.fetch_add(1)) < count;) {
+            try {
+                run_host(*E, width, height, data[i], weights ? weights[i] : nullptr, palette_size, options, palettes[i],
+                         palette_maps ? palette_maps[i] : nullptr);
+                exit_codes[i] = 0;
+            } catch (const std::exception &ex) {
+                fprintf(stderr, "patolette: %s\n", ex.what());
+                exit_codes[i] = -1;
+            }
+        }
+        pool_release(E);
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < workers; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
 }
 
 int patolette_amd_convert(int which, double *planar, size_t n) {
