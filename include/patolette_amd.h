@@ -42,6 +42,30 @@ void patolette_amd_device(size_t width, size_t height, const double *d_data, con
                           size_t palette_size, const patolette__QuantizationOptions *options,
                           double *palette, void *d_palette_map, int map_elem_bytes, int *exit_code);
 
+/* ---- 8-bit adaptors around the path ---------------------------------------
+ * Replace what every caller of the reference does by hand around quantize():
+ *   ingest          colors = img.reshape(-1,3).astype(float64) / 255           (README.md:156-158)
+ *   palette_u8      clip(palette * 255, 0, 255).astype(uint8)                  (README.md:178-181)
+ *   quantized       palette_u8[palette_map]                                    (README.md:186-187)
+ * pixels: width*height interleaved 8-bit sRGB, `channels` (3 or 4) bytes per pixel (a 4th byte is
+ * ignored).  weights: as for patolette() (NULL or width*height f64).  Outputs, each optional (NULL):
+ * palette (palette_size,3) column-major f64 exactly as patolette() returns it; palette_u8
+ * palette_size x 3 interleaved (unused rows 0); palette_map with elements of map_elem_bytes
+ * (1, 2, 4 or 8; must be able to hold palette_size-1); quantized = width*height x 3 interleaved.
+ * The conversion v/255.0 happens in the first kernel (3 B/px cross PCIe instead of 24), results
+ * are identical to the f64 entry point fed with the by-hand conversion.  The *_device flavour takes
+ * device pointers for pixels / weights / palette_map / quantized (map_elem_bytes 1 when
+ * palette_size <= 256, else 4); palette and palette_u8 stay host memory. */
+void patolette_amd_u8(size_t width, size_t height, const unsigned char *pixels, int channels, const double *weights,
+                      size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                      unsigned char *palette_u8, void *palette_map, int map_elem_bytes, unsigned char *quantized,
+                      int *exit_code);
+void patolette_amd_u8_device(size_t width, size_t height, const unsigned char *d_pixels, int channels,
+                             const double *d_weights, size_t palette_size,
+                             const patolette__QuantizationOptions *options, double *palette,
+                             unsigned char *palette_u8, void *d_palette_map, int map_elem_bytes,
+                             unsigned char *d_quantized, int *exit_code);
+
 /* ---- batch of independent images (SURVEY.md 8(b) "Batch extension") -----------------------
  * count images of identical width x height; data[i] / weights[i] (weights may be NULL or hold
  * NULL entries) / palettes[i] / palette_maps[i] / exit_codes[i] as for patolette(); device

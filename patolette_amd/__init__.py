@@ -7,7 +7,7 @@ constants.  The work behind it runs in hand-written HIP kernels on gfx950 throug
 `libpatolette_amd.so` (include/patolette.h); there is no CPU fallback.
 
 Additive (not in the reference): the `weights=` keyword (per-pixel weights, what the
-reference derives internally from its saliency map) and `quantize_batch`.
+reference derives internally from its saliency map) `quantize_batch` and the 8-bit adaptor `quantize_u8`.
 """
 import ctypes as C
 
@@ -87,6 +87,43 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
     return (success, palette, palette_map, message)
 
 
+def quantize_u8(image, palette_size, dither=True, palette_only=False, color_space=ColorSpace_ICtCp, kmeans_niter=32,
+                kmeans_max_samples=512 ** 2, weights=None, want_quantized=True):
+    """8-bit adaptor (additive): `image` is an (H, W, 3|4) uint8 sRGB array as an image
+    decoder returns it.  Does on the GPU what callers of the reference do by hand around `quantize`
+    (README.md:147-194): `colors = img/255`, `palette_u8 = clip(palette*255).astype(uint8)` and
+    `quantized = palette_u8[palette_map]`; 3 bytes per pixel cross PCIe instead of 24.
+
+    Returns (success, palette_u8 (K,3) uint8, palette_map (H,W) uint8|uint16|uint32 or None,
+    quantized (H,W,3) uint8 or None, palette (K,3) float64 as `quantize` returns it, message)."""
+    img = np.ascontiguousarray(image)
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] not in (3, 4):
+        raise ValueError("image must be an (H, W, 3|4) uint8 array")
+    height, width, channels = img.shape
+    n = width * height
+    w = None
+    if weights is not None:
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
+        if w.size != n:
+            raise ValueError("weights must hold width*height values")
+    opts = _native.QuantizationOptions(bool(dither), bool(palette_only), int(color_space), int(kmeans_niter),
+                                       int(kmeans_max_samples), False)
+    palette = np.zeros((palette_size, 3), dtype=np.float64, order='F')
+    palette_u8 = np.zeros((max(palette_size, 0), 3), dtype=np.uint8)
+    map_dtype = np.uint8 if palette_size <= 256 else (np.uint16 if palette_size <= 65536 else np.uint32)
+    pmap = None if palette_only else np.zeros((height, width), dtype=map_dtype)
+    quant = np.zeros((height, width, 3), dtype=np.uint8) if (want_quantized and not palette_only) else None
+    code = C.c_int(0)
+    L = _native.lib()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size > 0 else None   # noqa: E731
+    L.patolette_amd_u8(width, height, vp(img), channels, _dp(w), palette_size, C.byref(opts), _dp(palette), vp(palette_u8),
+                       vp(pmap), np.dtype(map_dtype).itemsize, vp(quant), C.byref(code))
+    message = L.get_patolette_exit_code_info_message(code.value).decode('UTF-8')
+    if code.value != 0:
+        return (False, None, None, None, None, message)
+    return (True, palette_u8, pmap, quant, palette, message)
+
+
 def quantize_batch(width, height, images, palette_size, weights=None, dither=True, palette_only=False,
                    color_space=ColorSpace_ICtCp, kmeans_niter=32, kmeans_max_samples=512 ** 2, verbose=False):
     """Quantise a list of independent images of identical size on the current GPU through
@@ -132,6 +169,7 @@ __all__ = [
     "__version__",
     "quantize",
     "quantize_batch",
+    "quantize_u8",
     "ColorSpace_sRGB",
     "ColorSpace_CIELuv",
     "ColorSpace_ICtCp",

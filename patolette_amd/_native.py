@@ -50,6 +50,11 @@ SYMBOLS = {
     "patolette_amd_fill_weights": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
     "patolette_amd_device": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.POINTER(QuantizationOptions), dp, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "patolette_amd_u8": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, dp, C.c_size_t, C.POINTER(QuantizationOptions), dp,
+                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "patolette_amd_u8_device": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                       C.POINTER(QuantizationOptions), dp, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.POINTER(C.c_int)]),
     "patolette_amd_batch": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(dp), C.POINTER(dp), C.c_size_t,
                                    C.POINTER(QuantizationOptions), C.POINTER(dp), C.POINTER(zp), C.POINTER(C.c_int)]),
     "patolette_amd_convert": (C.c_int, [C.c_int, dp, C.c_size_t]),

@@ -13,14 +13,28 @@
 
 namespace pamd {
 
-template <int WHICH>
-__global__ __launch_bounds__(256) void k_convert(const double *__restrict__ src, double *__restrict__ dst,
-                                                 size_t n, ConvertStats *stats) {
+// pixel sources: planar f64 sRGB (the reference ABI) or interleaved 8-bit sRGB (v/255.0 in f64, what every
+// caller of the reference computes by hand, README.md:156-158)
+struct SrcF64 {
+    const double *p; size_t n;
+    __device__ __forceinline__ void load(size_t i, double c[3]) const { c[0] = p[i]; c[1] = p[n + i]; c[2] = p[2 * n + i]; }
+};
+struct SrcU8 {
+    const unsigned char *p; int ch;
+    __device__ __forceinline__ void load(size_t i, double c[3]) const {
+        const unsigned char *q = p + i * (size_t)ch;
+        c[0] = (double)q[0] / 255.0; c[1] = (double)q[1] / 255.0; c[2] = (double)q[2] / 255.0;
+    }
+};
+
+template <int WHICH, class SRC>
+__global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ dst, size_t n, ConvertStats *stats) {
     // per-plane min / max of the OUTPUT (bounds for the binned accumulators downstream)
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double c[3] = {src[i], src[n + i], src[2 * n + i]};
+        double c[3];
+        src.load(i, c);
         dev_convert<WHICH>(c);
         dst[i] = c[0]; dst[n + i] = c[1]; dst[2 * n + i] = c[2];
 #pragma unroll
@@ -81,21 +95,75 @@ static int stream_grid(size_t n) {
     return (int)b;
 }
 
-void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s) {
+void launch_convert(int which, const double *src_p, double *dst, size_t n, ConvertStats *stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
     int g = stream_grid(n);
     KTIME("k_convert", s, 48.0 * n);
+    const SrcF64 src{src_p, n};
     switch (which) {
-        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL(k_convert<PAMD_SRGB_TO_ICTCP>, g, 256, 0, s, src, dst, n, stats); break;
-        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL(k_convert<PAMD_SRGB_TO_CIELUV>, g, 256, 0, s, src, dst, n, stats); break;
-        case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL(k_convert<PAMD_ICTCP_TO_REC2020>, g, 256, 0, s, src, dst, n, stats); break;
-        case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL(k_convert<PAMD_CIELUV_TO_REC2020>, g, 256, 0, s, src, dst, n, stats); break;
-        case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL(k_convert<PAMD_SRGB_TO_REC2020>, g, 256, 0, s, src, dst, n, stats); break;
-        case PAMD_REC2020_TO_SRGB: hipLaunchKernelGGL(k_convert<PAMD_REC2020_TO_SRGB>, g, 256, 0, s, src, dst, n, stats); break;
-        case PAMD_CIELUV_TO_ICTCP: hipLaunchKernelGGL(k_convert<PAMD_CIELUV_TO_ICTCP>, g, 256, 0, s, src, dst, n, stats); break;
-        case PAMD_COPY: hipLaunchKernelGGL(k_convert<PAMD_COPY>, g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_ICTCP_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_REC2020_TO_SRGB: hipLaunchKernelGGL((k_convert<PAMD_REC2020_TO_SRGB, SrcF64>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_CIELUV_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64>), g, 256, 0, s, src, dst, n, stats); break;
         default: throw HipError("patolette_amd: unknown conversion");
     }
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
+                       hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
+    int g = stream_grid(n);
+    KTIME("k_convert_u8", s, (24.0 + channels) * n);
+    const SrcU8 src{pixels, channels};
+    switch (which) {
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcU8>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcU8>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcU8>), g, 256, 0, s, src, dst, n, stats); break;
+        default: throw HipError("patolette_amd: unknown conversion");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// quantized image = palette_u8[map], interleaved RGB (README.md:184-191); 4 pixels (12 bytes) per thread
+template <typename MapT>
+__global__ __launch_bounds__(256) void k_reconstruct(const MapT *__restrict__ map, size_t n, const unsigned char *__restrict__ pal_u8,
+                                                     int k, unsigned char *__restrict__ out) {
+    extern __shared__ unsigned char spal[];
+    for (int i = threadIdx.x; i < 3 * k; i += blockDim.x) spal[i] = pal_u8[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t groups = n / 4;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+        unsigned int w[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned int m = (unsigned int)map[4 * g + j];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int b = 3 * j + c;
+                w[b >> 2] |= (unsigned int)spal[3 * m + c] << (8 * (b & 3));
+            }
+        }
+        unsigned int *o = reinterpret_cast<unsigned int *>(out + 12 * g);       // out is hipMalloc'd: 12*g is 4-byte aligned
+        o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = groups * 4 + threadIdx.x;
+        const unsigned int m = (unsigned int)map[i];
+        for (int c = 0; c < 3; c++) out[3 * i + c] = spal[3 * m + c];
+    }
+}
+
+void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned char *pal_u8, int k, unsigned char *out, hipStream_t s) {
+    KTIME("k_reconstruct", s, (3.0 + map_elem) * n);
+    const int g = stream_grid(ceil_div(n, 4));
+    if (map_elem == 1) hipLaunchKernelGGL(k_reconstruct<unsigned char>, g, 256, 3 * k, s, (const unsigned char *)map, n, pal_u8, k, out);
+    else hipLaunchKernelGGL(k_reconstruct<unsigned int>, g, 256, 3 * k, s, (const unsigned int *)map, n, pal_u8, k, out);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -26,6 +26,10 @@ namespace pamd {
 
 // launchers defined in color.hip
 void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s);
+void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
+                       hipStream_t s);
+void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned char *pal_u8, int k, unsigned char *out,
+                        hipStream_t s);
 void launch_weight_stats(const double *w, size_t n, ConvertStats *stats, hipStream_t s);
 void launch_fill_image(double *d, size_t n, uint64_t seed, hipStream_t s);
 void launch_fill_weights(double *d, size_t n, uint64_t seed, hipStream_t s);
@@ -112,7 +116,7 @@ struct Engine {
     DevBuf<double> hist, sum6, dpal;
     DevBuf<unsigned long long> hsize, tileoff;
     DevBuf<unsigned int> hcount, tilecnt;
-    DevBuf<unsigned char> lut, dmap;
+    DevBuf<unsigned char> lut, dmap, src8, pal8, quant8;
     DevBuf<ConvertStats> cstats;
     PinBuf<NodeIn> h_stage_in;
     PinBuf<NodeOut> h_stage_out;
@@ -598,7 +602,13 @@ static Bounds read_bounds(Engine &E, bool weighted) {
 // --------------------------------------------------------------------------------------------
 // the full path, inputs resident in HBM
 // --------------------------------------------------------------------------------------------
-static void run_device(Engine &E, size_t width, size_t height, const double *d_data, const double *d_weights, size_t K,
+struct Pixels {                      // device-resident input image: planar f64 sRGB, or interleaved 8-bit sRGB
+    const double *f64 = nullptr;
+    const unsigned char *u8 = nullptr;
+    int channels = 3;
+};
+
+static void run_device(Engine &E, size_t width, size_t height, Pixels px, const double *d_weights, size_t K,
                        const patolette__QuantizationOptions *opt, double *palette, void *d_map, int map_elem) {
     hipStream_t s = E.stream;
     const size_t N = width * height;
@@ -612,7 +622,8 @@ static void run_device(Engine &E, size_t width, size_t height, const double *d_d
     int which = PAMD_COPY;
     if (opt->color_space == patolette__CIELuv) which = PAMD_SRGB_TO_CIELUV;
     else if (opt->color_space == patolette__ICtCp) which = PAMD_SRGB_TO_ICTCP;
-    launch_convert(which, d_data, E.cvt.p, N, E.cstats.p, s);
+    if (px.u8) launch_convert_u8(which, px.u8, px.channels, E.cvt.p, N, E.cstats.p, s);
+    else launch_convert(which, px.f64, E.cvt.p, N, E.cstats.p, s);
     if (weighted) {
         HIP_CHECK(hipMemcpyAsync(E.cvt.p + 3 * N, d_weights, N * sizeof(double), hipMemcpyDeviceToDevice, s));
         launch_weight_stats(d_weights, N, E.cstats.p, s);
@@ -701,7 +712,7 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     const int me = map_elem_for(K);
     if (!opt->palette_only) E.dmap.reserve(N * (size_t)me);
     std::vector<double> pal(3 * K);
-    run_device(E, width, height, E.src.p, weights ? E.wsrc.p : nullptr, K, opt, pal.data(), E.dmap.p, me);
+    run_device(E, width, height, Pixels{E.src.p, nullptr, 3}, weights ? E.wsrc.p : nullptr, K, opt, pal.data(), E.dmap.p, me);
     t0 = now_ms();
     if (!opt->palette_only) {
         const bool touched = !(opt->dither && std::max(width, height) <= 1);   // 1x1 dither visits nothing (riemersma.c:452-456)
@@ -721,6 +732,99 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     E.stats.ms_upload = up;
     E.stats.ms_download = now_ms() - t0;
     E.stats.ms_total += up + E.stats.ms_download;
+}
+
+// palette_u8 = clip(palette * 255, 0, 255) truncated (README.md:178-181); unused rows (-1) become 0
+static void palette_to_u8(const double *palette, size_t K, unsigned char *out) {
+    for (size_t i = 0; i < K; i++)
+        for (int c = 0; c < 3; c++) {
+            double v = palette[K * (size_t)c + i] * 255.0;
+            v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+            out[3 * i + c] = (unsigned char)v;
+        }
+}
+
+// 8-bit adaptor around the path: interleaved u8 in; f64 palette, u8 palette, index map and
+// reconstructed u8 image out.  `pixels`, `d_map_out`, `d_quant_out` are device pointers when `on_device`.
+static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *pixels, int channels, const double *weights,
+                   size_t K, const patolette__QuantizationOptions *opt, double *palette, unsigned char *palette_u8,
+                   void *map_out, int map_elem_out, unsigned char *quant_out, bool on_device) {
+    const size_t N = width * height;
+    hipStream_t s = E.stream;
+    double t0 = now_ms();
+    const unsigned char *d_px = pixels;
+    const double *d_w = weights;
+    if (!on_device) {
+        E.src8.reserve(N * (size_t)channels);
+        HIP_CHECK(hipMemcpyAsync(E.src8.p, pixels, N * (size_t)channels, hipMemcpyHostToDevice, s));
+        d_px = E.src8.p;
+        if (weights) {
+            E.wsrc.reserve(N);
+            HIP_CHECK(hipMemcpyAsync(E.wsrc.p, weights, N * sizeof(double), hipMemcpyHostToDevice, s));
+            d_w = E.wsrc.p;
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    const double up = now_ms() - t0;
+    const int me = map_elem_for(K);
+    const bool want_map = !opt->palette_only && (map_out || quant_out);
+    patolette__QuantizationOptions o2 = *opt;
+    if (!want_map) o2.palette_only = true;
+    void *d_map = nullptr;
+    if (want_map) {
+        if (on_device && map_out && map_elem_out == me) d_map = map_out;
+        else { E.dmap.reserve(N * (size_t)me); d_map = E.dmap.p; }
+    }
+    std::vector<double> pal(3 * K);
+    run_device(E, width, height, Pixels{nullptr, d_px, channels}, d_w, K, &o2, pal.data(), d_map, me);
+    t0 = now_ms();
+    std::vector<unsigned char> p8(3 * K);
+    palette_to_u8(pal.data(), K, p8.data());
+    if (palette) std::memcpy(palette, pal.data(), 3 * K * sizeof(double));
+    if (palette_u8) std::memcpy(palette_u8, p8.data(), 3 * K);
+    const bool touched = !(opt->dither && std::max(width, height) <= 1);       // 1x1 dither visits nothing
+    if (want_map && touched) {
+        if (quant_out) {
+            E.pal8.reserve(3 * K);
+            HIP_CHECK(hipMemcpyAsync(E.pal8.p, p8.data(), 3 * K, hipMemcpyHostToDevice, s));
+            unsigned char *d_q = quant_out;
+            if (!on_device) { E.quant8.reserve(3 * N); d_q = E.quant8.p; }
+            launch_reconstruct(d_map, me, N, E.pal8.p, (int)K, d_q, s);
+            if (!on_device) HIP_CHECK(hipMemcpyAsync(quant_out, d_q, 3 * N, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+        if (map_out && d_map != map_out) {
+            if (on_device) throw HipError("patolette_amd: device map_elem_bytes must be 1 for K <= 256, else 4");
+            if (map_elem_out == me) HIP_CHECK(hipMemcpy(map_out, d_map, N * (size_t)me, hipMemcpyDeviceToHost));
+            else {
+                std::vector<unsigned char> tmp(N * (size_t)me);
+                HIP_CHECK(hipMemcpy(tmp.data(), d_map, tmp.size(), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < N; i++) {
+                    const size_t v = me == 1 ? (size_t)tmp[i] : (size_t)reinterpret_cast<unsigned int *>(tmp.data())[i];
+                    switch (map_elem_out) {
+                        case 1: ((unsigned char *)map_out)[i] = (unsigned char)v; break;
+                        case 2: ((unsigned short *)map_out)[i] = (unsigned short)v; break;
+                        case 4: ((unsigned int *)map_out)[i] = (unsigned int)v; break;
+                        default: ((size_t *)map_out)[i] = v; break;
+                    }
+                }
+            }
+        }
+        E.sync();
+    }
+    E.stats.ms_upload = up;
+    E.stats.ms_download = now_ms() - t0;
+    E.stats.ms_total += up + E.stats.ms_download;
+}
+
+static int validate_u8(size_t K, int channels, const void *map_out, int map_elem) {
+    if (channels != 3 && channels != 4) return -1;
+    if (map_out) {
+        if (map_elem != 1 && map_elem != 2 && map_elem != 4 && map_elem != 8) return -1;
+        if (map_elem == 1 && K > 256) return -1;
+        if (map_elem == 2 && K > 65536) return -1;
+    }
+    return 0;
 }
 
 }  // namespace pamd
@@ -802,7 +906,8 @@ void patolette_amd_device(size_t width, size_t height, const double *d_data, con
         Engine &E = engine();
         E.init();
         std::vector<double> pal(3 * palette_size);
-        run_device(E, width, height, d_data, d_weights, palette_size, options, pal.data(), d_palette_map, map_elem_bytes);
+        run_device(E, width, height, Pixels{d_data, nullptr, 3}, d_weights, palette_size, options, pal.data(), d_palette_map,
+                   map_elem_bytes);
         std::memcpy(palette, pal.data(), 3 * palette_size * sizeof(double));
         *exit_code = 0;
     } catch (const std::exception &ex) {
@@ -810,6 +915,44 @@ void patolette_amd_device(size_t width, size_t height, const double *d_data, con
         fprintf(stderr, "patolette: %s\n", ex.what());
         *exit_code = -1;
     }
+}
+
+static void u8_entry(bool on_device, size_t width, size_t height, const unsigned char *pixels, int channels,
+                     const double *weights, size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                     unsigned char *palette_u8, void *palette_map, int map_elem_bytes, unsigned char *quantized, int *exit_code) {
+    *exit_code = validate(width, height, palette_size);
+    if (*exit_code != 0) return;
+    if (validate_u8(palette_size, channels, palette_map, map_elem_bytes) != 0) {
+        fprintf(stderr, "patolette_amd: bad channels / map_elem_bytes for the u8 entry point\n");
+        *exit_code = -1;
+        return;
+    }
+    try {
+        Engine &E = engine();
+        E.init();
+        run_u8(E, width, height, pixels, channels, weights, palette_size, options, palette, palette_u8, palette_map, map_elem_bytes,
+               quantized, on_device);
+        *exit_code = 0;
+    } catch (const std::exception &ex) {
+        engine().last_error = ex.what();
+        fprintf(stderr, "patolette: %s\n", ex.what());
+        *exit_code = -1;
+    }
+}
+
+void patolette_amd_u8(size_t width, size_t height, const unsigned char *pixels, int channels, const double *weights,
+                      size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                      unsigned char *palette_u8, void *palette_map, int map_elem_bytes, unsigned char *quantized, int *exit_code) {
+    u8_entry(false, width, height, pixels, channels, weights, palette_size, options, palette, palette_u8, palette_map,
+             map_elem_bytes, quantized, exit_code);
+}
+
+void patolette_amd_u8_device(size_t width, size_t height, const unsigned char *d_pixels, int channels, const double *d_weights,
+                             size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                             unsigned char *palette_u8, void *d_palette_map, int map_elem_bytes, unsigned char *d_quantized,
+                             int *exit_code) {
+    u8_entry(true, width, height, d_pixels, channels, d_weights, palette_size, options, palette, palette_u8, d_palette_map,
+             map_elem_bytes, d_quantized, exit_code);
 }
 
 // Independent images: up to three are in flight at once, each on its own engine (HIP stream + workspace) driven by

@@ -239,3 +239,36 @@ def test_batch_equals_individual_calls(gpu, ob):
         one = p.quantize(w, h, imgs[i], K, dither=False, tile_size=0, kmeans_niter=4, kmeans_max_samples=65536, weights=wts[i])
         assert batch[i][0] and one[0]
         assert np.array_equal(batch[i][1], one[1]) and np.array_equal(batch[i][2], one[2])
+
+
+@pytest.mark.parametrize("channels,K,dither,cs", [(3, 64, False, 2), (4, 64, True, 1), (3, 300, False, 0), (3, 16, True, 2)])
+def test_u8_adaptor_equals_by_hand_steps(gpu, ob, channels, K, dither, cs):
+    """quantize_u8 == what README.md:147-194 does by hand around quantize(), and == the oracle fed with img/255."""
+    import patolette_amd as p
+    w, h = 83, 61
+    n = w * h
+    rng = np.random.default_rng(5 + K)
+    img = rng.integers(0, 256, size=(h, w, channels), dtype=np.uint8)
+    wts = ob.weights(n, 9) if dither else None
+    ok, pal8, pmap, quant, pal, msg = p.quantize_u8(img, K, dither=dither, color_space=cs, kmeans_niter=3,
+                                                    kmeans_max_samples=4096, weights=wts)
+    assert ok and msg == "Quantization successful."
+    colors = img[:, :, :3].reshape(-1, 3).astype(np.float64)
+    colors /= 255
+    ok2, pal_f, pmap_f, _ = p.quantize(w, h, colors, K, dither=dither, color_space=cs, tile_size=0, kmeans_niter=3,
+                                       kmeans_max_samples=4096, weights=wts)
+    assert ok2
+    assert np.array_equal(pal, pal_f)
+    assert np.array_equal(pmap.reshape(-1).astype(np.uintp), pmap_f)
+    by_hand = np.clip(pal_f * 255, 0, 255).astype(np.uint8)
+    assert pal8.dtype == np.uint8 and np.array_equal(pal8, by_hand)
+    assert np.array_equal(quant, by_hand[pmap_f].reshape(h, w, 3))
+    assert pmap.dtype == (np.uint8 if K <= 256 else np.uint16)
+    ec, pal_o, pmap_o = ob.patolette(w, h, ob.planar(colors), wts, K, dither=dither, color_space=cs, kmeans_niter=3,
+                                     kmeans_max_samples=4096)
+    assert ec == 0 and np.array_equal(pmap_f, pmap_o)
+    assert np.allclose(pal_f, pal_o, rtol=0, atol=1e-9)
+    # palette only / no reconstructed image
+    ok3, pal8b, pm3, q3, _, _ = p.quantize_u8(img, K, palette_only=True, color_space=cs, kmeans_niter=3, kmeans_max_samples=4096,
+                                              dither=dither, weights=wts)
+    assert ok3 and pm3 is None and q3 is None and np.array_equal(pal8b, pal8)
