@@ -42,13 +42,38 @@ void patolette_amd_device(size_t width, size_t height, const double *d_data, con
                           size_t palette_size, const patolette__QuantizationOptions *options,
                           double *palette, void *d_palette_map, int map_elem_bytes, int *exit_code);
 
+/* ---- saliency-derived weights ----------------------------------------------
+ * What the reference's Python binding computes before calling patolette() when tile_size > 0
+ * (`get_weights`, src/patolette/patolette.pyx:203-313, called at :407-414): minimum-barrier-distance
+ * saliency of the channel-mean image (3 raster scans), Mahalanobis colour contrast against the four
+ * border bands in CIELAB, centre prior, sigmoid; weight = 1 + sal^2 * width*height / tile_size^2.
+ *
+ * patolette_amd_quantize = patolette() with the binding's tile_size semantics: `weights` non-NULL ->
+ * used as given; else tile_size > 0 -> weights derived on the device (never leave HBM); else
+ * unweighted.  Extra exit codes (messages via get_patolette_exit_code_info_message): -5 the image
+ * shape cannot be processed (the reference raises for it too: a side <= 3 pixels, fewer than 100
+ * pixels, or a border band of floor(0.1*sqrt(w*h)) pixels that does not fit), -6 a border band has
+ * a singular colour covariance (numpy raises LinAlgError in the reference). */
+void patolette_amd_quantize(size_t width, size_t height, const double *data, const double *weights,
+                            double tile_size, size_t palette_size,
+                            const patolette__QuantizationOptions *options, double *palette,
+                            size_t *palette_map, int *exit_code);
+/* the stage alone, host buffers: data as for patolette(); weights_out[width*height].  Returns 0,
+ * -1 (HIP error), -2 (shape), -3 (singular covariance). */
+int patolette_amd_saliency_weights(size_t width, size_t height, const double *data, double tile_size,
+                                   double *weights_out);
+
+/* mbd(img, iters) alone (patolette.pyx:156-201): img / out f32 row-major (rows, cols), host buffers.
+ * Returns 0, -1 (HIP error) or -2 (rows <= 3 or cols <= 3: the reference returns None). */
+int patolette_amd_mbd(size_t rows, size_t cols, const float *img, int iters, float *out);
+
 /* ---- 8-bit adaptors around the path ---------------------------------------
  * Replace what every caller of the reference does by hand around quantize():
  *   ingest          colors = img.reshape(-1,3).astype(float64) / 255           (README.md:156-158)
  *   palette_u8      clip(palette * 255, 0, 255).astype(uint8)                  (README.md:178-181)
  *   quantized       palette_u8[palette_map]                                    (README.md:186-187)
  * pixels: width*height interleaved 8-bit sRGB, `channels` (3 or 4) bytes per pixel (a 4th byte is
- * ignored).  weights: as for patolette() (NULL or width*height f64).  Outputs, each optional (NULL):
+ * ignored).  weights / tile_size: as for patolette_amd_quantize().  Outputs, each optional (NULL):
  * palette (palette_size,3) column-major f64 exactly as patolette() returns it; palette_u8
  * palette_size x 3 interleaved (unused rows 0); palette_map with elements of map_elem_bytes
  * (1, 2, 4 or 8; must be able to hold palette_size-1); quantized = width*height x 3 interleaved.
@@ -57,11 +82,11 @@ void patolette_amd_device(size_t width, size_t height, const double *d_data, con
  * device pointers for pixels / weights / palette_map / quantized (map_elem_bytes 1 when
  * palette_size <= 256, else 4); palette and palette_u8 stay host memory. */
 void patolette_amd_u8(size_t width, size_t height, const unsigned char *pixels, int channels, const double *weights,
-                      size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                      double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
                       unsigned char *palette_u8, void *palette_map, int map_elem_bytes, unsigned char *quantized,
                       int *exit_code);
 void patolette_amd_u8_device(size_t width, size_t height, const unsigned char *d_pixels, int channels,
-                             const double *d_weights, size_t palette_size,
+                             const double *d_weights, double tile_size, size_t palette_size,
                              const patolette__QuantizationOptions *options, double *palette,
                              unsigned char *palette_u8, void *d_palette_map, int map_elem_bytes,
                              unsigned char *d_quantized, int *exit_code);
@@ -109,7 +134,7 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
 
 /* ---- statistics of the last full-path call on this thread -------------------------------- */
 typedef struct patolette_amd__Stats {
-    double ms_total, ms_upload, ms_convert, ms_gq, ms_lq, ms_kmeans, ms_map, ms_download;
+    double ms_total, ms_upload, ms_convert, ms_gq, ms_lq, ms_kmeans, ms_map, ms_download, ms_saliency;
     size_t n_base_clusters;   /* clusters produced by the global quantiser */
     size_t n_clusters;        /* final palette rows */
     size_t split_evals;       /* split_cluster evaluations performed on the GPU */

@@ -76,6 +76,8 @@ def lib():
         L.orc_dither_riemersma_prefix.restype = None
         L.orc_hilbert_order.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]
         L.orc_hilbert_order.restype = C.c_size_t
+        L.orc_mbd.argtypes = [C.c_size_t, C.c_size_t, fp, C.c_int, fp]
+        L.orc_mbd.restype = C.c_int
         L.orc_patolette.argtypes = [C.c_size_t, C.c_size_t, dp, dp, C.c_size_t, C.POINTER(Options),
                                     dp, zp, C.POINTER(C.c_int)]
         L.orc_patolette.restype = None
@@ -178,6 +180,15 @@ def hilbert_order(width, height):
     out = np.zeros(max(1, width * height), dtype=np.uint64)
     n = lib().orc_hilbert_order(width, height, out.ctypes.data_as(C.POINTER(C.c_uint64)))
     return out[:n].copy()
+
+
+def mbd(img32, iters=3):
+    """img32: (rows, cols) float32.  Returns D (rows, cols) float32, or None for images <= 3 in a dimension."""
+    img32 = np.ascontiguousarray(img32, dtype=np.float32)
+    rows, cols = img32.shape
+    out = np.zeros((rows, cols), dtype=np.float32)
+    rc = lib().orc_mbd(rows, cols, img32.ctypes.data_as(fp), iters, out.ctypes.data_as(fp))
+    return None if rc != 0 else out
 
 
 def patolette(width, height, flat, w, K, dither=True, palette_only=False, color_space=2,

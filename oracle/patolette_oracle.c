@@ -1404,3 +1404,58 @@ void orc_patolette(size_t width, size_t height, const double *data, const double
     g_timings[5] = now_s() - t0;
     *exit_code = 0;
 }
+
+/* ======================================================================================
+ * Minimum-barrier-distance scans of the saliency map -- src/patolette/patolette.pyx:54-201
+ * (the Cython loops of the Python binding; everything around them is numpy/scipy and is
+ * restated in oracle/saliency.py).  All f32, row-major (rows, cols).
+ * ==================================================================================== */
+static inline float mbd_max(float a, float b) { return a > b ? a : b; }
+static inline float mbd_min(float a, float b) { return a < b ? a : b; }
+
+/* One visit (patolette.pyx:75-98 / :124-147): candidate barriers through the already-scanned
+ * vertical neighbour (b1) and horizontal neighbour (b2); keep d when it is <= both, else b1
+ * when it is the strictly-better-than-d, not-worse-than-b2 one, else b2. */
+static inline void mbd_visit(const float *img, float *L, float *U, float *D, size_t at, size_t vert, size_t horz) {
+    float ix = img[at], d = D[at];
+    float u1 = U[vert], l1 = L[vert], u2 = U[horz], l2 = L[horz];
+    float b1 = mbd_max(u1, ix) - mbd_min(l1, ix);
+    float b2 = mbd_max(u2, ix) - mbd_min(l2, ix);
+    if (d <= b1 && d <= b2) return;
+    if (b1 < d && b1 <= b2) { D[at] = b1; U[at] = mbd_max(u1, ix); L[at] = mbd_min(l1, ix); }
+    else { D[at] = b2; U[at] = mbd_max(u2, ix); L[at] = mbd_min(l2, ix); }
+}
+
+/* forward scan: rows 1..rows-2, cols 1..cols-2, neighbours above / left (patolette.pyx:72-103) */
+static void mbd_scan_forward(size_t rows, size_t cols, const float *img, float *L, float *U, float *D) {
+    for (size_t x = 1; x + 1 < rows; x++)
+        for (size_t y = 1; y + 1 < cols; y++)
+            mbd_visit(img, L, U, D, x * cols + y, (x - 1) * cols + y, x * cols + y - 1);
+}
+/* inverse scan: rows rows-2..2, cols cols-2..2 (the loops stop at `> 1`), neighbours below / right
+ * (patolette.pyx:121-152) */
+static void mbd_scan_inverse(size_t rows, size_t cols, const float *img, float *L, float *U, float *D) {
+    for (size_t x = rows - 2; x > 1; x--)
+        for (size_t y = cols - 2; y > 1; y--)
+            mbd_visit(img, L, U, D, x * cols + y, (x + 1) * cols + y, x * cols + y + 1);
+}
+
+/* mbd(img, iter) (patolette.pyx:156-201): L = U = img, D = +inf inside / 0 on the one-pixel frame;
+ * pass p runs the forward scan when p is odd, the inverse scan when p is even.  Returns 0, or -1
+ * for images with rows <= 3 or cols <= 3 (the reference returns None). */
+int orc_mbd(size_t rows, size_t cols, const float *img, int iters, float *D) {
+    if (rows <= 3 || cols <= 3) return -1;
+    size_t n = rows * cols;
+    float *L = (float *)malloc(sizeof(float) * n), *U = (float *)malloc(sizeof(float) * n);
+    memcpy(L, img, sizeof(float) * n);
+    memcpy(U, img, sizeof(float) * n);
+    for (size_t x = 0; x < rows; x++)
+        for (size_t y = 0; y < cols; y++)
+            D[x * cols + y] = (x == 0 || y == 0 || x == rows - 1 || y == cols - 1) ? 0.0f : INFINITY;
+    for (int p = 0; p < iters; p++) {
+        if (p % 2 == 1) mbd_scan_forward(rows, cols, img, L, U, D);
+        else mbd_scan_inverse(rows, cols, img, L, U, D);
+    }
+    free(L); free(U);
+    return 0;
+}

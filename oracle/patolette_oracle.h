@@ -94,6 +94,10 @@ void orc_dither_riemersma_prefix(const double *colors, size_t width, size_t heig
  * returns its length (== width*height unless the image is 1x1). */
 size_t orc_hilbert_order(size_t width, size_t height, uint64_t *order);
 
+/* ---- minimum-barrier-distance scans of the saliency map (src/patolette/patolette.pyx:54-201);
+ * img / D: f32 row-major (rows, cols).  The numpy part of get_weights is oracle/saliency.py. */
+int orc_mbd(size_t rows, size_t cols, const float *img, int iters, float *D);
+
 /* ---- the whole thing: same signature and semantics as patolette() (lib/src/patolette.c:157-343) */
 void orc_patolette(size_t width, size_t height, const double *data, const double *weights,
                    size_t palette_size, const orc_Options *options, double *palette,

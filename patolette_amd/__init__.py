@@ -6,8 +6,9 @@ the same `(success, palette, palette_map, message)` return tuple, plus the `Colo
 constants.  The work behind it runs in hand-written HIP kernels on gfx950 through the C ABI of
 `libpatolette_amd.so` (include/patolette.h); there is no CPU fallback.
 
-Additive (not in the reference): the `weights=` keyword (per-pixel weights, what the
-reference derives internally from its saliency map) `quantize_batch` and the 8-bit adaptor `quantize_u8`.
+`tile_size > 0` derives the saliency weights on the GPU as the reference's binding does on the CPU
+(patolette.pyx:203-313).  Additive (not in the reference): the `weights=` keyword (explicit
+per-pixel weights instead of the saliency-derived ones), `saliency_weights`, `quantize_batch` and the 8-bit adaptor `quantize_u8`.
 """
 import ctypes as C
 
@@ -28,10 +29,15 @@ color_mismatch = "The number of colors doesn't match the supplied width and heig
 bad_channel_count = 'Expected colors to be in sRGB[0, 1] space. Channel count mismatch: {} found.'
 bad_tile_size = 'tile_size parameter expected to be in the range [0, inf]'
 
-_no_saliency = (
-    "patolette_amd: tile_size > 0 asks for the reference's saliency-derived weights "
-    "(patolette.pyx:203-313), which this build does not implement yet. Pass tile_size=0 "
-    "(no weights) or weights=<array of width*height floats >= 1>.")
+
+
+def _raise_saliency(code, message):
+    """Exit codes of the saliency stage: the reference raises Python exceptions in the same situations
+    (patolette.pyx:157-158 / :228-232 shape, numpy LinAlgError for a singular border covariance)."""
+    if code == -5:
+        raise ValueError(message)
+    if code == -6:
+        raise np.linalg.LinAlgError("Singular matrix (%s)" % message)
 
 
 def _dp(a):
@@ -63,8 +69,6 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
         w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
         if w.size != color_count:
             raise ValueError("weights must hold width*height values")
-    elif tile_size > 0:
-        raise NotImplementedError(_no_saliency)
 
     opts = _native.QuantizationOptions(bool(dither), bool(palette_only), int(color_space), int(kmeans_niter),
                                        int(kmeans_max_samples), bool(verbose))
@@ -75,11 +79,13 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
         palette_map = np.zeros(width * height, dtype=np.uintp)
     exit_code = C.c_int(0)
     L = _native.lib()
-    L.patolette(width, height, _dp(data), _dp(w), palette_size, C.byref(opts), _dp(palette),
-                palette_map.ctypes.data_as(_native.zp) if palette_map is not None and palette_map.size > 0 else None,
-                C.byref(exit_code))
+    # tile_size > 0 and no explicit weights: saliency weights derived on the device (patolette.pyx:407-414)
+    L.patolette_amd_quantize(width, height, _dp(data), _dp(w), float(tile_size), palette_size, C.byref(opts), _dp(palette),
+                             palette_map.ctypes.data_as(_native.zp) if palette_map is not None and palette_map.size > 0 else None,
+                             C.byref(exit_code))
     success = exit_code.value == 0
     message = L.get_patolette_exit_code_info_message(exit_code.value).decode('UTF-8')
+    _raise_saliency(exit_code.value, message)
     if not success:
         return (success, None, None, message)
     if opts.palette_only:
@@ -87,8 +93,27 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
     return (success, palette, palette_map, message)
 
 
-def quantize_u8(image, palette_size, dither=True, palette_only=False, color_space=ColorSpace_ICtCp, kmeans_niter=32,
-                kmeans_max_samples=512 ** 2, weights=None, want_quantized=True):
+def saliency_weights(width, height, colors, tile_size=512):
+    """The weights `quantize` derives when tile_size > 0 (reference `get_weights`, patolette.pyx:203-313),
+    computed on the GPU.  colors as for `quantize`.  Returns width*height float64."""
+    colors = np.asarray(colors)
+    if colors.ndim != 2 or colors.shape[1] != 3 or colors.shape[0] != width * height:
+        raise ValueError(color_mismatch)
+    data = np.asfortranarray(colors, dtype=np.float64)
+    out = np.zeros(width * height, dtype=np.float64)
+    L = _native.lib()
+    rc = L.patolette_amd_saliency_weights(width, height, _dp(data), float(tile_size), _dp(out))
+    if rc == -2:
+        _raise_saliency(-5, L.get_patolette_exit_code_info_message(-5).decode('UTF-8'))
+    if rc == -3:
+        _raise_saliency(-6, L.get_patolette_exit_code_info_message(-6).decode('UTF-8'))
+    if rc != 0:
+        raise RuntimeError(_native.last_error())
+    return out
+
+
+def quantize_u8(image, palette_size, dither=True, palette_only=False, color_space=ColorSpace_ICtCp, tile_size=512,
+                kmeans_niter=32, kmeans_max_samples=512 ** 2, weights=None, want_quantized=True):
     """8-bit adaptor (additive): `image` is an (H, W, 3|4) uint8 sRGB array as an image
     decoder returns it.  Does on the GPU what callers of the reference do by hand around `quantize`
     (README.md:147-194): `colors = img/255`, `palette_u8 = clip(palette*255).astype(uint8)` and
@@ -116,9 +141,10 @@ def quantize_u8(image, palette_size, dither=True, palette_only=False, color_spac
     code = C.c_int(0)
     L = _native.lib()
     vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size > 0 else None   # noqa: E731
-    L.patolette_amd_u8(width, height, vp(img), channels, _dp(w), palette_size, C.byref(opts), _dp(palette), vp(palette_u8),
-                       vp(pmap), np.dtype(map_dtype).itemsize, vp(quant), C.byref(code))
+    L.patolette_amd_u8(width, height, vp(img), channels, _dp(w), float(tile_size), palette_size, C.byref(opts), _dp(palette),
+                       vp(palette_u8), vp(pmap), np.dtype(map_dtype).itemsize, vp(quant), C.byref(code))
     message = L.get_patolette_exit_code_info_message(code.value).decode('UTF-8')
+    _raise_saliency(code.value, message)
     if code.value != 0:
         return (False, None, None, None, None, message)
     return (True, palette_u8, pmap, quant, palette, message)
@@ -170,6 +196,7 @@ __all__ = [
     "quantize",
     "quantize_batch",
     "quantize_u8",
+    "saliency_weights",
     "ColorSpace_sRGB",
     "ColorSpace_CIELuv",
     "ColorSpace_ICtCp",

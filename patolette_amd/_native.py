@@ -22,7 +22,7 @@ class QuantizationOptions(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_total", "ms_upload", "ms_convert", "ms_gq", "ms_lq",
-                                          "ms_kmeans", "ms_map", "ms_download")] + \
+                                          "ms_kmeans", "ms_map", "ms_download", "ms_saliency")] + \
                [(n, C.c_size_t) for n in ("n_base_clusters", "n_clusters", "split_evals", "split_px",
                                           "lq_rounds", "kmeans_samples")]
 
@@ -50,9 +50,14 @@ SYMBOLS = {
     "patolette_amd_fill_weights": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
     "patolette_amd_device": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.POINTER(QuantizationOptions), dp, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
-    "patolette_amd_u8": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, dp, C.c_size_t, C.POINTER(QuantizationOptions), dp,
-                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
-    "patolette_amd_u8_device": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+    "patolette_amd_quantize": (None, [C.c_size_t, C.c_size_t, dp, dp, C.c_double, C.c_size_t, C.POINTER(QuantizationOptions), dp, zp,
+                                      C.POINTER(C.c_int)]),
+    "patolette_amd_saliency_weights": (C.c_int, [C.c_size_t, C.c_size_t, dp, C.c_double, dp]),
+    "patolette_amd_mbd": (C.c_int, [C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]),
+    "patolette_amd_u8": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, dp, C.c_double, C.c_size_t,
+                                C.POINTER(QuantizationOptions), dp, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                C.POINTER(C.c_int)]),
+    "patolette_amd_u8_device": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_size_t,
                                        C.POINTER(QuantizationOptions), dp, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.POINTER(C.c_int)]),
     "patolette_amd_batch": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(dp), C.POINTER(dp), C.c_size_t,

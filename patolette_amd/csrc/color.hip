@@ -13,20 +13,6 @@
 
 namespace pamd {
 
-// pixel sources: planar f64 sRGB (the reference ABI) or interleaved 8-bit sRGB (v/255.0 in f64, what every
-// caller of the reference computes by hand, README.md:156-158)
-struct SrcF64 {
-    const double *p; size_t n;
-    __device__ __forceinline__ void load(size_t i, double c[3]) const { c[0] = p[i]; c[1] = p[n + i]; c[2] = p[2 * n + i]; }
-};
-struct SrcU8 {
-    const unsigned char *p; int ch;
-    __device__ __forceinline__ void load(size_t i, double c[3]) const {
-        const unsigned char *q = p + i * (size_t)ch;
-        c[0] = (double)q[0] / 255.0; c[1] = (double)q[1] / 255.0; c[2] = (double)q[2] / 255.0;
-    }
-};
-
 template <int WHICH, class SRC>
 __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ dst, size_t n, ConvertStats *stats) {
     // per-plane min / max of the OUTPUT (bounds for the binned accumulators downstream)

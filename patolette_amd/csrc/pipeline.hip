@@ -20,6 +20,7 @@
 #include "host_math.h"
 #include "kmeans.h"
 #include "map.h"
+#include "saliency.h"
 #include "quant.h"
 
 namespace pamd {
@@ -127,9 +128,12 @@ struct Engine {
     PinBuf<unsigned char> h_bytes;
     KMeansWork km;
     NNWork nn;
+    SalWork sal;
+    DevBuf<double> wsal;
     DevBuf<int> perm_dev;
     size_t perm_N = 0, perm_nx = 0;
     patolette_amd__Stats stats{};
+    double ms_saliency = 0.0;
     std::string last_error;
 
     void init() {
@@ -610,6 +614,7 @@ struct Pixels {                      // device-resident input image: planar f64 
 
 static void run_device(Engine &E, size_t width, size_t height, Pixels px, const double *d_weights, size_t K,
                        const patolette__QuantizationOptions *opt, double *palette, void *d_map, int map_elem) {
+    // d_map == nullptr with palette_only unset: the palette takes the same conversions, the map kernels are skipped
     hipStream_t s = E.stream;
     const size_t N = width * height;
     const bool weighted = d_weights != nullptr;
@@ -650,30 +655,36 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
             void (*pf)(double[3]) = hm::color::srgb_to_rec2020;
             if (opt->color_space == patolette__CIELuv) { pix = PAMD_CIELUV_TO_REC2020; pf = hm::color::cieluv_to_rec2020; }
             else if (opt->color_space == patolette__ICtCp) { pix = PAMD_ICTCP_TO_REC2020; pf = hm::color::ictcp_to_rec2020; }
-            E.aux.reserve(3 * N);
-            launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);              // plane stride of cvt is N for x,y,z
             palette_rows(pal, len, pf);
-            HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            launch_dither(E.aux.p, N, width, height, E.dpal.p, (int)len, d_map, map_elem, s);
+            if (d_map) {
+                E.aux.reserve(3 * N);
+                launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);          // plane stride of cvt is N for x,y,z
+                HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                launch_dither(E.aux.p, N, width, height, E.dpal.p, (int)len, d_map, map_elem, s);
+            }
             palette_rows(pal, len, hm::color::rec2020_to_srgb);
         } else {                                                               // patolette.c:300-324
             const double *pixels = E.cvt.p;
             const double *blo = bnd.lo, *bhi = bnd.hi;                         // exact min/max of the pixels being mapped
             Bounds b2;
             if (opt->color_space == patolette__CIELuv) {
-                E.aux.reserve(3 * N);
-                launch_convert(PAMD_CIELUV_TO_ICTCP, E.cvt.p, E.aux.p, N, E.cstats.p, s);
-                b2 = read_bounds(E, false);
-                blo = b2.lo; bhi = b2.hi;
-                pixels = E.aux.p;
+                if (d_map) {
+                    E.aux.reserve(3 * N);
+                    launch_convert(PAMD_CIELUV_TO_ICTCP, E.cvt.p, E.aux.p, N, E.cstats.p, s);
+                    b2 = read_bounds(E, false);
+                    blo = b2.lo; bhi = b2.hi;
+                    pixels = E.aux.p;
+                }
                 palette_rows(pal, len, hm::color::cieluv_to_rec2020);
                 palette_rows(pal, len, hm::color::rec2020_to_srgb);
                 palette_rows(pal, len, hm::color::srgb_to_ictcp);
             }
-            HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            launch_nn_map(pixels, N, N, E.dpal.p, (int)len, d_map, map_elem, blo, bhi, E.nn, s);
+            if (d_map) {
+                HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                launch_nn_map(pixels, N, N, E.dpal.p, (int)len, d_map, map_elem, blo, bhi, E.nn, s);
+            }
             palette_rows(pal, len, hm::color::ictcp_to_rec2020);
             palette_rows(pal, len, hm::color::rec2020_to_srgb);
         }
@@ -684,6 +695,24 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     for (size_t j = 0; j < K * 3; j++) palette[j] = -1.0;
     for (int j = 0; j < 3; j++) for (size_t i = 0; i < len; i++) palette[K * (size_t)j + i] = pal[(size_t)j * len + i];
     E.stats.ms_total = now_ms() - t_start;
+}
+
+struct CodeError : std::runtime_error {        // failure with a dedicated exit code (saliency stage)
+    int code;
+    CodeError(int c, const char *m) : std::runtime_error(m), code(c) {}
+};
+
+// weights the Python binding derives when tile_size > 0 (patolette.pyx:407-414), left on the device
+static const double *derive_weights(Engine &E, const double *d_f64, const unsigned char *d_u8, int channels, size_t width,
+                                    size_t height, double tile_size) {
+    E.wsal.reserve(width * height);
+    const double t0 = now_ms();
+    const int rc = saliency_weights(E.sal, d_f64, d_u8, channels, width, height, tile_size, E.wsal.p, E.stream);
+    if (ktimer().enabled) ktimer().collect();
+    E.ms_saliency = now_ms() - t0;
+    if (rc == kSalBadShape) throw CodeError(-5, "saliency weights: image shape not supported");
+    if (rc == kSalSingular) throw CodeError(-6, "saliency weights: singular border covariance");
+    return E.wsal.p;
 }
 
 static int validate(size_t width, size_t height, size_t K) {               // patolette.c:61-95
@@ -697,8 +726,8 @@ static int validate(size_t width, size_t height, size_t K) {               // pa
 static int map_elem_for(size_t K) { return K <= 256 ? 1 : 4; }
 
 // host-buffer entry: upload, run, download + widen
-static void run_host(Engine &E, size_t width, size_t height, const double *data, const double *weights, size_t K,
-                     const patolette__QuantizationOptions *opt, double *palette, size_t *palette_map) {
+static void run_host(Engine &E, size_t width, size_t height, const double *data, const double *weights, double tile_size,
+                     size_t K, const patolette__QuantizationOptions *opt, double *palette, size_t *palette_map) {
     const size_t N = width * height;
     double t0 = now_ms();
     E.src.reserve(3 * N);
@@ -709,10 +738,15 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     }
     HIP_CHECK(hipStreamSynchronize(E.stream));
     const double up = now_ms() - t0;
+    const double *d_w = weights ? E.wsrc.p : nullptr;
+    E.ms_saliency = 0.0;
+    if (!weights && tile_size > 0.0) d_w = derive_weights(E, E.src.p, nullptr, 3, width, height, tile_size);
     const int me = map_elem_for(K);
     if (!opt->palette_only) E.dmap.reserve(N * (size_t)me);
     std::vector<double> pal(3 * K);
-    run_device(E, width, height, Pixels{E.src.p, nullptr, 3}, weights ? E.wsrc.p : nullptr, K, opt, pal.data(), E.dmap.p, me);
+    run_device(E, width, height, Pixels{E.src.p, nullptr, 3}, d_w, K, opt, pal.data(), E.dmap.p, me);
+    E.stats.ms_saliency = E.ms_saliency;
+    E.stats.ms_total += E.ms_saliency;
     t0 = now_ms();
     if (!opt->palette_only) {
         const bool touched = !(opt->dither && std::max(width, height) <= 1);   // 1x1 dither visits nothing (riemersma.c:452-456)
@@ -747,7 +781,7 @@ static void palette_to_u8(const double *palette, size_t K, unsigned char *out) {
 // 8-bit adaptor around the path: interleaved u8 in; f64 palette, u8 palette, index map and
 // reconstructed u8 image out.  `pixels`, `d_map_out`, `d_quant_out` are device pointers when `on_device`.
 static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *pixels, int channels, const double *weights,
-                   size_t K, const patolette__QuantizationOptions *opt, double *palette, unsigned char *palette_u8,
+                   double tile_size, size_t K, const patolette__QuantizationOptions *opt, double *palette, unsigned char *palette_u8,
                    void *map_out, int map_elem_out, unsigned char *quant_out, bool on_device) {
     const size_t N = width * height;
     hipStream_t s = E.stream;
@@ -766,17 +800,19 @@ static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *
         HIP_CHECK(hipStreamSynchronize(s));
     }
     const double up = now_ms() - t0;
+    E.ms_saliency = 0.0;
+    if (!weights && tile_size > 0.0) d_w = derive_weights(E, nullptr, d_px, channels, width, height, tile_size);
     const int me = map_elem_for(K);
     const bool want_map = !opt->palette_only && (map_out || quant_out);
-    patolette__QuantizationOptions o2 = *opt;
-    if (!want_map) o2.palette_only = true;
-    void *d_map = nullptr;
+    void *d_map = nullptr;                  // stays null when no map-derived output is wanted: the map kernels are skipped
     if (want_map) {
         if (on_device && map_out && map_elem_out == me) d_map = map_out;
         else { E.dmap.reserve(N * (size_t)me); d_map = E.dmap.p; }
     }
     std::vector<double> pal(3 * K);
-    run_device(E, width, height, Pixels{nullptr, d_px, channels}, d_w, K, &o2, pal.data(), d_map, me);
+    run_device(E, width, height, Pixels{nullptr, d_px, channels}, d_w, K, opt, pal.data(), d_map, me);
+    E.stats.ms_saliency = E.ms_saliency;
+    E.stats.ms_total += E.ms_saliency;
     t0 = now_ms();
     std::vector<unsigned char> p8(3 * K);
     palette_to_u8(pal.data(), K, p8.data());
@@ -834,9 +870,12 @@ static int validate_u8(size_t K, int channels, const void *map_out, int map_elem
 // ============================================================================================
 using namespace pamd;
 
-static const char *kMessages[6] = {                                        // patolette.c:32-38
+static const char *kMessages[8] = {                                        // patolette.c:32-38, then the additive codes
     "Quantization successful.", "Internal quantization error.", "Image dimensions should be greater than 0.",
-    "Palette size should be greater than 0.", "Image dimensions are too big.", nullptr};
+    "Palette size should be greater than 0.", "Image dimensions are too big.",
+    "Saliency weights: image shape not supported (needs more than 3 pixels per side, at least 100 pixels, and a "
+    "border band that fits).",
+    "Saliency weights: a border band has a singular colour covariance.", nullptr};
 
 #define PAMD_GUARD_BEGIN try { Engine &E = engine(); E.init(); (void)E;
 #define PAMD_GUARD_END(ret_fail)                                             \
@@ -855,7 +894,7 @@ void patolette(size_t width, size_t height, const double *data, const double *we
     try {
         Engine &E = engine();
         E.init();
-        run_host(E, width, height, data, weights, palette_size, options, palette, palette_map);
+        run_host(E, width, height, data, weights, 0.0, palette_size, options, palette, palette_map);
         *exit_code = 0;
     } catch (const std::exception &ex) {
         engine().last_error = ex.what();
@@ -864,7 +903,59 @@ void patolette(size_t width, size_t height, const double *data, const double *we
     }
 }
 
-const char *get_patolette_exit_code_info_message(int exit_code) { return kMessages[-1 * exit_code]; }
+void patolette_amd_quantize(size_t width, size_t height, const double *data, const double *weights, double tile_size,
+                            size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                            size_t *palette_map, int *exit_code) {
+    *exit_code = validate(width, height, palette_size);
+    if (*exit_code != 0) return;
+    try {
+        Engine &E = engine();
+        E.init();
+        run_host(E, width, height, data, weights, tile_size, palette_size, options, palette, palette_map);
+        *exit_code = 0;
+    } catch (const CodeError &ex) {
+        engine().last_error = ex.what();
+        *exit_code = ex.code;
+    } catch (const std::exception &ex) {
+        engine().last_error = ex.what();
+        fprintf(stderr, "patolette: %s\n", ex.what());
+        *exit_code = -1;
+    }
+}
+
+int patolette_amd_saliency_weights(size_t width, size_t height, const double *data, double tile_size, double *weights_out) {
+    const size_t N = width * height;
+    if (N == 0) return kSalBadShape;
+    try {
+        Engine &E = engine();
+        E.init();
+        E.src.reserve(3 * N);
+        HIP_CHECK(hipMemcpyAsync(E.src.p, data, 3 * N * sizeof(double), hipMemcpyHostToDevice, E.stream));
+        const double *d_w = derive_weights(E, E.src.p, nullptr, 3, width, height, tile_size);
+        HIP_CHECK(hipMemcpy(weights_out, d_w, N * sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const CodeError &ex) {
+        engine().last_error = ex.what();
+        return ex.code == -5 ? kSalBadShape : kSalSingular;
+    } catch (const std::exception &ex) {
+        engine().last_error = ex.what();
+        fprintf(stderr, "patolette: %s\n", ex.what());
+        return -1;
+    }
+}
+
+int patolette_amd_mbd(size_t rows, size_t cols, const float *img, int iters, float *out) {
+    PAMD_GUARD_BEGIN
+    const int rc = mbd_device(E.sal, img, rows, cols, iters, out, E.stream);
+    if (ktimer().enabled) ktimer().collect();
+    return rc;
+    PAMD_GUARD_END(-1)
+}
+
+const char *get_patolette_exit_code_info_message(int exit_code) {
+    if (exit_code > 0 || exit_code < -6) return nullptr;
+    return kMessages[-1 * exit_code];
+}
 
 patolette__QuantizationOptions *patolette_create_default_options(void) {   // patolette.c:107-119
     patolette__QuantizationOptions *o = (patolette__QuantizationOptions *)malloc(sizeof *o);
@@ -918,7 +1009,7 @@ void patolette_amd_device(size_t width, size_t height, const double *d_data, con
 }
 
 static void u8_entry(bool on_device, size_t width, size_t height, const unsigned char *pixels, int channels,
-                     const double *weights, size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                     const double *weights, double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
                      unsigned char *palette_u8, void *palette_map, int map_elem_bytes, unsigned char *quantized, int *exit_code) {
     *exit_code = validate(width, height, palette_size);
     if (*exit_code != 0) return;
@@ -930,9 +1021,12 @@ static void u8_entry(bool on_device, size_t width, size_t height, const unsigned
     try {
         Engine &E = engine();
         E.init();
-        run_u8(E, width, height, pixels, channels, weights, palette_size, options, palette, palette_u8, palette_map, map_elem_bytes,
-               quantized, on_device);
+        run_u8(E, width, height, pixels, channels, weights, tile_size, palette_size, options, palette, palette_u8, palette_map,
+               map_elem_bytes, quantized, on_device);
         *exit_code = 0;
+    } catch (const CodeError &ex) {
+        engine().last_error = ex.what();
+        *exit_code = ex.code;
     } catch (const std::exception &ex) {
         engine().last_error = ex.what();
         fprintf(stderr, "patolette: %s\n", ex.what());
@@ -941,17 +1035,17 @@ static void u8_entry(bool on_device, size_t width, size_t height, const unsigned
 }
 
 void patolette_amd_u8(size_t width, size_t height, const unsigned char *pixels, int channels, const double *weights,
-                      size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                      double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
                       unsigned char *palette_u8, void *palette_map, int map_elem_bytes, unsigned char *quantized, int *exit_code) {
-    u8_entry(false, width, height, pixels, channels, weights, palette_size, options, palette, palette_u8, palette_map,
+    u8_entry(false, width, height, pixels, channels, weights, tile_size, palette_size, options, palette, palette_u8, palette_map,
              map_elem_bytes, quantized, exit_code);
 }
 
 void patolette_amd_u8_device(size_t width, size_t height, const unsigned char *d_pixels, int channels, const double *d_weights,
-                             size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                             double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
                              unsigned char *palette_u8, void *d_palette_map, int map_elem_bytes, unsigned char *d_quantized,
                              int *exit_code) {
-    u8_entry(true, width, height, d_pixels, channels, d_weights, palette_size, options, palette, palette_u8, d_palette_map,
+    u8_entry(true, width, height, d_pixels, channels, d_weights, tile_size, palette_size, options, palette, palette_u8, d_palette_map,
              map_elem_bytes, d_quantized, exit_code);
 }
 
@@ -998,7 +1092,7 @@ void patolette_amd_batch(size_t count, size_t width, size_t height, const double
         }
         for (size_t i; (i = next.fetch_add(1)) < count;) {
             try {
-                run_host(*E, width, height, data[i], weights ? weights[i] : nullptr, palette_size, options, palettes[i],
+                run_host(*E, width, height, data[i], weights ? weights[i] : nullptr, 0.0, palette_size, options, palettes[i],
                          palette_maps ? palette_maps[i] : nullptr);
                 exit_codes[i] = 0;
             } catch (const std::exception &ex) {

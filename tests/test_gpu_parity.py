@@ -222,8 +222,6 @@ def test_python_quantize_tuple_contract(gpu, ob):
     assert ok and pmap2 is None
     ok, pal3, pmap3, msg = p.quantize(w, h, colors, 0, tile_size=0)
     assert (ok, pal3, pmap3, msg) == (False, None, None, "Palette size should be greater than 0.")
-    with pytest.raises(NotImplementedError):
-        p.quantize(w, h, colors, K)            # default tile_size=512 needs the saliency weights (next row)
     res = p.quantize_batch(w, h, [colors, colors[::-1].copy()], K, dither=False, kmeans_niter=0)
     assert np.array_equal(res[0][2], pmap) and res[1][0]
 
@@ -250,7 +248,7 @@ def test_u8_adaptor_equals_by_hand_steps(gpu, ob, channels, K, dither, cs):
     rng = np.random.default_rng(5 + K)
     img = rng.integers(0, 256, size=(h, w, channels), dtype=np.uint8)
     wts = ob.weights(n, 9) if dither else None
-    ok, pal8, pmap, quant, pal, msg = p.quantize_u8(img, K, dither=dither, color_space=cs, kmeans_niter=3,
+    ok, pal8, pmap, quant, pal, msg = p.quantize_u8(img, K, dither=dither, color_space=cs, tile_size=0, kmeans_niter=3,
                                                     kmeans_max_samples=4096, weights=wts)
     assert ok and msg == "Quantization successful."
     colors = img[:, :, :3].reshape(-1, 3).astype(np.float64)
@@ -269,6 +267,15 @@ def test_u8_adaptor_equals_by_hand_steps(gpu, ob, channels, K, dither, cs):
     assert ec == 0 and np.array_equal(pmap_f, pmap_o)
     assert np.allclose(pal_f, pal_o, rtol=0, atol=1e-9)
     # palette only / no reconstructed image
-    ok3, pal8b, pm3, q3, _, _ = p.quantize_u8(img, K, palette_only=True, color_space=cs, kmeans_niter=3, kmeans_max_samples=4096,
-                                              dither=dither, weights=wts)
-    assert ok3 and pm3 is None and q3 is None and np.array_equal(pal8b, pal8)
+    ok3, pal8b, pm3, q3, _, _ = p.quantize_u8(img, K, palette_only=True, color_space=cs, tile_size=0, kmeans_niter=3,
+                                              kmeans_max_samples=4096, dither=dither, weights=wts)
+    # palette_only leaves the palette in the quantisation space, as the reference does (patolette.c:267 skips the
+    # back-conversion together with the map): the adaptor reports exactly what the by-hand steps would
+    ok4, pal_po, _, _ = p.quantize(w, h, colors, K, palette_only=True, color_space=cs, tile_size=0, kmeans_niter=3,
+                                   kmeans_max_samples=4096, dither=dither, weights=wts)
+    assert ok3 and ok4 and pm3 is None and q3 is None
+    assert np.array_equal(pal8b, np.clip(pal_po * 255, 0, 255).astype(np.uint8))
+    # palette wanted in sRGB but no map / image: want_quantized=False and the map dropped by the caller still converts
+    ok5, pal8c, pm5, q5, _, _ = p.quantize_u8(img, K, color_space=cs, tile_size=0, kmeans_niter=3, kmeans_max_samples=4096,
+                                              dither=dither, weights=wts, want_quantized=False)
+    assert ok5 and q5 is None and np.array_equal(pal8c, pal8) and np.array_equal(pm5, pmap)
