@@ -7,7 +7,7 @@ image whose f64 planar pixels are ALREADY RESIDENT IN HBM when the timed region 
 `value`).  Default workload = the configuration the metric is quoted on ("256-color ICtCp +
 KMeans"): BASELINE.json configs[2], 4096x4096, K=256, ICtCp, KMeans 32 it / 512^2 samples, dither off.
 
-  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3full|c4|c4map] [--no-cpu-baseline]
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3full|c3sal|c4|c4map] [--no-cpu-baseline]
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); images are independent, so the
 ranks shard the batch with NO data-path collective ("scaling": "weak": every rank quantises its own
@@ -34,6 +34,8 @@ CONFIGS = {
     "c3full": (4096, 4096, 256, 2, 32, 4096 * 4096, False, False, "configs[2] stress: as c3 but kmeans_max_samples = N (all pixels clustered)"),
     "c4": (8192, 8192, 256, 1, 0, 512 ** 2, True, True, "BASELINE configs[3]: 8192x8192, 256 colors, CIELuv + weights + Riemersma dither"),
     "c4map": (8192, 8192, 256, 1, 0, 512 ** 2, False, True, "configs[3] without dither: 8192x8192, 256 colors, CIELuv + weights, NN map"),
+    # the Python binding's default weighting: 8-bit image in HBM, saliency weights (tile_size 512) derived on the device
+    "c3sal": (4096, 4096, 256, 2, 32, 512 ** 2, False, "saliency", "configs[2] + saliency weights (tile_size 512) from an 8-bit image resident in HBM"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
@@ -62,8 +64,12 @@ class Runner:
         pal = np.zeros((K, 3), dtype=np.float64, order="F")
         code = C.c_int(0)
         src = (i * self.S + j) % len(self.d_imgs)
-        self.L.patolette_amd_device(width, height, self.d_imgs[src], self.d_wts[src] if weighted else None, K,
-                                    C.byref(self.opts), pal.ctypes.data_as(self.native.dp), self.map_ptr(i, j), 1, C.byref(code))
+        if weighted == "saliency":
+            self.L.patolette_amd_u8_device(width, height, self.d_imgs[src], 3, None, 512.0, K, C.byref(self.opts),
+                                           pal.ctypes.data_as(self.native.dp), None, self.map_ptr(i, j), 1, None, C.byref(code))
+        else:
+                self.L.patolette_amd_device(width, height, self.d_imgs[src], self.d_wts[src] if weighted else None, K,
+                                        C.byref(self.opts), pal.ctypes.data_as(self.native.dp), self.map_ptr(i, j), 1, C.byref(code))
         if code.value != 0:
             raise RuntimeError("bench.py: quantisation failed: %s" % self.native.last_error())
         if self.pals is not None:
@@ -147,6 +153,12 @@ def main():
     pool = max(S, S2, min(3, args.steps))
     d_imgs, d_wts = [], []
     for i in range(pool):
+        if weighted == "saliency":
+            p = L.patolette_amd_malloc(3 * n)
+            img8 = np.random.default_rng(100 * rank + i).integers(0, 256, size=3 * n, dtype=np.uint8)
+            assert p and L.patolette_amd_memcpy_h2d(p, img8.ctypes.data_as(C.c_void_p), 3 * n) == 0
+            d_imgs.append(p)
+            continue
         p = L.patolette_amd_malloc(3 * n * 8)
         if not p:
             raise SystemExit("bench.py: hipMalloc failed")
@@ -266,6 +278,9 @@ def main():
         flat = ob.image(sn, 0)
         wt = ob.weights(sn, 0) if weighted else None
         t1 = time.perf_counter()
+        if weighted == "saliency":               # the reference derives these on the CPU inside quantize(): part of the job
+            from oracle import saliency
+            wt = saliency.get_weights(np.ascontiguousarray(flat.reshape(3, sn).T).reshape(sh, sw, 3), 512.0)
         ec, _, _ = ob.patolette(sw, sh, flat, wt, K, dither=dither, color_space=cs, kmeans_niter=niter,
                                 kmeans_max_samples=min(max_samples, sn) if max_samples > 512 ** 2 else max_samples)
         dt = time.perf_counter() - t1

@@ -20,7 +20,6 @@ struct SalDev {                      // device-resident scalars of one saliency 
 };
 
 struct SalWork {
-    DevBuf<float4> dummy;
     DevBuf<float4> st;               // minimum-barrier state {img, D, U, L} per pixel, row-major
     DevBuf<float> tmp;
     DevBuf<double> lab, s;           // CIELAB planes, running saliency map

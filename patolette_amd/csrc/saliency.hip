@@ -278,9 +278,10 @@ __global__ __launch_bounds__(256) void k_sal_pass_e(size_t n, double npx, double
 // minimum-barrier raster scan (patolette.pyx:54-152)
 // ---------------------------------------------------------------------------------------------------
 // State per pixel as one 16-byte record {img, D, U, L} (row-major): a visit reads and writes one record.
+constexpr size_t kMbdPad = 256;      // records of padding on both sides of the state (lanes read past row ends)
+
 struct MbdArgs {
-    float4 *st;
-    float4 *dummy;                   // one record per lane of every strip: target of the stores of inactive lanes
+    float4 *st;                      // first record of the image; kMbdPad readable records before and after it
     int rows, cols;
     unsigned int *progress;
 };
@@ -291,7 +292,6 @@ __device__ __forceinline__ float wave_shr1(float from_above, float v) {
                                                                  0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
-constexpr int kPF = 16;              // records in flight per lane (register ring, indexed by step)
 constexpr int kChunk = 32;           // columns of the row above a strip fetched / published at a time
 
 // DIR = +1: forward scan (rows 1..rows-2, cols 1..cols-2, neighbours above / left);
@@ -301,6 +301,10 @@ constexpr int kChunk = 32;           // columns of the row above a strip fetched
 // One wavefront per strip of 64 scan rows; lane r visits column t - r at step t, so the visit of the row above
 // is one step old in the neighbouring lane (wave shift) and the previous column is the lane's own last result.
 // Strip s+1 reads the last row of strip s from HBM, kChunk columns at a time, behind a progress flag.
+// v_max_f32 / v_min_f32 without the canonicalising self-max the compiler adds for fmaxf / fminf (no NaNs here)
+__device__ __forceinline__ float hw_max(float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float hw_min(float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+
 template <int DIR>
 __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
     const int lane = threadIdx.x, strip = blockIdx.x;
@@ -311,42 +315,35 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
     const int sx = strip * 64 + lane;
     const bool rowok = sx < R;
     const int rl = min(63, R - 1 - strip * 64);             // last valid lane of this strip
-    const long rowoff = base + (long)sx * rs;               // record index of (sx, 0)
-    const long aboveoff = base + (long)(strip * 64 - 1) * rs;   // (first row of the strip - 1, 0)
+    // record (sx, -lane): the record of step t is p[DIR * t].  Lanes past the last row shadow the last row (their
+    // results are discarded); columns outside [0, Cn) fall into neighbouring rows or the padding of the buffer and
+    // are only ever read.
+    float4 *p = a.st + (base + (long)min(sx, R - 1) * rs - (long)DIR * lane);
+    const float4 *above = a.st + (base + (long)(strip * 64 - 1) * rs);   // (first row of the strip - 1, 0)
     const int T = Cn + rl;                                   // steps until the last valid lane is done
 
-    float4 ring[kPF];
+    float4 ring[kChunk];
     float outU = 0.f, outL = 0.f;                            // this lane's latest result = "previous column" of the next visit
-    if (rowok) { const float4 f = a.st[rowoff - DIR]; outU = f.x; outL = f.x; }   // frame column: U = L = img, never modified
+    { const float4 f = p[DIR * (lane - 1)]; outU = f.x; outL = f.x; }   // frame column: U = L = img, never modified
     float bu = 0.f, bl = 0.f;                                // row above the strip: lane j holds column chunk0 + j
+    const int last = rowok ? lane + Cn - 1 : -1;             // this lane visits at steps lane .. last
 
-    // loads and stores are unconditional (clamped / redirected to a per-lane dummy record) so that the loop body has no
-    // divergent branches and the prefetched records stay in flight across steps
-    const long rowclamped = base + (long)min(sx, R - 1) * rs;
-    auto fetch = [&](int t, float4 &dst) {
-        const int c = min(max(t - lane, 0), Cn - 1);
-        dst = a.st[rowclamped + (long)DIR * c];
-    };
-    auto visit = [&](int t, const float4 cur) {
+    auto visit = [&](int t, float4 *q, const float4 cur) {
         const int idx = t & (kChunk - 1);
         const float fu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bu), idx));
         const float fl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bl), idx));
         const float u1 = wave_shr1(fu, outU), l1 = wave_shr1(fl, outL);
         const float ix = cur.x, d = cur.y;
-        const float hu1 = fmaxf(u1, ix), hl1 = fminf(l1, ix);
-        const float hu2 = fmaxf(outU, ix), hl2 = fminf(outL, ix);
+        const float hu1 = hw_max(u1, ix), hl1 = hw_min(l1, ix);
+        const float hu2 = hw_max(outU, ix), hl2 = hw_min(outL, ix);
         const float b1 = hu1 - hl1, b2 = hu2 - hl2;
         const bool keep = (d <= b1) && (d <= b2);
         const bool t1 = (b1 < d) && (b1 <= b2);
-        const float nd = keep ? d : (t1 ? b1 : b2);
-        const float nu = keep ? cur.z : (t1 ? hu1 : hu2);
-        const float nl = keep ? cur.w : (t1 ? hl1 : hl2);
-        const int c = t - lane;
-        const bool ok = rowok && c >= 0 && c < Cn;
-        outU = ok ? nu : outU;
-        outL = ok ? nl : outL;
-        float4 *dst = ok ? a.st + (rowoff + (long)DIR * c) : a.dummy + (strip * 64 + lane);
-        *dst = make_float4(ix, nd, nu, nl);
+        if (t >= lane && t <= last) {
+            outU = keep ? cur.z : (t1 ? hu1 : hu2);
+            outL = keep ? cur.w : (t1 ? hl1 : hl2);
+            if (!keep) *q = make_float4(ix, t1 ? b1 : b2, outU, outL);
+        }
     };
     auto chunk_begin = [&](int t0) {
         // steps t0 .. t0+kChunk-1 of lane 0 consume scan columns t0 .. t0+kChunk-1 of the row above the strip
@@ -354,12 +351,12 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
         if (strip > 0) {
             const unsigned int need = (unsigned int)min(Cn, t0 + kChunk);
             while (__hip_atomic_load(&a.progress[strip - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         const int col = t0 + lane;
         if (lane < kChunk && col < Cn) {
-            const float4 f = a.st[aboveoff + (long)DIR * col];
+            const float4 f = above[DIR * col];
             bu = f.z; bl = f.w;
         }
     };
@@ -371,20 +368,24 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
         if (lane == 0) __hip_atomic_store(&a.progress[strip], (unsigned int)min(Cn, done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
+    // Blocks of kChunk steps.  The records of the next block are requested during the first half of the current one,
+    // so they have landed when the flag handshake at the block boundary drains the memory counter.
 #pragma unroll
-    for (int j = 0; j < kPF; j++) fetch(j, ring[j]);
-    for (int t0 = 0; t0 < T; t0 += kPF) {
+    for (int j = 0; j < kChunk; j++) ring[j] = p[DIR * j];
+    for (int t0 = 0; t0 < T; t0 += kChunk) {
+        chunk_begin(t0);
+        float4 next[kChunk];
+        float4 *q = p + DIR * t0;
 #pragma unroll
-        for (int j = 0; j < kPF; j++) {
-            const int t = t0 + j;
-            if ((t & (kChunk - 1)) == 0) chunk_begin(t);
-            const float4 cur = ring[j];
-            fetch(t + kPF, ring[j]);
-            visit(t, cur);
-            if ((t & (kChunk - 1)) == kChunk - 1) chunk_end(t);
+        for (int j = 0; j < kChunk; j++) {
+            if (j < kChunk / 2) { next[2 * j] = q[DIR * (kChunk + 2 * j)]; next[2 * j + 1] = q[DIR * (kChunk + 2 * j + 1)]; }
+            visit(t0 + j, q + DIR * j, ring[j]);
         }
+        chunk_end(t0 + kChunk - 1);
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) ring[j] = next[j];
     }
-    chunk_end(T + kPF);
+    chunk_end(T + kChunk);
 }
 
 int stream_grid(size_t n) {
@@ -416,8 +417,7 @@ __global__ __launch_bounds__(256) void k_mbd_extract(const float4 *__restrict__ 
 static void run_mbd_scans(SalWork &w, int rows, int cols, int iters, hipStream_t s) {
     const int strips_f = (int)ceil_div((size_t)rows - 2, 64), strips_i = (int)ceil_div((size_t)rows - 3, 64);
     w.progress.reserve((size_t)strips_f);
-    w.dummy.reserve((size_t)strips_f * 64);
-    MbdArgs ma{w.st.p, w.dummy.p, rows, cols, w.progress.p};
+    MbdArgs ma{w.st.p + kMbdPad, rows, cols, w.progress.p};
     for (int pass = 0; pass < iters; pass++) {
         HIP_CHECK(hipMemsetAsync(w.progress.p, 0, sizeof(unsigned int) * (size_t)strips_f, s));
         KTIME("k_mbd_scan", s, 32.0 * rows * cols);
@@ -430,11 +430,11 @@ static void run_mbd_scans(SalWork &w, int rows, int cols, int iters, hipStream_t
 int mbd_device(SalWork &w, const float *h_img, size_t rows, size_t cols, int iters, float *h_out, hipStream_t s) {
     if (rows <= 3 || cols <= 3) return kSalBadShape;
     const size_t n = rows * cols;
-    w.st.reserve(n); w.tmp.reserve(n);
+    w.st.reserve(n + 2 * kMbdPad); w.tmp.reserve(n);
     HIP_CHECK(hipMemcpyAsync(w.tmp.p, h_img, n * sizeof(float), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_mbd_init, stream_grid(n), 256, 0, s, w.tmp.p, n, (int)rows, (int)cols, w.st.p);
+    hipLaunchKernelGGL(k_mbd_init, stream_grid(n), 256, 0, s, w.tmp.p, n, (int)rows, (int)cols, w.st.p + kMbdPad);
     run_mbd_scans(w, (int)rows, (int)cols, iters, s);
-    hipLaunchKernelGGL(k_mbd_extract, stream_grid(n), 256, 0, s, w.st.p, n, w.tmp.p);
+    hipLaunchKernelGGL(k_mbd_extract, stream_grid(n), 256, 0, s, w.st.p + kMbdPad, n, w.tmp.p);
     HIP_CHECK(hipMemcpyAsync(h_out, w.tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     return kSalOk;
@@ -448,7 +448,7 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     const int bt = (int)std::floor(0.1 * std::sqrt((double)(height * width)));
     if (rows <= 3 || cols <= 3 || bt < 1 || rows < bt + 1 || cols < bt + 1) return kSalBadShape;
 
-    w.st.reserve(n);
+    w.st.reserve(n + 2 * kMbdPad);
     w.lab.reserve(3 * n); w.s.reserve(n);
     w.dev.reserve(1);
     w.host.reserve(1);
@@ -457,8 +457,8 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     hipLaunchKernelGGL(k_sal_init, 1, 256, 0, s, w.dev.p);
     {
         KTIME("k_sal_prepare", s, (d_u8 ? (double)channels : 24.0) * n + 40.0 * n);
-        if (d_u8) hipLaunchKernelGGL((k_sal_prepare<SrcU8>), g, 256, 0, s, SrcU8{d_u8, channels}, n, rows, cols, w.st.p, w.lab.p);
-        else hipLaunchKernelGGL((k_sal_prepare<SrcF64>), g, 256, 0, s, SrcF64{d_f64, n}, n, rows, cols, w.st.p, w.lab.p);
+        if (d_u8) hipLaunchKernelGGL((k_sal_prepare<SrcU8>), g, 256, 0, s, SrcU8{d_u8, channels}, n, rows, cols, w.st.p + kMbdPad, w.lab.p);
+        else hipLaunchKernelGGL((k_sal_prepare<SrcF64>), g, 256, 0, s, SrcF64{d_f64, n}, n, rows, cols, w.st.p + kMbdPad, w.lab.p);
     }
     // border bands in the reference's order and naming (patolette.pyx:215-219): "left" = first bt rows, "right" = bt rows
     // ending one short of the last, "top" = first bt columns, "bottom" = bt columns ending one short of the last
@@ -485,7 +485,7 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     run_mbd_scans(w, rows, cols, 3, s);                      // mbd(img_mean, 3), patolette.pyx:205
     {
         KTIME("k_sal_pass_a", s, 28.0 * n);
-        hipLaunchKernelGGL(k_sal_pass_a, g, 256, 0, s, w.lab.p, w.st.p, n, w.dev.p);
+        hipLaunchKernelGGL(k_sal_pass_a, g, 256, 0, s, w.lab.p, w.st.p + kMbdPad, n, w.dev.p);
     }
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 0, 5, 1);
     {
@@ -495,7 +495,7 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 5, 1, 1);
     {
         KTIME("k_sal_pass_c", s, 20.0 * n);
-        hipLaunchKernelGGL(k_sal_pass_c, g, 256, 0, s, w.st.p, n, w.dev.p, w.s.p);
+        hipLaunchKernelGGL(k_sal_pass_c, g, 256, 0, s, w.st.p + kMbdPad, n, w.dev.p, w.s.p);
     }
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 6, 1, 0);
     const double w2 = (double)rows / 2.0, h2 = (double)cols / 2.0;
