@@ -484,7 +484,7 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
 
     run_mbd_scans(w, rows, cols, 3, s);                      // mbd(img_mean, 3), patolette.pyx:205
     {
-        KTIME("k_sal_pass_a", s, 28.0 * n);
+        KTIME("k_sal_pass_a", s, 40.0 * n);
         hipLaunchKernelGGL(k_sal_pass_a, g, 256, 0, s, w.lab.p, w.st.p + kMbdPad, n, w.dev.p);
     }
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 0, 5, 1);
@@ -494,7 +494,7 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     }
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 5, 1, 1);
     {
-        KTIME("k_sal_pass_c", s, 20.0 * n);
+        KTIME("k_sal_pass_c", s, 32.0 * n);
         hipLaunchKernelGGL(k_sal_pass_c, g, 256, 0, s, w.st.p + kMbdPad, n, w.dev.p, w.s.p);
     }
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 6, 1, 0);
