@@ -69,6 +69,7 @@ SYMBOLS = {
     "patolette_amd_dither": (C.c_int, [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp]),
     "patolette_amd_last_stats": (None, [C.POINTER(Stats)]),
     "patolette_amd_profile_enable": (None, [C.c_int]),
+    "patolette_amd_profile_only": (None, [C.c_char_p]),
     "patolette_amd_profile_count": (C.c_int, []),
     "patolette_amd_profile_get": (C.c_int, [C.c_int, C.c_char_p, dp, zp, dp]),
 }
@@ -103,7 +104,9 @@ def last_stats():
     return s.as_dict()
 
 
-def profile(enable=True):
+def profile(enable=True, only=None):
+    """Per-kernel HIP-event timing on/off (resets the counters); `only` restricts it to one kernel name."""
+    lib().patolette_amd_profile_only(only.encode() if only else None)
     lib().patolette_amd_profile_enable(1 if enable else 0)
 
 

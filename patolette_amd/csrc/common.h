@@ -39,6 +39,7 @@ constexpr double kDelta = 1e-16;     // reference: math/misc.h:5
 struct KernelTimer {
     struct Rec { hipEvent_t a, b; int id; double bytes; };
     bool enabled = false;
+    std::string only;                // when not empty: time just the kernel of this name
     std::vector<std::string> names;
     std::vector<double> total_ms, total_bytes;
     std::vector<size_t> launches;
@@ -56,7 +57,8 @@ KernelTimer &ktimer();
 struct ScopedKernel {
     bool on;
     hipStream_t s;
-    ScopedKernel(const char *name, hipStream_t stream, double bytes) : on(ktimer().enabled), s(stream) {
+    ScopedKernel(const char *name, hipStream_t stream, double bytes)
+        : on(ktimer().enabled && (ktimer().only.empty() || ktimer().only == name)), s(stream) {
         if (on) ktimer().begin(ktimer().id_of(name), s, bytes);
     }
     ~ScopedKernel() { if (on) ktimer().end(s); }

@@ -1199,6 +1199,7 @@ void patolette_amd_profile_enable(int on) {
     t.reset();
     t.enabled = on != 0;
 }
+void patolette_amd_profile_only(const char *kernel_name) { ktimer().only = kernel_name ? kernel_name : ""; }
 int patolette_amd_profile_count(void) { return (int)ktimer().names.size(); }
 int patolette_amd_profile_get(int i, char *name64, double *total_ms, size_t *launches, double *total_bytes) {
     KernelTimer &t = ktimer();
