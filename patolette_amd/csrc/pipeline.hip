@@ -121,7 +121,7 @@ struct Engine {
     DevBuf<ConvertStats> cstats;
     PinBuf<NodeIn> h_stage_in;
     PinBuf<NodeOut> h_stage_out;
-    PinBuf<int> h_ids;
+    PinBuf<int> h_ids, h_ids_get;
     PinBuf<Tile> h_tilesA, h_tilesP;
     PinBuf<int> h_round, h_tile0;
     PinBuf<double> h_dbl;
@@ -221,16 +221,17 @@ static void put_nodes(Engine &E, const std::vector<int> &ids, const std::vector<
     HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
     hipLaunchKernelGGL(k_put_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.stage_in.p, E.ids.p, n);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(E.stream));     // h_stage_in / h_ids are shared with get_nodes
+    // no sync: h_stage_in / h_ids belong to put_nodes alone and every put is followed by a stream sync (get_nodes or an
+    // explicit one) before the next put rewrites them
 }
 
 static void get_nodes(Engine &E, const std::vector<int> &ids, std::vector<NodeOut> &recs) {
     const int n = (int)ids.size();
     recs.resize(n);
     if (!n) return;
-    E.stage_out.reserve(n); E.ids.reserve(n); E.h_stage_out.reserve(n); E.h_ids.reserve(n);
-    std::memcpy(E.h_ids.p, ids.data(), n * sizeof(int));
-    HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
+    E.stage_out.reserve(n); E.ids.reserve(n); E.h_stage_out.reserve(n); E.h_ids_get.reserve(n);
+    std::memcpy(E.h_ids_get.p, ids.data(), n * sizeof(int));
+    HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids_get.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
     hipLaunchKernelGGL(k_get_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.stage_out.p, E.ids.p, n);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(E.h_stage_out.p, E.stage_out.p, n * sizeof(NodeOut), hipMemcpyDeviceToHost, E.stream));
@@ -313,9 +314,11 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     std::vector<double> hh(hs);
     std::vector<unsigned int> hc(kBuckets);
     HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.hist.p, hs * sizeof(double), hipMemcpyDeviceToHost, s));
+    E.h_round.reserve(kBuckets);
+    HIP_CHECK(hipMemcpyAsync(E.h_round.p, E.hcount.p, kBuckets * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     E.sync();
     std::memcpy(hh.data(), E.h_dbl.p, hs * sizeof(double));
-    HIP_CHECK(hipMemcpy(hc.data(), E.hcount.p, kBuckets * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    std::memcpy(hc.data(), E.h_round.p, kBuckets * sizeof(unsigned int));
     auto H = [&](int q, int b) { return hh[(size_t)(q * 2 + 0) * kBuckets + b] + hh[(size_t)(q * 2 + 1) * kBuckets + b]; };
 
     auto cm = std::make_unique<hm::CellMoments>();

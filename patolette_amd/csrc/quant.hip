@@ -318,89 +318,105 @@ __global__ __launch_bounds__(256) void k_scan(const int *__restrict__ round_node
 }
 
 template <bool W, bool COV>
-__global__ __launch_bounds__(256) void k_scatter(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes,
-                                                 const unsigned char *__restrict__ lut, const unsigned long long *__restrict__ tileoff) {
+__global__ __launch_bounds__(256, 5) void k_scatter(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
+                                                    const unsigned char *__restrict__ lut, const unsigned long long *__restrict__ tileoff) {
     constexpr int R = kTileP / 256;
     __shared__ unsigned long long off[R][4][kMaxChildren];
     __shared__ double sm[28 * 4];
-    const Tile t = tiles[blockIdx.x];
-    const NodeDev &nd = nodes[t.node];
-    const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
-    const int nch = nd.nchild;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned long long ltmask = (1ULL << lane) - 1ULL;
-    int child[R]; unsigned rank[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        unsigned i = r * 256 + threadIdx.x;
-        child[r] = i < t.count ? (int)l[qb.bkt[t.start + i]] : 255;
-        rank[r] = 0;
-        for (int k = 0; k < nch; k++) {
-            unsigned long long m = __ballot(child[r] == k);
-            if (child[r] == k) rank[r] = (unsigned)__popcll(m & ltmask);
-            if (lane == 0) off[r][wid][k] = (unsigned long long)__popcll(m);
-        }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nch) {
-        unsigned long long run = tileoff[(size_t)blockIdx.x * kMaxChildren + threadIdx.x];
-        for (int r = 0; r < R; r++)
-            for (int w = 0; w < 4; w++) { unsigned long long c = off[r][w][threadIdx.x]; off[r][w][threadIdx.x] = run; run += c; }
-    }
-    __syncthreads();
-    const double *sx = qb.buf[nd.buf], *sy = sx + qb.N, *sz = sy + qb.N, *sw = sz + qb.N;
-    double *dx = qb.buf[1 - nd.buf], *dy = dx + qb.N, *dz = dy + qb.N, *dw = dz + qb.N;
-    // COV (binary splits only): the children's centred moments are accumulated while their pixels pass through
-    // registers -- pca.c:62-101 / cluster.c:111-152 about the child means k_cut already wrote
-    double a[28];
-    double m0[2], m1[2], m2[2];
-    BinK kq;
+    // A block walks consecutive tiles (the tiles of one node are consecutive).  COV: each thread sums its products per
+    // child and quantity in plain f64 -- a fixed set of pixels in a fixed order for a given tiling, so deterministic --
+    // and the 14 per-thread partials are split onto the exact grids, reduced over the block and added atomically only
+    // when the node changes or the block is done.
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tfirst = (int)blockIdx.x * per, tlast = min(ntiles, tfirst + per);
+    double pl[7], pr[7];
     if constexpr (COV) {
 #pragma unroll
-        for (int i = 0; i < 28; i++) a[i] = 0;
-        const NodeDev &c0 = nodes[nd.child0], &c1 = nodes[nd.child0 + 1];
-        m0[0] = c0.mean[0]; m1[0] = c0.mean[1]; m2[0] = c0.mean[2];
-        m0[1] = c1.mean[0]; m1[1] = c1.mean[1]; m2[1] = c1.mean[2];
-        kq = nd.kquad;
+        for (int i = 0; i < 7; i++) { pl[i] = 0; pr[i] = 0; }
     }
+    for (int ti = tfirst; ti < tlast; ti++) {
+        const Tile t = tiles[ti];
+        const NodeDev &nd = nodes[t.node];
+        const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
+        const int nch = nd.nchild;
+        unsigned cr[R];                                      // child (low byte) | rank within the wave << 8
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        if (child[r] != 255) {
-            const size_t src = t.start + r * 256 + threadIdx.x;
-            const size_t dst = off[r][wid][child[r]] + rank[r];
-            const double x = sx[src], y = sy[src], z = sz[src];
-            double w = 1.0;
-            if constexpr (W) w = sw[src];
-            dx[dst] = x; dy[dst] = y; dz[dst] = z;
-            if constexpr (W) dw[dst] = w;
-            if constexpr (COV) {
-                const bool right = child[r] != 0;
-                const double rf = right ? 1.0 : 0.0, lf = right ? 0.0 : 1.0;
-                const double ex = x - (right ? m0[1] : m0[0]), ey = y - (right ? m1[1] : m1[0]), ez = z - (right ? m2[1] : m2[0]);
-                const double wx = w * ex, wy = w * ey, wz = w * ez;
-                const double q[7] = {wx * ex, wy * ex, wz * ex, wy * ey, wz * ey, wz * ez, ((ex * ex + ey * ey) + ez * ez) * w};
+        for (int r = 0; r < R; r++) {
+            unsigned i = r * 256 + threadIdx.x;
+            const int ch = i < t.count ? (int)l[qb.bkt[t.start + i]] : 255;
+            unsigned rk = 0;
+            for (int k = 0; k < nch; k++) {
+                unsigned long long m = __ballot(ch == k);
+                if (ch == k) rk = (unsigned)__popcll(m & ltmask);
+                if (lane == 0) off[r][wid][k] = (unsigned long long)__popcll(m);
+            }
+            cr[r] = (unsigned)ch | (rk << 8);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nch) {
+            unsigned long long run = tileoff[(size_t)ti * kMaxChildren + threadIdx.x];
+            for (int r = 0; r < R; r++)
+                for (int w = 0; w < 4; w++) { unsigned long long c = off[r][w][threadIdx.x]; off[r][w][threadIdx.x] = run; run += c; }
+        }
+        __syncthreads();
+        const double *sx = qb.buf[nd.buf], *sy = sx + qb.N, *sz = sy + qb.N, *sw = sz + qb.N;
+        double *dx = qb.buf[1 - nd.buf], *dy = dx + qb.N, *dz = dy + qb.N, *dw = dz + qb.N;
+        // COV (binary splits only): the children's centred moments are accumulated while their pixels pass through
+        // registers -- pca.c:62-101 / cluster.c:111-152 about the child means k_cut already wrote
+        double m0[2], m1[2], m2[2];
+        if constexpr (COV) {
+            const NodeDev &c0 = nodes[nd.child0], &c1 = nodes[nd.child0 + 1];
+            m0[0] = c0.mean[0]; m1[0] = c0.mean[1]; m2[0] = c0.mean[2];
+            m0[1] = c1.mean[0]; m1[1] = c1.mean[1]; m2[1] = c1.mean[2];
+        }
 #pragma unroll
-                for (int i = 0; i < 7; i++) {
-                    double v0, v1;
-                    bin_split(q[i], kq, v0, v1);
-                    // v * {0,1} is exact and x + (+-0) = x: one full-rate FMA instead of two 64-bit selects and an add
-                    a[2 * i] = __builtin_fma(v0, lf, a[2 * i]);           a[2 * i + 1] = __builtin_fma(v1, lf, a[2 * i + 1]);
-                    a[14 + 2 * i] = __builtin_fma(v0, rf, a[14 + 2 * i]); a[14 + 2 * i + 1] = __builtin_fma(v1, rf, a[14 + 2 * i + 1]);
+        for (int r = 0; r < R; r++) {
+            const int ch = (int)(cr[r] & 255u);
+            if (ch != 255) {
+                const size_t src = t.start + r * 256 + threadIdx.x;
+                const size_t dst = off[r][wid][ch] + (cr[r] >> 8);
+                const double x = sx[src], y = sy[src], z = sz[src];
+                double w = 1.0;
+                if constexpr (W) w = sw[src];
+                dx[dst] = x; dy[dst] = y; dz[dst] = z;
+                if constexpr (W) dw[dst] = w;
+                if constexpr (COV) {
+                    const bool right = ch != 0;
+                    const double rf = right ? 1.0 : 0.0, lf = right ? 0.0 : 1.0;      // q * {0,1} exact, x + (+-0) = x
+                    const double ex = x - (right ? m0[1] : m0[0]), ey = y - (right ? m1[1] : m1[0]), ez = z - (right ? m2[1] : m2[0]);
+                    const double wx = w * ex, wy = w * ey, wz = w * ez;
+                    const double q[7] = {wx * ex, wy * ex, wz * ex, wy * ey, wz * ey, wz * ez, ((ex * ex + ey * ey) + ez * ez) * w};
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { pl[i] = __builtin_fma(q[i], lf, pl[i]); pr[i] = __builtin_fma(q[i], rf, pr[i]); }
                 }
             }
         }
-    }
-    if constexpr (COV) {
-        block_sum<28>(a, sm);
-        if (threadIdx.x == 0) {
-            for (int side = 0; side < 2; side++) {
-                NodeDev &ch = nodes[nd.child0 + side];
+        if constexpr (COV) {
+            const bool flush = (ti + 1 == tlast) || tiles[ti + 1].node != t.node;       // block-uniform
+            if (flush) {
+                const BinK kq = nd.kquad;
+                double a[28];
+#pragma unroll
                 for (int i = 0; i < 7; i++) {
-                    if (a[14 * side + 2 * i] != 0.0) unsafeAtomicAdd(&ch.acc[blockIdx.x & (kSlots - 1)][i][0], a[14 * side + 2 * i]);
-                    if (a[14 * side + 2 * i + 1] != 0.0) unsafeAtomicAdd(&ch.acc[blockIdx.x & (kSlots - 1)][i][1], a[14 * side + 2 * i + 1]);
+                    bin_split(pl[i], kq, a[2 * i], a[2 * i + 1]);
+                    bin_split(pr[i], kq, a[14 + 2 * i], a[14 + 2 * i + 1]);
+                    pl[i] = 0; pr[i] = 0;
+                }
+                block_sum<28>(a, sm);
+                if (threadIdx.x == 0) {
+                    for (int side = 0; side < 2; side++) {
+                        NodeDev &ch = nodes[nd.child0 + side];
+                        for (int i = 0; i < 7; i++) {
+                            if (a[14 * side + 2 * i] != 0.0) unsafeAtomicAdd(&ch.acc[blockIdx.x & (kSlots - 1)][i][0], a[14 * side + 2 * i]);
+                            if (a[14 * side + 2 * i + 1] != 0.0) unsafeAtomicAdd(&ch.acc[blockIdx.x & (kSlots - 1)][i][1], a[14 * side + 2 * i + 1]);
+                        }
+                    }
                 }
             }
         }
+        __syncthreads();                                     // `off` is rewritten by the next tile
     }
 }
 
@@ -530,11 +546,12 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
     {
         KTIME(fuse_cov ? "k_scatter_cov" : "k_scatter", s, (qb.weighted ? 66.0 : 50.0) * px);
         if (fuse_cov) {
-            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true>), nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
-            else hipLaunchKernelGGL((k_scatter<false, true>), nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+            const int g = std::min(nptiles, 256 * 5);            // 5 resident blocks per CU, each loops over its run of tiles
+            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
+            else hipLaunchKernelGGL((k_scatter<false, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
         } else {
-            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, false>), nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
-            else hipLaunchKernelGGL((k_scatter<false, false>), nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tileoff);
+            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
+            else hipLaunchKernelGGL((k_scatter<false, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
         }
     }
     HIP_CHECK(hipGetLastError());
