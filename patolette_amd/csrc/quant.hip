@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__r
 // bucket moments: sort.c:61-87 (bucket id) + local.c:118-134 (LQ) / cells.c:82-112 (GQ)
 // --------------------------------------------------------------------------------------------
 template <bool W, bool GQ>
-__global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes,
+__global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
                                               double *hist, unsigned long long *hsize, unsigned int *hcount) {
     constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
     constexpr int NQS = GQ ? kNQ_GQ : kNQ_LQ;            // slot stride in quantities
@@ -111,65 +111,74 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
     for (int i = threadIdx.x; i < 2 * kBuckets; i += blockDim.x) cnt[i] = 0u;
     __syncthreads();
 
-    const Tile t = tiles[blockIdx.x];
-    NodeDev &nd = nodes[t.node];
-    const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
-    double mn, mx;
-    node_minmax(nd, mn, mx);
-    const bool degenerate = (mx - mn < kDelta);
-    const double sc = 1 / (mx - mn);
-    const BinK klin = nd.klin, kquad = nd.kquad;
-    const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
-    if (threadIdx.x == 0) nd.degenerate = degenerate ? 1 : 0;
+    // a block walks consecutive tiles (the tiles of one node are consecutive) and flushes its LDS histogram to HBM
+    // only when the node changes: far fewer global f64 atomics than one flush per tile
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tfirst = (int)blockIdx.x * per, tlast = min(ntiles, tfirst + per);
+    for (int ti = tfirst; ti < tlast; ti++) {
+        const Tile t = tiles[ti];
+        NodeDev &nd = nodes[t.node];
+        const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
+        double mn, mx;
+        node_minmax(nd, mn, mx);
+        const bool degenerate = (mx - mn < kDelta);
+        const double sc = 1 / (mx - mn);
+        const BinK klin = nd.klin, kquad = nd.kquad;
+        const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
+        if (threadIdx.x == 0) nd.degenerate = degenerate ? 1 : 0;
 
-    for (unsigned i = threadIdx.x; i < t.count; i += blockDim.x) {
-        const size_t p = t.start + i;
-        const double x = px[p], y = py[p], z = pz[p];
-        double w = 1.0;
-        if constexpr (W) w = pw[p];
-        unsigned b;
-        if (degenerate) {
-            b = (unsigned)((p - nd.begin) % kBuckets);
-        } else {
-            double ratio = (project(x, y, z, a0, a1, a2) - mn) * sc;
-            unsigned long long bq = (unsigned long long)((double)kBuckets * ratio);
-            b = bq < (unsigned long long)(kBuckets - 1) ? (unsigned)bq : (unsigned)(kBuckets - 1);
-        }
-        qb.bkt[p] = (unsigned short)b;
-        atomicAdd(&cnt[b], 1u);
-        double v0, v1;
+        for (unsigned i = threadIdx.x; i < t.count; i += blockDim.x) {
+            const size_t p = t.start + i;
+            const double x = px[p], y = py[p], z = pz[p];
+            double w = 1.0;
+            if constexpr (W) w = pw[p];
+            unsigned b;
+            if (degenerate) {
+                b = (unsigned)((p - nd.begin) % kBuckets);
+            } else {
+                double ratio = (project(x, y, z, a0, a1, a2) - mn) * sc;
+                unsigned long long bq = (unsigned long long)((double)kBuckets * ratio);
+                b = bq < (unsigned long long)(kBuckets - 1) ? (unsigned)bq : (unsigned)(kBuckets - 1);
+            }
+            qb.bkt[p] = (unsigned short)b;
+            atomicAdd(&cnt[b], 1u);
+            double v0, v1;
 #define HADD(q, val, K)                                         \
     do {                                                        \
         bin_split((val), (K), v0, v1);                          \
         unsafeAtomicAdd(&h[((q) * 2 + 0) * kBuckets + b], v0);  \
         unsafeAtomicAdd(&h[((q) * 2 + 1) * kBuckets + b], v1);  \
     } while (0)
-        if constexpr (!GQ) {
-            HADD(0, x * w, klin); HADD(1, y * w, klin); HADD(2, z * w, klin);
-            if constexpr (W) {
-                HADD(3, w, klin);
-                atomicAdd(&siz[b], (unsigned)(unsigned long long)w);      // size_t += double truncates (local.c:133)
+            if constexpr (!GQ) {
+                HADD(0, x * w, klin); HADD(1, y * w, klin); HADD(2, z * w, klin);
+                if constexpr (W) {
+                    HADD(3, w, klin);
+                    atomicAdd(&siz[b], (unsigned)(unsigned long long)w);      // size_t += double truncates (local.c:133)
+                }
+            } else {
+                HADD(0, x, klin); HADD(1, y, klin); HADD(2, z, klin);
+                HADD(3, (x * x + y * y) + z * z, kquad);
+                HADD(4, x * x, kquad); HADD(5, x * y, kquad); HADD(6, y * y, kquad);
+                HADD(7, x * z, kquad); HADD(8, y * z, kquad); HADD(9, z * z, kquad);
+                if constexpr (W) { HADD(10, x * w, klin); HADD(11, y * w, klin); HADD(12, z * w, klin); HADD(13, w, klin); }
             }
-        } else {
-            HADD(0, x, klin); HADD(1, y, klin); HADD(2, z, klin);
-            HADD(3, (x * x + y * y) + z * z, kquad);
-            HADD(4, x * x, kquad); HADD(5, x * y, kquad); HADD(6, y * y, kquad);
-            HADD(7, x * z, kquad); HADD(8, y * z, kquad); HADD(9, z * z, kquad);
-            if constexpr (W) { HADD(10, x * w, klin); HADD(11, y * w, klin); HADD(12, z * w, klin); HADD(13, w, klin); }
-        }
 #undef HADD
-    }
-    __syncthreads();
-    const size_t slot = (size_t)nd.slot;
-    double *gh = hist + slot * (size_t)(NQS * 2 * kBuckets);
-    for (int i = threadIdx.x; i < NQ * 2 * kBuckets; i += blockDim.x) {
-        double v = h[i];
-        if (v != 0.0) unsafeAtomicAdd(&gh[i], v);
-    }
-    for (int b = threadIdx.x; b < kBuckets; b += blockDim.x) {
-        unsigned c = cnt[b];
-        if (c) atomicAdd(&hcount[slot * kBuckets + b], c);
-        if constexpr (W && !GQ) { unsigned s = siz[b]; if (s) atomicAdd(&hsize[slot * kBuckets + b], (unsigned long long)s); }
+        }
+        const bool flush = (ti + 1 == tlast) || tiles[ti + 1].node != t.node;           // block-uniform
+        if (!flush) continue;
+        __syncthreads();
+        const size_t slot = (size_t)nd.slot;
+        double *gh = hist + slot * (size_t)(NQS * 2 * kBuckets);
+        for (int i = threadIdx.x; i < NQ * 2 * kBuckets; i += blockDim.x) {
+            double v = h[i];
+            if (v != 0.0) { unsafeAtomicAdd(&gh[i], v); h[i] = 0.0; }
+        }
+        for (int b = threadIdx.x; b < kBuckets; b += blockDim.x) {
+            unsigned c = cnt[b];
+            if (c) { atomicAdd(&hcount[slot * kBuckets + b], c); cnt[b] = 0u; }
+            if constexpr (W && !GQ) { unsigned s = siz[b]; if (s) { atomicAdd(&hsize[slot * kBuckets + b], (unsigned long long)s); siz[b] = 0u; } }
+        }
+        __syncthreads();
     }
 }
 
@@ -515,7 +524,8 @@ static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntile
         attr_set = true;
     }
     KTIME(GQ ? "k_hist_gq" : "k_hist_lq", s, (W ? 34.0 : 26.0) * px);
-    hipLaunchKernelGGL((k_hist<W, GQ>), ntiles, 512, lds, s, qb, d_tiles, d_nodes, d_hist, d_hsize, d_hcount);
+    const int g = std::min(ntiles, 256 * 4);             // 4 resident blocks per CU (LDS), each walks its run of tiles
+    hipLaunchKernelGGL((k_hist<W, GQ>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount);
     HIP_CHECK(hipGetLastError());
 }
 
