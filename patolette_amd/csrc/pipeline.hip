@@ -96,6 +96,44 @@ __global__ void k_get_nodes(const NodeDev *table, NodeOut *stage, const int *ids
     stage[i] = o;
 }
 
+// One launch prepares a split round from the packet the host uploaded in one copy: node records into the table,
+// the tile lists of both tilings (a pure function of the nodes' segments), and zeroed histograms.
+struct RoundSetup {
+    const NodeIn *recs; const int *ids; const int *tA0; const int *tP0;    // device pointers into the packet
+    int nr, ntA, ntP;
+    Tile *tilesA, *tilesP;
+    double *hist; size_t nhist;
+    unsigned long long *hsize; unsigned int *hcount; size_t nbk;
+};
+__device__ __forceinline__ int node_of_tile(const int *t0, int nr, int t) {   // largest r with t0[r] <= t
+    int lo = 0, hi = nr;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t0[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup a) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < (size_t)a.nr; i += stride) {
+        const NodeIn in = a.recs[i];
+        NodeDev &d = table[a.ids[i]];
+        d.begin = in.begin; d.n = in.n; d.buf = in.buf; d.slot = in.slot; d.child0 = in.child0; d.nchild = in.nchild;
+        for (int j = 0; j < 3; j++) { d.axis[j] = in.axis[j]; d.mean[j] = in.mean[j]; }
+        d.sw = in.sw; d.klin = in.klin; d.kquad = in.kquad;
+        node_reset_outputs(d);
+    }
+    for (size_t t = tid; t < (size_t)a.ntA; t += stride) {
+        const int r = node_of_tile(a.tA0, a.nr, (int)t);
+        const unsigned long long o = (unsigned long long)((int)t - a.tA0[r]) * kTileA, n = a.recs[r].n;
+        a.tilesA[t] = Tile{a.recs[r].begin + o, (unsigned)(n - o < (unsigned long long)kTileA ? n - o : kTileA), (unsigned)a.ids[r]};
+    }
+    for (size_t t = tid; t < (size_t)a.ntP; t += stride) {
+        const int r = node_of_tile(a.tP0, a.nr, (int)t);
+        const unsigned long long o = (unsigned long long)((int)t - a.tP0[r]) * kTileP, n = a.recs[r].n;
+        a.tilesP[t] = Tile{a.recs[r].begin + o, (unsigned)(n - o < (unsigned long long)kTileP ? n - o : kTileP), (unsigned)a.ids[r]};
+    }
+    for (size_t i = tid; i < a.nhist; i += stride) a.hist[i] = 0.0;
+    for (size_t i = tid; i < a.nbk; i += stride) { a.hsize[i] = 0ULL; a.hcount[i] = 0u; }
+}
+
 struct Bounds { double cmax, range, wmax; int e_lin, e_quad; double lo[3], hi[3]; };
 
 static int exp_bound(double v) {                 // smallest E with 2^E > v (v > 0)
@@ -125,7 +163,8 @@ struct Engine {
     PinBuf<Tile> h_tilesA, h_tilesP;
     PinBuf<int> h_round, h_tile0;
     PinBuf<double> h_dbl;
-    PinBuf<unsigned char> h_bytes;
+    PinBuf<unsigned char> h_bytes, h_packet;
+    DevBuf<unsigned char> packet;
     KMeansWork km;
     NNWork nn;
     SalWork sal;
@@ -233,6 +272,18 @@ static void get_nodes(Engine &E, const std::vector<int> &ids, std::vector<NodeOu
     std::memcpy(E.h_ids_get.p, ids.data(), n * sizeof(int));
     HIP_CHECK(hipMemcpyAsync(E.ids.p, E.h_ids_get.p, n * sizeof(int), hipMemcpyHostToDevice, E.stream));
     hipLaunchKernelGGL(k_get_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.stage_out.p, E.ids.p, n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(E.h_stage_out.p, E.stage_out.p, n * sizeof(NodeOut), hipMemcpyDeviceToHost, E.stream));
+    E.sync();
+    std::memcpy(recs.data(), E.h_stage_out.p, n * sizeof(NodeOut));
+}
+
+// as get_nodes, the ids already on the device (part of the round packet)
+static void get_nodes_dev(Engine &E, const int *d_ids, int n, std::vector<NodeOut> &recs) {
+    recs.resize(n);
+    if (!n) return;
+    E.stage_out.reserve(n); E.h_stage_out.reserve(n);
+    hipLaunchKernelGGL(k_get_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.stage_out.p, d_ids, n);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(E.h_stage_out.p, E.stage_out.p, n * sizeof(NodeOut), hipMemcpyDeviceToHost, E.stream));
     E.sync();
@@ -482,27 +533,44 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             const int nr = (int)todo.size();
             size_t rpx = 0;
             for (int id : todo) rpx += hn[id].n;
-            put_nodes(E, ids, recs);
-            build_tiles(todo, hn, kTileA, tA, nullptr);
-            build_tiles(todo, hn, kTileP, tP, &tile0);
-            upload_tiles(E, tA, E.tilesA, E.h_tilesA);
-            upload_tiles(E, tP, E.tilesP, E.h_tilesP);
-            upload_ints(E, todo, E.round_nodes, E.h_round);
-            upload_ints(E, tile0, E.node_tile0, E.h_tile0);
+            // one packet, one copy: node records, ids, tile prefixes of both tilings, children ids
+            std::vector<int> tA0(nr + 1), tP0(nr + 1), cids;
+            tA0[0] = 0; tP0[0] = 0;
+            for (int r = 0; r < nr; r++) {
+                const unsigned long long n = hn[todo[r]].n;
+                tA0[r + 1] = tA0[r] + (int)((n + kTileA - 1) / kTileA);
+                tP0[r + 1] = tP0[r] + (int)((n + kTileP - 1) / kTileP);
+            }
+            const int ntA = tA0[nr], ntP = tP0[nr];
+            for (int id : todo) { cids.push_back(hn[id].left); cids.push_back(hn[id].right); }
+            const size_t o_recs = 0, o_ids = o_recs + (size_t)nr * sizeof(NodeIn), o_tA0 = o_ids + (size_t)nr * sizeof(int),
+                         o_tP0 = o_tA0 + (size_t)(nr + 1) * sizeof(int), o_cids = o_tP0 + (size_t)(nr + 1) * sizeof(int),
+                         pk_bytes = o_cids + cids.size() * sizeof(int);
+            E.h_packet.reserve(pk_bytes); E.packet.reserve(pk_bytes);
+            std::memcpy(E.h_packet.p + o_recs, recs.data(), (size_t)nr * sizeof(NodeIn));
+            std::memcpy(E.h_packet.p + o_ids, ids.data(), (size_t)nr * sizeof(int));
+            std::memcpy(E.h_packet.p + o_tA0, tA0.data(), (size_t)(nr + 1) * sizeof(int));
+            std::memcpy(E.h_packet.p + o_tP0, tP0.data(), (size_t)(nr + 1) * sizeof(int));
+            std::memcpy(E.h_packet.p + o_cids, cids.data(), cids.size() * sizeof(int));
+            HIP_CHECK(hipMemcpyAsync(E.packet.p, E.h_packet.p, pk_bytes, hipMemcpyHostToDevice, s));
             const size_t lqs = (size_t)kNQ_LQ * 2 * kBuckets;
             E.hist.reserve(std::max(hs, lqs * nr)); E.hsize.reserve((size_t)nr * kBuckets); E.hcount.reserve((size_t)nr * kBuckets);
             E.lut.reserve((size_t)nr * kBuckets);
-            E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
-            HIP_CHECK(hipMemsetAsync(E.hist.p, 0, lqs * nr * sizeof(double), s));
-            HIP_CHECK(hipMemsetAsync(E.hsize.p, 0, (size_t)nr * kBuckets * sizeof(unsigned long long), s));
-            HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, (size_t)nr * kBuckets * sizeof(unsigned int), s));
-            launch_minmax(qlq, E.tilesA.p, (int)tA.size(), rpx, E.nodes.p, s);
-            launch_hist(qlq, false, E.tilesA.p, (int)tA.size(), rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
-            launch_cut(weighted, E.nodes.p, E.round_nodes.p, nr, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s);
-            launch_partition(qlq, E.tilesP.p, (int)tP.size(), rpx, E.round_nodes.p, E.node_tile0.p, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s);
-            std::vector<int> cids;
-            for (int id : todo) { cids.push_back(hn[id].left); cids.push_back(hn[id].right); }
-            get_nodes(E, cids, got);
+            E.tilesA.reserve(ntA); E.tilesP.reserve(ntP);
+            E.tilecnt.reserve((size_t)ntP * kMaxChildren); E.tileoff.reserve((size_t)ntP * kMaxChildren);
+            const int *d_ids = (const int *)(E.packet.p + o_ids), *d_tP0 = (const int *)(E.packet.p + o_tP0);
+            RoundSetup rs{(const NodeIn *)(E.packet.p + o_recs), d_ids, (const int *)(E.packet.p + o_tA0), d_tP0, nr, ntA, ntP,
+                          E.tilesA.p, E.tilesP.p, E.hist.p, lqs * nr, E.hsize.p, E.hcount.p, (size_t)nr * kBuckets};
+            {
+                const size_t work = std::max<size_t>(std::max<size_t>(ntP, lqs * nr / 4), 256);
+                hipLaunchKernelGGL(k_round_setup, (unsigned)std::min<size_t>((work + 255) / 256, 2048), 256, 0, s, E.nodes.p, rs);
+                HIP_CHECK(hipGetLastError());
+            }
+            launch_minmax(qlq, E.tilesA.p, ntA, rpx, E.nodes.p, s);
+            launch_hist(qlq, false, E.tilesA.p, ntA, rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+            launch_cut(weighted, E.nodes.p, d_ids, nr, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s);
+            launch_partition(qlq, E.tilesP.p, ntP, rpx, d_ids, d_tP0, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s);
+            get_nodes_dev(E, (const int *)(E.packet.p + o_cids), (int)cids.size(), got);
             for (size_t i = 0; i < cids.size(); i++) {
                 HNode &c = hn[cids[i]];
                 const NodeOut &d = got[i];
