@@ -418,33 +418,21 @@ inline bool gq_should_terminate(const std::vector<size_t> &q, const double ax[3]
     return bias < 0.1;
 }
 
-// global.c:189-298: returns the cut vector [0 = q0, ..., qk = 512]; empty on error.
-inline std::vector<size_t> gq_principal_quantizer(size_t palette_size, const CellMoments &c) {
+// global.c:189-298: returns the cut vector [0 = q0, ..., qk = 512]; empty on error.  The O(k * 512^2) dynamic
+// programme itself (global.c:232-280) runs on the device (quant.hip k_gq_dp) for every k up to max_k; `cut[k][n]` is
+// the reference's L[k][n].  Here: the bias termination test per k (global.c:99-187) and the backtrack.
+inline std::vector<size_t> gq_principal_quantizer(size_t palette_size, const CellMoments &c, const int (*cut)[513]) {
     const size_t N = 512, max_k = 12;
     double ax[3];
     if (!c.axis(0, N, ax)) return {};
     bool error = false;
-    std::vector<double> E(N + 1, 0.0), Ep(N + 1, 0.0);
     size_t kmax = palette_size < max_k ? palette_size : max_k;
-    std::vector<std::vector<double>> L(kmax + 2, std::vector<double>(N + 2, 0.0));
-    for (size_t i = 1; i <= N; i++) E[i] = c.distortion(0, i);
-    for (size_t i = 1; i <= kmax + 1 && i <= palette_size; i++) L[i][i] = (double)i;
     std::vector<size_t> result = {0, N};
     for (size_t k = 2; k <= kmax; k++) {
         if (gq_should_terminate(result, ax, c, error)) break;
-        Ep = E;
-        for (size_t n = k + 1; n <= N; n++) {
-            double cut = (double)(n - 1), e = Ep[n - 1];
-            for (size_t t = n - 2; t >= k - 1; t--) {
-                double v = Ep[t] + c.distortion(t, n);
-                if (v < e) { cut = (double)t; e = v; }
-            }
-            L[k][n] = cut;
-            E[n] = e;
-        }
         result.assign(k + 1, 0);
         size_t t = N;
-        for (size_t j = k - 1; j >= 1; j--) { t = (size_t)L[j + 1][t]; result[j] = t; }
+        for (size_t j = k - 1; j >= 1; j--) { t = (size_t)cut[j + 1][t]; result[j] = t; }
         result[0] = 0; result[k] = N;
     }
     return result;

@@ -169,6 +169,8 @@ struct Engine {
     NNWork nn;
     SalWork sal;
     DevBuf<double> wsal;
+    DevBuf<GqDpDev> gq;
+    PinBuf<GqDpDev> h_gq;
     DevBuf<int> perm_dev;
     size_t perm_N = 0, perm_nx = 0;
     patolette_amd__Stats stats{};
@@ -362,6 +364,10 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, kBuckets * sizeof(unsigned int), s));
     launch_minmax(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
     launch_hist(qroot, true, E.tilesA.p, (int)tA.size(), N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+    const int gq_kmax = (int)std::min<size_t>(K, kGqMaxK);
+    E.gq.reserve(1); E.h_gq.reserve(1);
+    launch_gq_dp(E.hist.p, E.hcount.p, gq_kmax, E.gq.p, s);
+    HIP_CHECK(hipMemcpyAsync(E.h_gq.p->cut, E.gq.p->cut, sizeof(E.h_gq.p->cut), hipMemcpyDeviceToHost, s));
     std::vector<double> hh(hs);
     std::vector<unsigned int> hc(kBuckets);
     HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.hist.p, hs * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -385,7 +391,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         for (int r = 0; r < 3; r++) cm->w1[r][i] += cm->w1[r][i - 1];
         for (int q = 0; q < 6; q++) cm->wrs[q][i] += cm->wrs[q][i - 1];
     }
-    std::vector<size_t> cuts = hm::gq_principal_quantizer(K, *cm);
+    std::vector<size_t> cuts = hm::gq_principal_quantizer(K, *cm, E.h_gq.p->cut);
     if (cuts.size() < 2) return -1;
     const int kbase = (int)cuts.size() - 1;
 

@@ -81,6 +81,16 @@ struct QuantBuffers {
 
 // all launchers enqueue on `s` and return immediately
 void launch_sum3(const double *planar, size_t N, BinK k, double *d_out6, hipStream_t s);
+// global quantiser DP state on the device (global.c:189-298)
+constexpr int kGqMaxK = 12;                // global.c:23 max_k
+struct GqDpDev {
+    unsigned long long w0[kBuckets + 1];
+    double w1[3][kBuckets + 1], w2[kBuckets + 1];
+    double E[2][kBuckets + 1];
+    int cut[kGqMaxK + 1][kBuckets + 1];    // cut[k][n] = L[k][n] of the reference
+};
+void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, GqDpDev *d_g, hipStream_t s);
+
 void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s);
 void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
                  double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s);

@@ -529,6 +529,80 @@ static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntile
     HIP_CHECK(hipGetLastError());
 }
 
+// --------------------------------------------------------------------------------------------
+// Global quantiser DP on the device (global.c:232-280): E_k[n] = min_t E_{k-1}[t] + distortion(t, n).
+// The 512-bucket moment table already lives in HBM; the reference's O(k * 512^2) double loop is ~0.3 ms per k on one
+// host core (up to 12 k), here one launch per k with a block per n and the t-range across the block.  Same f64
+// expressions in the same order (cells.c:141-182), same precedence among equal minima (the sequential loop runs t
+// downwards with a strict '<', starting from t = n-1), so the cut table is bit-identical.  All kmax steps are run;
+// the host applies the bias termination test (global.c:99-187) to the downloaded table step by step.
+// --------------------------------------------------------------------------------------------
+__global__ void k_gq_prefix(const double *__restrict__ hist, const unsigned int *__restrict__ hcount, GqDpDev *g) {
+    // thread q builds one inclusive prefix sequentially (cells.c:114-136): 0 = w0, 1..3 = w1[r], 4 = w2
+    const int q = threadIdx.x;
+    if (q == 0) { unsigned long long a = 0; g->w0[0] = 0; for (int b = 0; b < kBuckets; b++) { a += hcount[b]; g->w0[b + 1] = a; } }
+    else if (q <= 4) {
+        const int hq = q - 1;                                  // GQ quantities 0..2 = sum c, 3 = sum |c|^2
+        double *dst = q <= 3 ? g->w1[q - 1] : g->w2;
+        double a = 0; dst[0] = 0;
+        for (int b = 0; b < kBuckets; b++) {
+            const double h = hist[(size_t)(hq * 2 + 0) * kBuckets + b] + hist[(size_t)(hq * 2 + 1) * kBuckets + b];
+            // the host mirrors: table[b+1] = H(q,b), then table[i] += table[i-1]
+            a = h + a;
+            dst[b + 1] = a;
+        }
+    }
+}
+__device__ __forceinline__ double gq_distortion(const GqDpDev *g, int a, int b) {      // cells.c:141-182
+    if (g->w0[a] == g->w0[b]) return 0;
+    const double q0 = g->w1[0][b] - g->w1[0][a], q1 = g->w1[1][b] - g->w1[1][a], q2 = g->w1[2][b] - g->w1[2][a];
+    return g->w2[b] - g->w2[a] - (q0 * q0 + q1 * q1 + q2 * q2) / (double)(g->w0[b] - g->w0[a]);
+}
+__global__ void k_gq_init(GqDpDev *g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= kBuckets) g->E[0][i] = i >= 1 ? gq_distortion(g, 0, i) : 0.0;
+}
+// step k: reads E[(k & 1)], writes E[(k & 1) ^ 1] and cut[k][n]
+__global__ __launch_bounds__(256) void k_gq_dp(GqDpDev *g, int k) {
+    const int n = (int)blockIdx.x;                              // 0..512
+    const double *Ep = g->E[k & 1];
+    double *En = g->E[(k & 1) ^ 1];
+    if (n < k + 1) { if (threadIdx.x == 0) En[n] = Ep[n]; return; }
+    // candidates t = n-2 .. k-1 across the block; the sequential loop keeps the first strict minimum in descending t,
+    // i.e. the largest t among equal minima, and t = n-1 (value Ep[n-1], no distortion term) precedes them all
+    double best = INFINITY; int bt = -1;
+    for (int t = n - 2 - (int)threadIdx.x; t >= k - 1; t -= (int)blockDim.x) {
+        const double v = Ep[t] + gq_distortion(g, t, n);
+        if (v < best) { best = v; bt = t; }                     // descending t within the thread: first minimum = largest t
+    }
+    __shared__ double sv[256];
+    __shared__ int st[256];
+    sv[threadIdx.x] = best; st[threadIdx.x] = bt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double v2 = sv[threadIdx.x + o]; const int t2 = st[threadIdx.x + o];
+            const double v1 = sv[threadIdx.x]; const int t1 = st[threadIdx.x];
+            if (t2 >= 0 && (t1 < 0 || v2 < v1 || (v2 == v1 && t2 > t1))) { sv[threadIdx.x] = v2; st[threadIdx.x] = t2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double e = Ep[n - 1]; int cut = n - 1;
+        if (st[0] >= 0 && sv[0] < e) { e = sv[0]; cut = st[0]; }
+        En[n] = e;
+        g->cut[k][n] = cut;
+    }
+}
+
+void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, GqDpDev *d_g, hipStream_t s) {
+    KTIME("k_gq_dp", s, (double)kmax * 513 * 513 * 8);
+    hipLaunchKernelGGL(k_gq_prefix, 1, 64, 0, s, d_hist, d_hcount, d_g);
+    hipLaunchKernelGGL(k_gq_init, 3, 256, 0, s, d_g);
+    for (int k = 2; k <= kmax; k++) hipLaunchKernelGGL(k_gq_dp, kBuckets + 1, 256, 0, s, d_g, k);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
                  double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s) {
     if (!ntiles) return;
