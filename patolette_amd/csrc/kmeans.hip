@@ -299,7 +299,6 @@ __global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sor
                         h += v.w;
                         c0 = __builtin_fmaf(v.x, v.w, c0); c1 = __builtin_fmaf(v.y, v.w, c1); c2 = __builtin_fmaf(v.z, v.w, c2);
                     } else {
-                        h += 1.0f;
                         c0 += v.x; c1 += v.y; c2 += v.z;
                     }
                 }
@@ -310,13 +309,17 @@ __global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sor
                         h += v.w;
                         c0 = __builtin_fmaf(v.x, v.w, c0); c1 = __builtin_fmaf(v.y, v.w, c1); c2 = __builtin_fmaf(v.z, v.w, c2);
                     } else {
-                        h += 1.0f;
                         c0 += v.x; c1 += v.y; c2 += v.z;
                     }
                 }
             }
             pb ^= 1;
         }
+    }
+    if constexpr (!W) {
+        // the reference's h += 1.0f per sample is exact below 2^24 and sticks there (16777216 + 1 rounds back)
+        const size_t cnt = hi - lo;
+        h = cnt < (size_t)16777216 ? (float)cnt : 16777216.0f;
     }
     if (lane == 0) {
         if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
