@@ -151,12 +151,15 @@ def quantize_u8(image, palette_size, dither=True, palette_only=False, color_spac
 
 
 def quantize_batch(width, height, images, palette_size, weights=None, dither=True, palette_only=False,
-                   color_space=ColorSpace_ICtCp, kmeans_niter=32, kmeans_max_samples=512 ** 2, verbose=False):
+                   color_space=ColorSpace_ICtCp, tile_size=512, kmeans_niter=32, kmeans_max_samples=512 ** 2, verbose=False):
     """Quantise a list of independent images of identical size on the current GPU through
     `patolette_amd_batch` (up to three images in flight: uploads and host-side work of one image
     overlap kernels of another).  Per-image results are identical to separate `quantize` calls
-    (batch extension).  `weights`: None or one entry (array or None) per image.
+    with the same arguments (SURVEY.md 8(b), batch extension).  `weights`: None or one entry (array or None) per image;
+    images without explicit weights get the saliency-derived ones when tile_size > 0, as in `quantize`.
     Returns a list of `quantize` tuples."""
+    if tile_size < 0:
+        return [(False, None, None, bad_tile_size)] * len(images)
     count = len(images)
     n = width * height
     datas = [np.asfortranarray(np.asarray(im), dtype=np.float64) for im in images]
@@ -179,10 +182,11 @@ def quantize_batch(width, height, images, palette_size, weights=None, dither=Tru
     m_arr = None if palette_only else PZ(*[m.ctypes.data_as(_native.zp) for m in maps])
     codes = (C.c_int * count)()
     L = _native.lib()
-    L.patolette_amd_batch(count, width, height, d_arr, w_arr, palette_size, C.byref(opts), p_arr, m_arr, codes)
+    L.patolette_amd_batch(count, width, height, d_arr, w_arr, float(tile_size), palette_size, C.byref(opts), p_arr, m_arr, codes)
     out = []
     for i in range(count):
         msg = L.get_patolette_exit_code_info_message(codes[i]).decode('UTF-8')
+        _raise_saliency(codes[i], msg)
         if codes[i] != 0:
             out.append((False, None, None, msg))
         else:

@@ -11,17 +11,32 @@
 #include "common.h"
 #include "devutil.h"
 
+#include <type_traits>
+
 namespace pamd {
 
 template <int WHICH, class SRC>
 __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ dst, size_t n, ConvertStats *stats) {
     // per-plane min / max of the OUTPUT (bounds for the binned accumulators downstream)
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    constexpr bool kLut = std::is_same<SRC, SrcU8>::value && (WHICH == PAMD_SRGB_TO_ICTCP || WHICH == PAMD_SRGB_TO_CIELUV);
+    __shared__ double glut[kLut ? 256 : 1];                // companding of the 256 possible 8-bit values (sRGB.c:70-89)
+    if constexpr (kLut) {
+        for (int b = threadIdx.x; b < 256; b += blockDim.x) glut[b] = dc::gamma_decode((double)b / 255.0);
+        __syncthreads();
+    }
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double c[3];
-        src.load(i, c);
-        dev_convert<WHICH>(c);
+        if constexpr (kLut) {
+            unsigned r, g, b;
+            src.load_bytes(i, r, g, b);
+            c[0] = glut[r]; c[1] = glut[g]; c[2] = glut[b];
+            dev_convert_linear<WHICH>(c);
+        } else {
+            src.load(i, c);
+            dev_convert<WHICH>(c);
+        }
         dst[i] = c[0]; dst[n + i] = c[1]; dst[2 * n + i] = c[2];
 #pragma unroll
         for (int p = 0; p < 3; p++) { mn[p] = fmin(mn[p], c[p]); mx[p] = fmax(mx[p], c[p]); }

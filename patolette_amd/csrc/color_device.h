@@ -39,11 +39,13 @@ __device__ __forceinline__ double gamma_encode(double c) {               // sRGB
     double r = (c <= 0.0031308) ? c * 12.92 : 1.055 * pow(c, 1.0 / 2.4) - 0.055;
     return fmin(fmax(r, 0.0), 1.0);
 }
-__device__ __forceinline__ void srgb_to_xyz(const double c[3], double &x, double &y, double &z) {   // xyz.c:14-40
-    double R = gamma_decode(c[0]), G = gamma_decode(c[1]), B = gamma_decode(c[2]);
+__device__ __forceinline__ void linear_to_xyz(double R, double G, double B, double &x, double &y, double &z) {   // xyz.c:27-39
     x = R * 0.4124564 + G * 0.3575761 + B * 0.1804375;
     y = R * 0.2126729 + G * 0.7151522 + B * 0.0721750;
     z = R * 0.0193339 + G * 0.1191920 + B * 0.9503041;
+}
+__device__ __forceinline__ void srgb_to_xyz(const double c[3], double &x, double &y, double &z) {   // xyz.c:14-40
+    linear_to_xyz(gamma_decode(c[0]), gamma_decode(c[1]), gamma_decode(c[2]), x, y, z);
 }
 __device__ __forceinline__ void xyz_to_rec2020(double x, double y, double z, double o[3]) {          // rec2020.c:80-102
     o[0] = x * 1.71666343 + y * -0.35567332 + z * -0.25336809;
@@ -80,8 +82,13 @@ __device__ __forceinline__ void ictcp_to_rec2020(double c[3]) {         // rec20
 __device__ constexpr double rwx = 0.95047, rwy = 1.0, rwz = 1.08883;
 __device__ constexpr double kE = 216.0 / 24389.0, kK = 24389.0 / 27.0, kKE = 8.0;
 
+__device__ __forceinline__ void linear_to_cieluv(double c[3]);
 __device__ __forceinline__ void srgb_to_cieluv(double c[3]) {           // CIELuv.c:166-197 + :54-89
-    double r = gamma_decode(c[0]), g = gamma_decode(c[1]), b = gamma_decode(c[2]);
+    c[0] = gamma_decode(c[0]); c[1] = gamma_decode(c[1]); c[2] = gamma_decode(c[2]);
+    linear_to_cieluv(c);
+}
+__device__ __forceinline__ void linear_to_cieluv(double c[3]) {         // the part after the companding
+    double r = c[0], g = c[1], b = c[2];
     double x = r * 0.4124564 + g * 0.3575761 + b * 0.1804375;
     double y = r * 0.2126729 + g * 0.7151522 + b * 0.0721750;
     double z = r * 0.0193339 + g * 0.1191920 + b * 0.9503041;
@@ -132,11 +139,29 @@ struct SrcF64 {
 };
 struct SrcU8 {
     const unsigned char *p; int ch;
+    __device__ __forceinline__ void load_bytes(size_t i, unsigned &r, unsigned &g, unsigned &b) const {
+        const unsigned char *q = p + i * (size_t)ch;
+        r = q[0]; g = q[1]; b = q[2];
+    }
     __device__ __forceinline__ void load(size_t i, double c[3]) const {
         const unsigned char *q = p + i * (size_t)ch;
         c[0] = (double)q[0] / 255.0; c[1] = (double)q[1] / 255.0; c[2] = (double)q[2] / 255.0;
     }
 };
+
+// conversions out of sRGB whose companding (sRGB.c:70-89) has already been applied: 8-bit sources look the 256
+// possible values up instead of evaluating three pow() per pixel; same expressions, same results
+template <int WHICH>
+__device__ __forceinline__ void dev_convert_linear(double c[3]) {
+    if constexpr (WHICH == PAMD_SRGB_TO_ICTCP) {
+        double x, y, z;
+        dc::linear_to_xyz(c[0], c[1], c[2], x, y, z);
+        dc::xyz_to_rec2020(x, y, z, c);
+        dc::rec2020_to_ictcp(c);
+    } else if constexpr (WHICH == PAMD_SRGB_TO_CIELUV) {
+        dc::linear_to_cieluv(c);
+    }
+}
 
 template <int WHICH>
 __device__ __forceinline__ void dev_convert(double c[3]) {

@@ -1146,7 +1146,7 @@ void pool_release(Engine *e) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool
 }  // namespace
 
 void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
-                         size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
+                         double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
                          size_t *const *palette_maps, int *exit_codes) {
     const int v = validate(width, height, palette_size);
     if (v != 0) { for (size_t i = 0; i < count; i++) exit_codes[i] = v; return; }
@@ -1169,9 +1169,11 @@ void patolette_amd_batch(size_t count, size_t width, size_t height, const double
         }
         for (size_t i; (i = next.fetch_add(1)) < count;) {
             try {
-                run_host(*E, width, height, data[i], weights ? weights[i] : nullptr, 0.0, palette_size, options, palettes[i],
+                run_host(*E, width, height, data[i], weights ? weights[i] : nullptr, tile_size, palette_size, options, palettes[i],
                          palette_maps ? palette_maps[i] : nullptr);
                 exit_codes[i] = 0;
+            } catch (const CodeError &ex) {
+                exit_codes[i] = ex.code;
             } catch (const std::exception &ex) {
                 fprintf(stderr, "patolette: %s\n", ex.what());
                 exit_codes[i] = -1;

@@ -13,6 +13,7 @@
 #include "saliency.h"
 
 #include <cmath>
+#include <type_traits>
 
 #include "devutil.h"
 
@@ -26,11 +27,9 @@ constexpr int kE_cov = 17;           // centred products < 2^17
 struct Band { int r0, r1, c0, c1; };             // [r0,r1) x [c0,c1)
 struct Bands { Band b[4]; };
 
-__device__ __forceinline__ void rgb_to_lab(const double c[3], double lab[3]) {
-    // skimage.color.rgb2lab: sRGB companding, XYZ (D65, 2 degree), CIELAB
-    double v[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) v[k] = (c[k] > 0.04045) ? pow((c[k] + 0.055) / 1.055, 2.4) : c[k] / 12.92;
+// skimage.color.rgb2lab: sRGB companding, then XYZ (D65, 2 degree) and CIELAB
+__device__ __forceinline__ double lab_compand(double c) { return (c > 0.04045) ? pow((c + 0.055) / 1.055, 2.4) : c / 12.92; }
+__device__ __forceinline__ void linear_to_lab(const double v[3], double lab[3]) {
     double x = (v[0] * 0.412453 + v[1] * 0.357580) + v[2] * 0.180423;
     double y = (v[0] * 0.212671 + v[1] * 0.715160) + v[2] * 0.072169;
     double z = (v[0] * 0.019334 + v[1] * 0.119193) + v[2] * 0.950227;
@@ -42,11 +41,21 @@ __device__ __forceinline__ void rgb_to_lab(const double c[3], double lab[3]) {
     lab[1] = 500.0 * (x - y);
     lab[2] = 200.0 * (y - z);
 }
+__device__ __forceinline__ void rgb_to_lab(const double c[3], double lab[3]) {
+    const double v[3] = {lab_compand(c[0]), lab_compand(c[1]), lab_compand(c[2])};
+    linear_to_lab(v, lab);
+}
 
 // channel mean (patolette.pyx:204), minimum-barrier initial state (:160-170) and CIELAB (:213)
 template <class SRC>
 __global__ __launch_bounds__(256) void k_sal_prepare(SRC src, size_t n, int rows, int cols, float4 *__restrict__ st,
                                                      double *__restrict__ lab) {
+    constexpr bool kLut = std::is_same<SRC, SrcU8>::value;
+    __shared__ double glut[kLut ? 256 : 1];                // companding of the 256 possible 8-bit values
+    if constexpr (kLut) {
+        for (int b = threadIdx.x; b < 256; b += blockDim.x) glut[b] = lab_compand((double)b / 255.0);
+        __syncthreads();
+    }
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double c[3], o[3];
@@ -55,7 +64,14 @@ __global__ __launch_bounds__(256) void k_sal_prepare(SRC src, size_t n, int rows
         const int r = (int)(i / (size_t)cols), q = (int)(i - (size_t)r * cols);
         const bool frame = r == 0 || q == 0 || r == rows - 1 || q == cols - 1;
         st[i] = make_float4(m, frame ? 0.0f : INFINITY, m, m);      // {img, D, U, L}
-        rgb_to_lab(c, o);
+        if constexpr (kLut) {
+            unsigned r8, g8, b8;
+            src.load_bytes(i, r8, g8, b8);
+            const double v[3] = {glut[r8], glut[g8], glut[b8]};
+            linear_to_lab(v, o);
+        } else {
+            rgb_to_lab(c, o);
+        }
         lab[i] = o[0]; lab[n + i] = o[1]; lab[2 * n + i] = o[2];
     }
 }

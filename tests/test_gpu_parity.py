@@ -222,7 +222,7 @@ def test_python_quantize_tuple_contract(gpu, ob):
     assert ok and pmap2 is None
     ok, pal3, pmap3, msg = p.quantize(w, h, colors, 0, tile_size=0)
     assert (ok, pal3, pmap3, msg) == (False, None, None, "Palette size should be greater than 0.")
-    res = p.quantize_batch(w, h, [colors, colors[::-1].copy()], K, dither=False, kmeans_niter=0)
+    res = p.quantize_batch(w, h, [colors, colors[::-1].copy()], K, dither=False, tile_size=0, kmeans_niter=0)
     assert np.array_equal(res[0][2], pmap) and res[1][0]
 
 
@@ -232,9 +232,10 @@ def test_batch_equals_individual_calls(gpu, ob):
     n = w * h
     imgs = [ob.image(n, 200 + i).reshape(3, n).T.copy() for i in range(count)]
     wts = [ob.weights(n, 200 + i) if i % 2 else None for i in range(count)]
-    batch = p.quantize_batch(w, h, imgs, K, weights=wts, dither=False, kmeans_niter=4, kmeans_max_samples=65536)
+    # images without explicit weights take the saliency-derived ones (tile_size > 0), like quantize()
+    batch = p.quantize_batch(w, h, imgs, K, weights=wts, dither=False, tile_size=64, kmeans_niter=4, kmeans_max_samples=65536)
     for i in range(count):
-        one = p.quantize(w, h, imgs[i], K, dither=False, tile_size=0, kmeans_niter=4, kmeans_max_samples=65536, weights=wts[i])
+        one = p.quantize(w, h, imgs[i], K, dither=False, tile_size=64, kmeans_niter=4, kmeans_max_samples=65536, weights=wts[i])
         assert batch[i][0] and one[0]
         assert np.array_equal(batch[i][1], one[1]) and np.array_equal(batch[i][2], one[2])
 
