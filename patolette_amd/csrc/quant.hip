@@ -283,24 +283,46 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
 __global__ __launch_bounds__(256) void k_count(QuantBuffers qb, const Tile *__restrict__ tiles, const NodeDev *__restrict__ nodes,
                                                const unsigned char *__restrict__ lut, unsigned int *tilecnt) {
     __shared__ unsigned int c[kMaxChildren];
+    __shared__ unsigned char sl[kBuckets];
     const Tile t = tiles[blockIdx.x];
     const NodeDev &nd = nodes[t.node];
     const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
     if (threadIdx.x < kMaxChildren) c[threadIdx.x] = 0;
-    __syncthreads();
     const int nch = nd.nchild;
-    for (unsigned i = threadIdx.x; i < ((t.count + 255u) & ~255u); i += blockDim.x) {
-        int child = i < t.count ? (int)l[qb.bkt[t.start + i]] : 255;
-        for (int k = 0; k < nch; k++) {
-            unsigned long long m = __ballot(child == k);
-            if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c[k], (unsigned)__popcll(m));
+    if (nch == 2) {
+        // binary split (every local-quantiser round): 8 buckets per thread in one 16-byte load, the child looked up in an
+        // LDS copy of the bucket -> child table, one LDS atomic per wavefront
+        for (int b = threadIdx.x; b < kBuckets; b += blockDim.x) sl[b] = l[b];
+        __syncthreads();
+        typedef unsigned short us8 __attribute__((ext_vector_type(8), aligned(2)));
+        const unsigned i0 = threadIdx.x * 8u;
+        unsigned right = 0;
+        if (i0 + 8u <= t.count) {
+            const us8 v = *reinterpret_cast<const us8 *>(qb.bkt + t.start + i0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) right += sl[v[j]];
+        } else {
+            for (unsigned i = i0; i < t.count && i < i0 + 8u; i++) right += sl[qb.bkt[t.start + i]];
         }
+        right = wave_sum_u32(right);
+        if ((threadIdx.x & 63) == 0 && right) atomicAdd(&c[1], right);
+        __syncthreads();
+        if (threadIdx.x == 0) c[0] = t.count - c[1];
+        __syncthreads();
+    } else {
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < ((t.count + 255u) & ~255u); i += blockDim.x) {
+            int child = i < t.count ? (int)l[qb.bkt[t.start + i]] : 255;
+            for (int k = 0; k < nch; k++) {
+                unsigned long long m = __ballot(child == k);
+                if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c[k], (unsigned)__popcll(m));
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x < kMaxChildren) tilecnt[(size_t)blockIdx.x * kMaxChildren + threadIdx.x] = c[threadIdx.x];
 }
-
-__global__ __launch_bounds__(256) void k_scan(const int *__restrict__ round_nodes, const int *__restrict__ node_tile0, NodeDev *nodes,
+__global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ round_nodes, const int *__restrict__ node_tile0, NodeDev *nodes,
                                               const unsigned int *__restrict__ tilecnt, unsigned long long *tileoff) {
     __shared__ unsigned long long su[16];
     __shared__ unsigned long long carry;
@@ -626,7 +648,7 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
                       unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s) {
     if (!nptiles) return;
     { KTIME("k_count", s, 2.0 * px); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt); }
-    { KTIME("k_scan", s, 12.0 * kMaxChildren * nptiles); hipLaunchKernelGGL(k_scan, nround, 256, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff); }
+    { KTIME("k_scan", s, 12.0 * kMaxChildren * nptiles); hipLaunchKernelGGL(k_scan, nround, 1024, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff); }
     {
         KTIME(fuse_cov ? "k_scatter_cov" : "k_scatter", s, (qb.weighted ? 66.0 : 50.0) * px);
         if (fuse_cov) {
