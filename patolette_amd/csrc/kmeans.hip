@@ -127,15 +127,32 @@ __global__ __launch_bounds__(256) void k_km_assign_count(KmSamples s, size_t nx,
 
 // per centroid: exclusive scan of its row of chunk counts (in place) + row total
 __global__ __launch_bounds__(256) void k_km_rowscan(unsigned int *table, int nchunks, unsigned int *rowtot) {
+    // exclusive prefix of one row of the count table; 16 consecutive entries per thread (4 x 16-byte loads), one block
+    // scan of the thread totals per 4096 entries
+    constexpr int IT = 16;
     __shared__ unsigned int sw[4];
     __shared__ unsigned int carry;
     unsigned int *row = table + (size_t)blockIdx.x * nchunks;
     if (threadIdx.x == 0) carry = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int c0 = 0; c0 < nchunks; c0 += 256) {
-        int c = c0 + threadIdx.x;
-        unsigned v = c < nchunks ? row[c] : 0u, inc = v;
+    for (int c0 = 0; c0 < nchunks; c0 += 256 * IT) {
+        const int base = c0 + (int)threadIdx.x * IT;
+        unsigned v[IT];
+        if (base + IT <= nchunks && (((size_t)blockIdx.x * nchunks + base) & 3) == 0) {
+#pragma unroll
+            for (int q = 0; q < IT / 4; q++) {
+                const uint4 u = *reinterpret_cast<const uint4 *>(row + base + 4 * q);
+                v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < IT; q++) v[q] = base + q < nchunks ? row[base + q] : 0u;
+        }
+        unsigned tot = 0;
+#pragma unroll
+        for (int q = 0; q < IT; q++) { const unsigned x = v[q]; v[q] = tot; tot += x; }      // exclusive within the thread
+        unsigned inc = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
         if (lane == 63) sw[wid] = inc;
@@ -143,7 +160,9 @@ __global__ __launch_bounds__(256) void k_km_rowscan(unsigned int *table, int nch
         unsigned pre = 0;
         for (int w = 0; w < wid; w++) pre += sw[w];
         const unsigned cr = carry;
-        if (c < nchunks) row[c] = cr + pre + inc - v;
+        const unsigned off = cr + pre + inc - tot;
+#pragma unroll
+        for (int q = 0; q < IT; q++) if (base + q < nchunks) row[base + q] = off + v[q];
         __syncthreads();
         if (threadIdx.x == 255) carry = cr + pre + inc;
         __syncthreads();
@@ -254,74 +273,82 @@ __device__ void km_split_clusters(float *cent, float *hassign, int k, unsigned l
 
 // ---- centroid update: one wavefront replays one centroid's sequential f32 chain; the last
 // wavefront to finish handles empty clusters and writes (y, |y|^2) for the next assignment ----
-template <bool W>
-__global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sorted, const unsigned int *__restrict__ rowtot, int k,
-                                                  unsigned long long nx, float *cent, float *hassign, float4 *c4,
-                                                  unsigned int *ticket, DevMT *mt) {
-    constexpr int D = 8;                                                   // 1-KiB LDS-DMA loads kept in flight
-    __shared__ float4 stage[2][64];
-    __shared__ int s_last;
-    const int kidx = blockIdx.x, lane = threadIdx.x;
-    // segment of this centroid = prefix of the row totals
-    unsigned pre = 0;
-    for (int j = lane; j < kidx; j += 64) pre += rowtot[j];
-    pre = wave_sum_u32(pre);
-    pre = __shfl(pre, 0, 64);
-    const size_t lo = pre, hi = lo + rowtot[kidx];
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, h = 0.f;
-    const long nblk = (long)((hi - lo + 63) / 64);
+// One wavefront per coordinate: the x, y, z (and weight) sums of a centroid are independent sequential chains, so a
+// block of four wavefronts runs them side by side -- per sample one LDS broadcast read and one add on each chain.
+template <bool W, int C>
+__device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, size_t lo, size_t hi, float4 (*stage)[64], int lane) {
+    constexpr int D = 8;                                                   // 1-KiB loads kept in flight
+    float acc = 0.f;
     float4 ring[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         ring[d] = make_float4(0, 0, 0, 0);
         if (lo + (size_t)d * 64 + lane < hi) ring[d] = sorted[lo + (size_t)d * 64 + lane];
     }
-    (void)nblk;
     int pb = 0;
     for (size_t sbase = lo; sbase < hi; sbase += (size_t)D * 64) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const size_t base = sbase + (size_t)d * 64;
             if (base >= hi) break;                                         // wave-uniform
-            stage[pb][lane] = ring[d];
+            stage[pb][lane] = ring[d];                                     // LDS of this wavefront only: in-order, no barrier
             {   // refill this ring slot with the block D steps ahead
                 const size_t nb = base + (size_t)D * 64 + lane;
                 ring[d] = make_float4(0, 0, 0, 0);
                 if (nb < hi) ring[d] = sorted[nb];
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             const int cnt = (int)(hi - base < 64 ? hi - base : 64);
+            const float *sp = reinterpret_cast<const float *>(&stage[pb][0]);
+            auto step = [&](int t) {
+                if constexpr (W) {
+                    const float w = sp[4 * t + 3];
+                    if constexpr (C == 3) acc += w; else acc = __builtin_fmaf(sp[4 * t + C], w, acc);
+                } else {
+                    acc += sp[4 * t + C];
+                }
+            };
             if (cnt == 64) {
 #pragma unroll 16
-                for (int t = 0; t < 64; t++) {
-                    const float4 v = stage[pb][t];                         // LDS broadcast read
-                    if constexpr (W) {
-                        h += v.w;
-                        c0 = __builtin_fmaf(v.x, v.w, c0); c1 = __builtin_fmaf(v.y, v.w, c1); c2 = __builtin_fmaf(v.z, v.w, c2);
-                    } else {
-                        c0 += v.x; c1 += v.y; c2 += v.z;
-                    }
-                }
+                for (int t = 0; t < 64; t++) step(t);
             } else {
-                for (int t = 0; t < cnt; t++) {
-                    const float4 v = stage[pb][t];
-                    if constexpr (W) {
-                        h += v.w;
-                        c0 = __builtin_fmaf(v.x, v.w, c0); c1 = __builtin_fmaf(v.y, v.w, c1); c2 = __builtin_fmaf(v.z, v.w, c2);
-                    } else {
-                        c0 += v.x; c1 += v.y; c2 += v.z;
-                    }
-                }
+                for (int t = 0; t < cnt; t++) step(t);
             }
+            __builtin_amdgcn_wave_barrier();
             pb ^= 1;
         }
     }
+    return acc;
+}
+
+template <bool W>
+__global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ sorted, const unsigned int *__restrict__ rowtot, int k,
+                                                  unsigned long long nx, float *cent, float *hassign, float4 *c4,
+                                                  unsigned int *ticket, DevMT *mt) {
+    __shared__ float4 stage[4][2][64];
+    __shared__ float res[4];
+    __shared__ int s_last;
+    const int kidx = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // segment of this centroid = prefix of the row totals
+    unsigned pre = 0;
+    for (int j = lane; j < kidx; j += 64) pre += rowtot[j];
+    pre = wave_sum_u32(pre);
+    pre = __shfl(pre, 0, 64);
+    const size_t lo = pre, hi = lo + rowtot[kidx];
+    float acc = 0.f;
+    if (wid == 0) acc = km_chain<W, 0>(sorted, lo, hi, stage[0], lane);
+    else if (wid == 1) acc = km_chain<W, 1>(sorted, lo, hi, stage[1], lane);
+    else if (wid == 2) acc = km_chain<W, 2>(sorted, lo, hi, stage[2], lane);
+    else if (W) acc = km_chain<W, 3>(sorted, lo, hi, stage[3], lane);
+    if (lane == 0) res[wid] = acc;
+    __syncthreads();
+    float c0 = res[0], c1 = res[1], c2 = res[2], h = res[3];
     if constexpr (!W) {
         // the reference's h += 1.0f per sample is exact below 2^24 and sticks there (16777216 + 1 rounds back)
         const size_t cnt = hi - lo;
         h = cnt < (size_t)16777216 ? (float)cnt : 16777216.0f;
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
         // publish with write-through (sc1) stores + drained counter: no per-wave L2 write-back fence
         // (256 release fences, each flushing the XCD's dirty lines, cost more than the chains themselves)
@@ -334,8 +361,8 @@ __global__ __launch_bounds__(64) void k_km_update(const float4 *__restrict__ sor
         s_last = (tk == (unsigned)k - 1u) ? 1 : 0;
     }
     __syncthreads();
-    if (!s_last) return;
-    // last wavefront: every centroid was published with sc1 stores; read them back with sc1 (L1-bypassing) loads
+    if (!s_last || wid != 0) return;                                      // terminated wavefronts do not count at later barriers
+    // last block: every centroid was published with sc1 stores; read them back with sc1 (L1-bypassing) loads
     bool mine_empty = false;
     for (int ci = lane; ci < k; ci += 64)
         if (__hip_atomic_load(&hassign[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.f) mine_empty = true;
@@ -419,8 +446,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         }
         {
             KTIME("k_km_update", s, 16.0 * nx);
-            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 64, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
-            else hipLaunchKernelGGL(k_km_update<false>, k, 64, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 256, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+            else hipLaunchKernelGGL(k_km_update<false>, k, 256, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
         }
     }
     HIP_CHECK(hipGetLastError());
