@@ -322,14 +322,18 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     // unweighted PCA of all pixels: mean, centred covariance, dsyev
     HNode root; root.begin = 0; root.n = N; root.buf = 0; root.sw = (double)N;
     int rootP = 1; while ((1ULL << rootP) < (N > 1 ? N : 2)) rootP++;
-    E.sum6.reserve(6);
+    E.sum6.reserve(kSum3Slots * 6);
     launch_sum3(E.cvt.p, N, make_bink(bnd.e_lin, rootP), E.sum6.p, s);
     E.h_dbl.reserve(16 * kBuckets * 2 + 64);
-    HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.sum6.p, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.sum6.p, kSum3Slots * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
     E.sync();
     {
         const double inv = 1 / (double)N;                       // matrix2D.c:229
-        for (int j = 0; j < 3; j++) root.mean[j] = (E.h_dbl.p[2 * j] + E.h_dbl.p[2 * j + 1]) * inv;
+        for (int j = 0; j < 3; j++) {
+            double p0 = 0, p1 = 0;                              // slot partials are exact multiples of the bin grids
+            for (int sl = 0; sl < kSum3Slots; sl++) { p0 += E.h_dbl.p[sl * 6 + 2 * j]; p1 += E.h_dbl.p[sl * 6 + 2 * j + 1]; }
+            root.mean[j] = (p0 + p1) * inv;
+        }
     }
     hn.push_back(root);                                         // id 0
     QuantBuffers qroot{{E.cvt.p, E.bufA.p}, E.bkt.p, N, weighted};

@@ -80,6 +80,7 @@ struct QuantBuffers {
 };
 
 // all launchers enqueue on `s` and return immediately
+constexpr int kSum3Slots = 32;         // d_out6 holds kSum3Slots x 6 partial sums (exact parts: the reader adds them in any order)
 void launch_sum3(const double *planar, size_t N, BinK k, double *d_out6, hipStream_t s);
 // global quantiser DP state on the device (global.c:189-298)
 constexpr int kGqMaxK = 12;                // global.c:23 max_k

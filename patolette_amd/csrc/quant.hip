@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void k_sum3(const double *__restrict__ c, size
         bin_add(c[2 * N + i], k, a[4], a[5]);
     }
     block_sum<6>(a, sm);
-    if (threadIdx.x == 0)
-        for (int q = 0; q < 6; q++) unsafeAtomicAdd(&out6[q], a[q]);
+    if (threadIdx.x == 0)                                   // same-address atomics serialise in L2: spread over slots
+        for (int q = 0; q < 6; q++) unsafeAtomicAdd(&out6[(blockIdx.x & (kSum3Slots - 1)) * 6 + q], a[q]);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_cov_nodes(QuantBuffers qb, const double
 size_t hist_slot_doubles() { return (size_t)kNQ_GQ * 2 * kBuckets; }
 
 void launch_sum3(const double *planar, size_t N, BinK k, double *d_out6, hipStream_t s) {
-    HIP_CHECK(hipMemsetAsync(d_out6, 0, 6 * sizeof(double), s));
+    HIP_CHECK(hipMemsetAsync(d_out6, 0, kSum3Slots * 6 * sizeof(double), s));
     size_t g = ceil_div(N, 256 * 16);
     if (g > 2048) g = 2048;
     if (g < 1) g = 1;

@@ -10,8 +10,8 @@ namespace pamd {
 constexpr int kSalMax = 8;           // maxima: 0..3 border contrasts, 4 barrier distance, 5 u_final, 6 s1, 7 s2
 
 struct SalDev {                      // device-resident scalars of one saliency evaluation
-    double sum[4][3][2];             // binned sums of Lab over the four border bands
-    double cov[4][6][2];             // binned centred products xx,xy,xz,yy,yz,zz
+    double sum[kStatSlots][4][3][2]; // binned sums of Lab over the four border bands (slots: same-address atomics serialise)
+    double cov[kStatSlots][4][6][2]; // binned centred products xx,xy,xz,yy,yz,zz
     double mean[4][3];
     double vi[4][9];                 // inverse covariance, row-major
     unsigned long long maxkey[kSalMax][kStatSlots];

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void k_sal_prepare(SRC src, size_t n, int rows
 
 __global__ void k_sal_init(SalDev *d) {
     const int t = threadIdx.x;
-    if (t < 4 * 3 * 2) (&d->sum[0][0][0])[t] = 0.0;
-    if (t < 4 * 6 * 2) (&d->cov[0][0][0])[t] = 0.0;
+    for (int i = t; i < kStatSlots * 4 * 3 * 2; i += blockDim.x) (&d->sum[0][0][0][0])[i] = 0.0;
+    for (int i = t; i < kStatSlots * 4 * 6 * 2; i += blockDim.x) (&d->cov[0][0][0][0])[i] = 0.0;
     for (int i = t; i < kSalMax * kStatSlots; i += blockDim.x) (&d->maxkey[0][0])[i] = f64_key(-INFINITY);
     if (t == 0) d->singular = 0;
 }
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void k_sal_band(const double *__restrict__ lab
     }
     block_sum<NV>(acc, sm);
     if (threadIdx.x == 0) {
-        double *dst = CENTRED ? &d->cov[blockIdx.y][0][0] : &d->sum[blockIdx.y][0][0];
+        const int slot = blockIdx.x & (kStatSlots - 1);
+        double *dst = CENTRED ? &d->cov[slot][blockIdx.y][0][0] : &d->sum[slot][blockIdx.y][0][0];
 #pragma unroll
         for (int k = 0; k < NV; k++) atomicAdd(&dst[k], acc[k]);
     }
@@ -124,7 +125,9 @@ __global__ void k_sal_means(SalDev *d, Bands bands) {
         const int r = t / 3, c = t % 3;
         const Band b = bands.b[r];
         const double cnt = (double)((size_t)(b.r1 - b.r0) * (size_t)(b.c1 - b.c0));
-        d->mean[r][c] = (d->sum[r][c][0] + d->sum[r][c][1]) / cnt;
+        double p0 = 0, p1 = 0;                                  // exact parts: any order
+        for (int sl = 0; sl < kStatSlots; sl++) { p0 += d->sum[sl][r][c][0]; p1 += d->sum[sl][r][c][1]; }
+        d->mean[r][c] = (p0 + p1) / cnt;
     }
 }
 
@@ -137,7 +140,11 @@ __global__ void k_sal_invcov(SalDev *d, Bands bands) {
     const double cnt = (double)((size_t)(b.r1 - b.r0) * (size_t)(b.c1 - b.c0));
     const double f = 1.0 / (cnt - 1.0);
     double c6[6];
-    for (int k = 0; k < 6; k++) c6[k] = (d->cov[r][k][0] + d->cov[r][k][1]) * f;
+    for (int k = 0; k < 6; k++) {
+        double p0 = 0, p1 = 0;
+        for (int sl = 0; sl < kStatSlots; sl++) { p0 += d->cov[sl][r][k][0]; p1 += d->cov[sl][r][k][1]; }
+        c6[k] = (p0 + p1) * f;
+    }
     double a[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
     double inv[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     bool sing = false;
