@@ -546,7 +546,9 @@ static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntile
         attr_set = true;
     }
     KTIME(GQ ? "k_hist_gq" : "k_hist_lq", s, (W ? 34.0 : 26.0) * px);
-    const int g = std::min(ntiles, 256 * 4);             // 4 resident blocks per CU (LDS), each walks its run of tiles
+    // resident blocks per CU by LDS footprint (4 for the local quantiser's 29 KB, 1 for the global quantiser's 82+ KB);
+    // each block walks its run of tiles and flushes once per node run
+    const int g = std::min(ntiles, 256 * (GQ ? 1 : 4));
     hipLaunchKernelGGL((k_hist<W, GQ>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount);
     HIP_CHECK(hipGetLastError());
 }
