@@ -102,6 +102,9 @@ void patolette_amd_batch(size_t count, size_t width, size_t height, const double
                          size_t *const *palette_maps, int *exit_codes);
 
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
+/* out[i] = pow(x[i], y) as the colour conversions evaluate it on the device (x >= 0; <= 0.51 ulp) */
+int patolette_amd_pow(const double *x, double y, double *out, size_t n);
+
 enum {
     PAMD_SRGB_TO_ICTCP = 0,     /* patolette__COLOR_sRGB_Matrix_to_ICtCp_Matrix            color/ICtCp.c:120-146 */
     PAMD_SRGB_TO_CIELUV = 1,    /* patolette__COLOR_sRGB_Matrix_to_CIELuv_Matrix           color/CIELuv.c:166-197 */

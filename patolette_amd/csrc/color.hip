@@ -168,6 +168,15 @@ void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned 
     HIP_CHECK(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void k_pow(const double *__restrict__ x, double y, double *__restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = pamd_pow(x[i], y);
+}
+void launch_pow(const double *x, double y, double *out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_pow, stream_grid(n), 256, 0, s, x, y, out, n);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_weight_stats(const double *w, size_t n, ConvertStats *stats, hipStream_t s) {
     KTIME("k_weight_stats", s, 8.0 * n);
     hipLaunchKernelGGL(k_weight_stats, stream_grid(n), 256, 0, s, w, n, stats);

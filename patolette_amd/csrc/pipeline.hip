@@ -32,6 +32,7 @@ void launch_convert_u8(int which, const unsigned char *pixels, int channels, dou
 void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned char *pal_u8, int k, unsigned char *out,
                         hipStream_t s);
 void launch_weight_stats(const double *w, size_t n, ConvertStats *stats, hipStream_t s);
+void launch_pow(const double *x, double y, double *out, size_t n, hipStream_t s);
 void launch_fill_image(double *d, size_t n, uint64_t seed, hipStream_t s);
 void launch_fill_weights(double *d, size_t n, uint64_t seed, hipStream_t s);
 
@@ -1189,6 +1190,18 @@ void patolette_amd_batch(size_t count, size_t width, size_t height, const double
     for (size_t t = 1; t < workers; t++) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+}
+
+int patolette_amd_pow(const double *x, double y, double *out, size_t n) {
+    PAMD_GUARD_BEGIN
+    if (n == 0) return 0;
+    E.src.reserve(2 * n);
+    HIP_CHECK(hipMemcpyAsync(E.src.p, x, n * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    launch_pow(E.src.p, y, E.src.p + n, n, E.stream);
+    HIP_CHECK(hipMemcpyAsync(out, E.src.p + n, n * sizeof(double), hipMemcpyDeviceToHost, E.stream));
+    E.sync();
+    return 0;
+    PAMD_GUARD_END(-1)
 }
 
 int patolette_amd_convert(int which, double *planar, size_t n) {

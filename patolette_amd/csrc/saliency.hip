@@ -28,7 +28,7 @@ struct Band { int r0, r1, c0, c1; };             // [r0,r1) x [c0,c1)
 struct Bands { Band b[4]; };
 
 // skimage.color.rgb2lab: sRGB companding, then XYZ (D65, 2 degree) and CIELAB
-__device__ __forceinline__ double lab_compand(double c) { return (c > 0.04045) ? pow((c + 0.055) / 1.055, 2.4) : c / 12.92; }
+__device__ __forceinline__ double lab_compand(double c) { return (c > 0.04045) ? pamd_pow((c + 0.055) / 1.055, 2.4) : c / 12.92; }
 __device__ __forceinline__ void linear_to_lab(const double v[3], double lab[3]) {
     double x = (v[0] * 0.412453 + v[1] * 0.357580) + v[2] * 0.180423;
     double y = (v[0] * 0.212671 + v[1] * 0.715160) + v[2] * 0.072169;

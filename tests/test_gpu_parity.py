@@ -280,3 +280,33 @@ def test_u8_adaptor_equals_by_hand_steps(gpu, ob, channels, K, dither, cs):
     ok5, pal8c, pm5, q5, _, _ = p.quantize_u8(img, K, color_space=cs, tile_size=0, kmeans_niter=3, kmeans_max_samples=4096,
                                               dither=dither, weights=wts, want_quantized=False)
     assert ok5 and q5 is None and np.array_equal(pal8c, pal8) and np.array_equal(pm5, pmap)
+
+
+@pytest.mark.parametrize("y", [2.4, 1 / 2.4, 0.1593017578125, 78.84375, 1 / 0.1593017578125, 1 / 78.84375, 1.0 / 3.0, 3.0])
+def test_device_pow_within_one_ulp_of_libm(gpu, native, y):
+    """The conversions' pow(): never more than one ulp from the host libm (correctly rounded in practice), >= 99 % identical."""
+    rng = np.random.default_rng(3)
+    n = 400000
+    u = rng.random(n)
+    x = np.concatenate([u[: n // 4], np.exp((u[n // 4: n // 2] - 0.6) * 20), 0.5 + u[n // 2: 3 * n // 4], u[3 * n // 4:] * 1e4,
+                        [0.0, 1.0, 2.0, 0.5, 1e-300, 4e-320, 1e300]])
+    out = np.zeros_like(x)
+    assert native.lib().patolette_amd_pow(_d(x), y, _d(out), x.size) == 0
+    import math
+
+    def libm_pow(v):                                           # glibc's scalar pow (numpy's vectorised power is ~1 ulp)
+        try:
+            return math.pow(v, y)
+        except OverflowError:
+            return math.inf
+    want = np.array([libm_pow(v) for v in x])
+    d = np.abs(out.view(np.int64) - want.view(np.int64))
+    finite = np.isfinite(want) & (np.abs(want) > 1e-300)       # gradual underflow: not compared bit for bit
+    assert d[finite].max() <= 1
+    assert np.mean(d[finite] == 0) >= 0.99
+    big = ~np.isfinite(want)
+    assert np.array_equal(out[big], want[big])
+    neg = np.array([-1.0, -0.25, np.nan])
+    o2 = np.zeros(3)
+    native.lib().patolette_amd_pow(_d(neg), y, _d(o2), 3)
+    assert np.all(np.isnan(o2)) or float(y).is_integer()
