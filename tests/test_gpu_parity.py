@@ -4,7 +4,8 @@ Every test here needs a real MI355X.  Sizes are chosen so the oracle finishes in
 full BASELINE sizes are covered by size-independent properties in test_gpu_properties.py.
 Bars: bit-exact for indices (NN map, dither, KMeans assignment -> centroids bit-exact in
 f32); 1e-9 relative for f64 palette centres (north_star asks 1e-5); colour conversions
-within 1e-12 of the reference arithmetic (device pow is not correctly rounded).
+within 1e-12 of the reference arithmetic and >= 98 % bit-identical (device pow is <= 0.51 ulp, not correctly
+rounded).
 """
 import ctypes as C
 
@@ -43,7 +44,9 @@ def test_convert_matches_oracle(gpu, ob, name):
     assert gpu.patolette_amd_convert(CONV_ID[name], _d(got), n) == 0
     scale = max(1.0, float(np.max(np.abs(want))))
     assert np.max(np.abs(got - want)) <= 1e-12 * scale
-    assert np.mean(got == want) > 0.2            # many values are bit-equal; the rest differ by pow ulps
+    frac = float(np.mean(got == want))
+    print("bit-equal fraction %s: %.4f" % (name, frac))
+    assert frac > 0.98                           # measured 0.987-0.9985: the rest are last-ulp neighbours from pow / cbrt
 
 
 def test_convert_reference_golden_edges(gpu):
