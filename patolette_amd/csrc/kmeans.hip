@@ -170,6 +170,199 @@ __global__ __launch_bounds__(256) void k_km_rowscan(unsigned int *table, int nch
     if (threadIdx.x == 0) rowtot[blockIdx.x] = carry;
 }
 
+// --------------------------------------------------------------------------------------------
+// Exact candidate pruning for the assignment when many samples are clustered (kmeans_max_samples large).
+// Brute force costs 256 x 8 instructions per sample.  A G^3 grid over the samples' bounding box stores, per cell, the
+// centroids that can win anywhere in the cell: mindist^2(cell, c_j) <= min_k maxdist^2(cell, c_k) + M, where M covers
+// four times the worst rounding error of the f32 expression the reference evaluates (|computed - true| <=
+// 16 * 2^-24 * (|x| + |c|)^2), so every centroid whose COMPUTED distance can equal or beat the winner's is in the list.
+// The survivors go through exactly the arithmetic of km_assign_one: the list is ordered by (j mod 8, j), i.e. by the
+// SIMD lane the AVX2 kernel would have held them in, each lane's strict-'<' minimum is taken in ascending j, the lanes
+// are merged with the (distance, index) rule, then the scalar leftovers (j >= 8*(k/8)) follow.  Centroids not in the
+// list lose every comparison they would take part in, so dropping them does not change the result.  Cells with more
+// than 15 candidates fall back to the full scan.  Rebuilt every iteration (the centroids move).
+// --------------------------------------------------------------------------------------------
+struct KmGridDev { float lo[3], hi[3]; };
+
+__device__ __forceinline__ unsigned f32_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+constexpr int kKmSlots = 32;
+__global__ __launch_bounds__(256) void k_km_bounds(KmSamples s, size_t nx, unsigned int *keys /* [kKmSlots][6] */) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride) {
+        const float v[3] = {s.x[i], s.y[i], s.z[i]};
+#pragma unroll
+        for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], v[a]); mx[a] = fmaxf(mx[a], v[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float lo = mn[a], hi = mx[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_down(lo, o, 64)); hi = fmaxf(hi, __shfl_down(hi, o, 64)); }
+        if ((threadIdx.x & 63) == 0 && lo <= hi) {
+            unsigned int *k6 = keys + (blockIdx.x & (kKmSlots - 1)) * 6;
+            atomicMin(&k6[a], f32_key(lo)); atomicMax(&k6[3 + a], f32_key(hi));
+        }
+    }
+}
+__global__ void k_km_bounds_init(unsigned int *keys) {
+    const int t = threadIdx.x;
+    if (t < kKmSlots * 6) keys[t] = (t % 6) < 3 ? 0xFFFFFFFFu : 0u;
+}
+__global__ void k_km_bounds_fold(const unsigned int *keys, KmGridDev *g) {
+    const int a = threadIdx.x;
+    if (a >= 3) return;
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (int sl = 0; sl < kKmSlots; sl++) { lo = min(lo, keys[sl * 6 + a]); hi = max(hi, keys[sl * 6 + 3 + a]); }
+    g->lo[a] = key_f32(lo); g->hi[a] = key_f32(hi);
+}
+
+__device__ __forceinline__ int km_cell(float x0, float x1, float x2, const KmGridDev &g, int G) {
+    int idx[3];
+    const float v[3] = {x0, x1, x2};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double r = (double)g.hi[a] - (double)g.lo[a];
+        const double inv = r > 0 ? (double)G / r : 0.0;
+        int q = (int)(((double)v[a] - (double)g.lo[a]) * inv);
+        idx[a] = q < 0 ? 0 : (q >= G ? G - 1 : q);
+    }
+    return (idx[2] * G + idx[1]) * G + idx[0];
+}
+
+__global__ __launch_bounds__(256) void k_km_lut_build(const float4 *__restrict__ c4, int k, const KmGridDev *__restrict__ gp, int G,
+                                                      unsigned char *__restrict__ lut) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= G * G * G) return;
+    const KmGridDev g = *gp;
+    const int idx[3] = {cell % G, (cell / G) % G, cell / (G * G)};
+    double cl[3], ch[3], cellnorm2 = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double r = (double)g.hi[a] - (double)g.lo[a], cw = r / G, m = 1e-9 * r + 1e-30;
+        cl[a] = (double)g.lo[a] + idx[a] * cw - m;
+        ch[a] = (double)g.lo[a] + (idx[a] + 1) * cw + m;
+        const double f = fmax(fabs(cl[a]), fabs(ch[a]));
+        cellnorm2 += f * f;
+    }
+    double U = INFINITY, cn2 = 0;
+    for (int j = 0; j < k; j++) {
+        const float4 y = c4[j];
+        const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
+        double mx = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - cl[a]), fabs(p[a] - ch[a])); mx += d * d; }
+        U = fmin(U, mx);
+        cn2 = fmax(cn2, (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+    }
+    const double rr = sqrt(cellnorm2) + sqrt(cn2);
+    const double thr = U * (1.0 + 1e-12) + 4.0 * (16.0 * 0x1.0p-24) * rr * rr + 1e-300;
+    unsigned char rec[16];
+    int cnt = 0;
+    const int ny_p = (k / 8) * 8;
+    auto test = [&](int j) {
+        const float4 y = c4[j];
+        const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
+        double mn = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0); mn += d * d; }
+        if (mn <= thr) { if (cnt < 15) rec[1 + cnt] = (unsigned char)j; cnt++; }
+    };
+    for (int l = 0; l < 8; l++) for (int j = l; j < ny_p; j += 8) test(j);      // ordered by SIMD lane, then index
+    for (int j = ny_p; j < k; j++) test(j);                                     // scalar leftovers last
+    rec[0] = (unsigned char)(cnt <= 15 ? cnt : 255);
+    for (int t = cnt < 15 ? cnt + 1 : 16; t < 16; t++) rec[t] = 0;
+    uint4 out;
+    out.x = rec[0] | (rec[1] << 8) | (rec[2] << 16) | ((unsigned)rec[3] << 24);
+    out.y = rec[4] | (rec[5] << 8) | (rec[6] << 16) | ((unsigned)rec[7] << 24);
+    out.z = rec[8] | (rec[9] << 8) | (rec[10] << 16) | ((unsigned)rec[11] << 24);
+    out.w = rec[12] | (rec[13] << 8) | (rec[14] << 16) | ((unsigned)rec[15] << 24);
+    reinterpret_cast<uint4 *>(lut)[cell] = out;
+}
+
+__device__ __forceinline__ int km_assign_pruned(const float x0, const float x1, const float x2, const float4 *c4, const int k, const uint4 rec) {
+    unsigned long long w0 = ((unsigned long long)rec.y << 32) | rec.x, w1 = ((unsigned long long)rec.w << 32) | rec.z;
+    const int cnt = (int)(w0 & 0xffULL);
+    if (cnt == 255) return km_assign_one(x0, x1, x2, c4, k);
+    w0 >>= 8;
+    int left = 7;
+    const float m0 = -2 * x0, m1 = -2 * x1, m2 = -2 * x2;
+    const float xn = __builtin_fmaf(x2, x2, __builtin_fmaf(x0, x0, x1 * x1));
+    const int ny_p = (k / 8) * 8;
+    float cur_d = 3.402823466e+38F; unsigned cur_i = 0xFFFFFFFFu;
+    int curl = -1;
+    float trd = 0.f; unsigned tri = 0u;
+    auto merge = [&]() {
+        float cand = trd + xn;
+        if (cand < 0) cand = 0;
+        if (cur_d > cand) { cur_d = cand; cur_i = tri; }
+        else if (cur_d == cand && cur_i > tri) cur_i = tri;
+    };
+    for (int t = 0; t < cnt; t++) {
+        const int j = (int)(w0 & 0xffULL);
+        w0 >>= 8;
+        if (--left == 0) { w0 = w1; left = 8; }
+        const float4 y = c4[j];
+        if (j < ny_p) {
+            const int l = j & 7;
+            if (l != curl) {
+                if (curl >= 0) merge();
+                curl = l; trd = 3.402823466e+38F - xn; tri = 0u;
+            }
+            float dp = m0 * y.x;
+            dp = __builtin_fmaf(m1, y.y, dp);
+            dp = __builtin_fmaf(m2, y.z, dp);
+            dp = dp + y.w;
+            if (dp < trd) { trd = dp; tri = (unsigned)j; }
+        } else {
+            if (curl >= 0) { merge(); curl = -1; }
+            float dp = __builtin_fmaf(x2, y.z, __builtin_fmaf(x1, y.y, x0 * y.x));     // simdlib_based.cpp:201-216
+            float d = xn + y.w - 2 * dp;
+            if (d < 0) d = 0;
+            if (cur_d > d) { cur_d = d; cur_i = (unsigned)j; }
+        }
+    }
+    if (curl >= 0) merge();
+    return (int)cur_i;
+}
+
+__global__ __launch_bounds__(256) void k_km_assign_lut(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, int nbits,
+                                                       int chunk_len, int nchunks, int *__restrict__ assign, unsigned int *table,
+                                                       const KmGridDev *__restrict__ gp, int G, const unsigned char *__restrict__ lut) {
+    extern __shared__ unsigned int lds_u[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float4 *lc4 = (float4 *)lds_u;
+    unsigned int *cnt = lds_u + 4 * (size_t)k + (size_t)wid * k;
+    for (int j = threadIdx.x; j < k; j += 256) lc4[j] = c4[j];
+    for (int j = lane; j < k; j += 64) cnt[j] = 0u;
+    __syncthreads();
+    const KmGridDev g = *gp;
+    const int chunk = blockIdx.x * 4 + wid;
+    if (chunk >= nchunks) return;
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
+    for (size_t base = lo; base < hi; base += 64) {
+        const size_t i = base + lane;
+        const bool v = i < hi;
+        int a = 0;
+        if (v) {
+            const float x0 = s.x[i], x1 = s.y[i], x2 = s.z[i];
+            const uint4 rec = reinterpret_cast<const uint4 *>(lut)[km_cell(x0, x1, x2, g, G)];
+            a = km_assign_pruned(x0, x1, x2, lc4, k, rec);
+            assign[i] = a;
+        }
+        const unsigned long long valid = __ballot(v);
+        const unsigned long long m = match_mask(a, nbits, valid);
+        if (v && (m & ((1ULL << lane) - 1ULL)) == 0ULL) cnt[a] += (unsigned)__popcll(m);   // group leader; distinct addresses
+    }
+    for (int j = lane; j < k; j += 64) table[(size_t)j * nchunks + chunk] = cnt[j];
+}
+
 // second half of the sort: samples -> (x,y,z,w) records grouped by centroid, sample order kept
 template <bool W>
 __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__restrict__ assign, size_t nx, int k, int nbits,
@@ -195,10 +388,15 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__re
         unsigned run = pre + inc - sum;
         for (int j = j0; j < j1; j++) { rowbase[j] = run; run += rowtot[j]; }
     }
-    for (int j = lane; j < k; j += 64) cnt[j] = 0u;
     __syncthreads();
     const int chunk = blockIdx.x * 4 + wid;
     if (chunk >= nchunks) return;
+    // next free slot of every centroid for THIS chunk: row base + what earlier chunks hold (one strided read of the
+    // count table per chunk instead of one random read per sample)
+    // (only when a chunk holds more samples than there are centroids; short chunks read their few entries directly)
+    const bool prebase = chunk_len >= 2 * k;
+    if (prebase) { for (int j = lane; j < k; j += 64) cnt[j] = rowbase[j] + table[(size_t)j * nchunks + chunk]; }
+    else { for (int j = lane; j < k; j += 64) cnt[j] = 0u; }
     const size_t lo = (size_t)chunk * chunk_len;
     const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
     const unsigned long long lt = (1ULL << lane) - 1ULL;
@@ -212,7 +410,7 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__re
         if (v) run = cnt[a];                                       // read before the leader bumps it
         const unsigned r = (unsigned)__popcll(m & lt);
         if (v) {
-            const size_t dst = (size_t)rowbase[a] + table[(size_t)a * nchunks + chunk] + run + r;
+            const size_t dst = prebase ? (size_t)run + r : (size_t)rowbase[a] + table[(size_t)a * nchunks + chunk] + run + r;
             float w = 1.0f;
             if constexpr (W) w = s.w[i];
             sorted[dst] = make_float4(s.x[i], s.y[i], s.z[i], w);
@@ -433,8 +631,29 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         attr = true;
     }
     { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (k + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p); }
+    // many samples: exact candidate pruning (the grid is rebuilt per iteration, ~0.1 ms, against ~1 ms of full scans per
+    // 16 M samples); few samples (the default 512^2): the full scan is cheaper than building the grid
+    const size_t lut_min = getenv("PAMD_KM_LUT_MIN") ? (size_t)atoll(getenv("PAMD_KM_LUT_MIN")) : ((size_t)1 << 21);
+    const bool use_lut = nx >= lut_min && k >= 16 && k <= 256;
+    const int G = nx >= ((size_t)1 << 23) ? 64 : 32;
+    if (use_lut) {
+        static bool attr2 = false;
+        if (!attr2) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_lut, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
+            attr2 = true;
+        }
+        w.lut.reserve((size_t)G * G * G * 16); w.bkeys.reserve(kKmSlots * 6); w.grid.reserve(sizeof(KmGridDev));
+        hipLaunchKernelGGL(k_km_bounds_init, 1, 256, 0, s, w.bkeys.p);
+        { KTIME("k_km_bounds", s, 12.0 * nx); hipLaunchKernelGGL(k_km_bounds, (int)std::min<size_t>(ceil_div(nx, 256), 2048), 256, 0, s, ks, nx, w.bkeys.p); }
+        hipLaunchKernelGGL(k_km_bounds_fold, 1, 64, 0, s, w.bkeys.p, (KmGridDev *)w.grid.p);
+    }
     for (int it = 0; it < niter; it++) {
-        {
+        if (use_lut) {
+            { KTIME("k_km_lut_build", s, 16.0 * G * G * G); hipLaunchKernelGGL(k_km_lut_build, (G * G * G + 255) / 256, 256, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, w.lut.p); }
+            KTIME("k_km_assign", s, 16.0 * nx);
+            hipLaunchKernelGGL(k_km_assign_lut, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p,
+                               (const KmGridDev *)w.grid.p, G, w.lut.p);
+        } else {
             KTIME("k_km_assign", s, 16.0 * nx);
             hipLaunchKernelGGL(k_km_assign_count, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p);
         }

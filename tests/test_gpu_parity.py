@@ -96,7 +96,12 @@ def test_quantize_clusters_matches_oracle(gpu, ob, case):
     assert np.allclose(got, ref, rtol=0, atol=1e-9 * scale, equal_nan=True), np.nanmax(np.abs(got - ref))
 
 
-def test_kmeans_bit_exact_vs_reference_faiss_golden(gpu):
+@pytest.mark.parametrize("pruned", [False, True])
+def test_kmeans_bit_exact_vs_reference_faiss_golden(gpu, monkeypatch, pruned):
+    """Centroids bit-identical to the reference's faiss; `pruned` forces the grid-pruned assignment (normally used
+    from 2 M samples on) onto these small cases (k < 16 keeps the full scan)."""
+    if pruned:
+        monkeypatch.setenv("PAMD_KM_LUT_MIN", "1")
     g = golden("kmeans_ref.npz")
     for ci, (n, k, niter, max_samples, weighted, seed, plant) in enumerate(g["cases"]):
         n, k = int(n), int(k)
@@ -107,6 +112,22 @@ def test_kmeans_bit_exact_vs_reference_faiss_golden(gpu):
         ref = g["cent_%d" % ci]
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "case %d: %d floats differ" % (
             ci, int(np.sum(got.view(np.uint32) != ref.view(np.uint32))))
+
+
+@pytest.mark.parametrize("cs,k,weighted", [("srgb_to_ictcp", 256, False), ("srgb_to_cieluv", 200, True), ("srgb_to_ictcp", 61, False)])
+def test_kmeans_pruned_assignment_many_samples(gpu, ob, cs, k, weighted):
+    """2.2 M samples, all clustered: the grid-pruned assignment (automatic at this size) against the oracle's full scans."""
+    n = 2200000
+    flat = ob.convert(cs, ob.image(n, 31))
+    w = ob.weights(n, 31) if weighted else None
+    rng = np.random.default_rng(k)
+    cent = flat.reshape(3, n).T[rng.choice(n, size=k, replace=False)].copy()
+    cent[5] = cent[9]                                       # duplicate centroid: distance ties, one cluster starves
+    want = ob.kmeans_refine(flat, w, n, cent, 2, n)
+    c = np.ascontiguousarray(cent.T).reshape(-1).copy()
+    assert gpu.patolette_amd_kmeans_refine(_d(flat), _d(w), n, _d(c), k, 2, n) == 0
+    got = c.reshape(3, k).T
+    assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
 
 
 def test_nn_map_bit_exact(gpu, ob):
