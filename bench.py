@@ -7,7 +7,7 @@ image whose f64 planar pixels are ALREADY RESIDENT IN HBM when the timed region 
 `value`).  Default workload = the configuration the metric is quoted on ("256-color ICtCp +
 KMeans"): BASELINE.json configs[2], 4096x4096, K=256, ICtCp, KMeans 32 it / 512^2 samples, dither off.
 
-  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3full|c3sal|c4|c4map] [--no-cpu-baseline]
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c3full|c3sal|c4|c4map|c4km] [--no-cpu-baseline]
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); images are independent, so the
 ranks shard the batch with NO data-path collective ("scaling": "weak": every rank quantises its own
@@ -34,6 +34,7 @@ CONFIGS = {
     "c3full": (4096, 4096, 256, 2, 32, 4096 * 4096, False, False, "configs[2] stress: as c3 but kmeans_max_samples = N (all pixels clustered)"),
     "c4": (8192, 8192, 256, 1, 0, 512 ** 2, True, True, "BASELINE configs[3]: 8192x8192, 256 colors, CIELuv + weights + Riemersma dither"),
     "c4map": (8192, 8192, 256, 1, 0, 512 ** 2, False, True, "configs[3] without dither: 8192x8192, 256 colors, CIELuv + weights, NN map"),
+    "c4km": (8192, 8192, 256, 2, 8, 8192 * 8192, False, False, "67 MP, 256 colors, ICtCp, KMeans over all 67 M pixels (8 it), NN map: the north-star kernels at full size"),
     # the Python binding's default weighting: 8-bit image in HBM, saliency weights (tile_size 512) derived on the device
     "c3sal": (4096, 4096, 256, 2, 32, 512 ** 2, False, "saliency", "configs[2] + saliency weights (tile_size 512) from an 8-bit image resident in HBM"),
 }
