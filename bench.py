@@ -292,7 +292,7 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         from oracle import binding as ob
-        sw, sh = (2048, 1536) if n > 2048 * 1536 else (width, height)
+        sw, sh = (4096, 2048) if n > 4096 * 2048 else (width, height)      # ~10 s of single-core work for the C3 workload
         if dither and n > 1024 * 1024:
             sw, sh = 1024, 1024
         sn = sw * sh

@@ -58,6 +58,13 @@ void patolette_amd_quantize(size_t width, size_t height, const double *data, con
                             double tile_size, size_t palette_size,
                             const patolette__QuantizationOptions *options, double *palette,
                             size_t *palette_map, int *exit_code);
+/* The same with the colours as (width*height, 3) ROW-MAJOR f64 -- the layout of `img.reshape(-1, 3)` in numpy
+ * (README.md:156) -- so a binding need not transpose into the planar layout patolette() takes
+ * (np.asfortranarray at patolette.pyx:388-391 costs ~60 ms on a 16 MP image, six times the device time). */
+void patolette_amd_quantize_rows(size_t width, size_t height, const double *rows, const double *weights,
+                                 double tile_size, size_t palette_size,
+                                 const patolette__QuantizationOptions *options, double *palette,
+                                 size_t *palette_map, int *exit_code);
 /* the stage alone, host buffers: data as for patolette(); weights_out[width*height].  Returns 0,
  * -1 (HIP error), -2 (shape), -3 (singular covariance). */
 int patolette_amd_saliency_weights(size_t width, size_t height, const double *data, double tile_size,

@@ -72,7 +72,13 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
 
     opts = _native.QuantizationOptions(bool(dither), bool(palette_only), int(color_space), int(kmeans_niter),
                                        int(kmeans_max_samples), bool(verbose))
-    data = np.asfortranarray(colors, dtype=np.float64)           # planar R|G|B copy (patolette.pyx:388-391)
+    # The reference transposes into planar R|G|B here (np.asfortranarray, patolette.pyx:388-391): ~60 ms for 16 MP.
+    # An F-ordered float64 array goes to the planar entry as is; anything else is handed over row-major (at most a
+    # dtype cast) and the first kernel reads it with stride 3.
+    if colors.dtype == np.float64 and colors.flags.f_contiguous and not colors.flags.c_contiguous:
+        data, entry = colors, "patolette_amd_quantize"
+    else:
+        data, entry = np.ascontiguousarray(colors, dtype=np.float64), "patolette_amd_quantize_rows"
     palette = np.zeros((palette_size, 3), dtype=np.float64, order='F')
     palette_map = None
     if not opts.palette_only:
@@ -80,7 +86,7 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
     exit_code = C.c_int(0)
     L = _native.lib()
     # tile_size > 0 and no explicit weights: saliency weights derived on the device (patolette.pyx:407-414)
-    L.patolette_amd_quantize(width, height, _dp(data), _dp(w), float(tile_size), palette_size, C.byref(opts), _dp(palette),
+    getattr(L, entry)(width, height, _dp(data), _dp(w), float(tile_size), palette_size, C.byref(opts), _dp(palette),
                              palette_map.ctypes.data_as(_native.zp) if palette_map is not None and palette_map.size > 0 else None,
                              C.byref(exit_code))
     success = exit_code.value == 0

@@ -52,6 +52,8 @@ SYMBOLS = {
                                     C.POINTER(QuantizationOptions), dp, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "patolette_amd_quantize": (None, [C.c_size_t, C.c_size_t, dp, dp, C.c_double, C.c_size_t, C.POINTER(QuantizationOptions), dp, zp,
                                       C.POINTER(C.c_int)]),
+    "patolette_amd_quantize_rows": (None, [C.c_size_t, C.c_size_t, dp, dp, C.c_double, C.c_size_t, C.POINTER(QuantizationOptions), dp,
+                                           zp, C.POINTER(C.c_int)]),
     "patolette_amd_saliency_weights": (C.c_int, [C.c_size_t, C.c_size_t, dp, C.c_double, dp]),
     "patolette_amd_mbd": (C.c_int, [C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]),
     "patolette_amd_u8": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, dp, C.c_double, C.c_size_t,

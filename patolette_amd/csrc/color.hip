@@ -115,6 +115,20 @@ void launch_convert(int which, const double *src_p, double *dst, size_t n, Conve
     HIP_CHECK(hipGetLastError());
 }
 
+void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
+    int g = stream_grid(n);
+    KTIME("k_convert", s, 48.0 * n);
+    const SrcF64Rows src{rows};
+    switch (which) {
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats); break;
+        default: throw HipError("patolette_amd: unknown conversion");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
                        hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);

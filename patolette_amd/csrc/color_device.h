@@ -171,6 +171,10 @@ struct SrcF64 {
     const double *p; size_t n;
     __device__ __forceinline__ void load(size_t i, double c[3]) const { c[0] = p[i]; c[1] = p[n + i]; c[2] = p[2 * n + i]; }
 };
+struct SrcF64Rows {                  // (N,3) row-major f64: what numpy hands over without a transpose
+    const double *p;
+    __device__ __forceinline__ void load(size_t i, double c[3]) const { c[0] = p[3 * i]; c[1] = p[3 * i + 1]; c[2] = p[3 * i + 2]; }
+};
 struct SrcU8 {
     const unsigned char *p; int ch;
     __device__ __forceinline__ void load_bytes(size_t i, unsigned &r, unsigned &g, unsigned &b) const {

@@ -27,6 +27,7 @@ namespace pamd {
 
 // launchers defined in color.hip
 void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s);
+void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s);
 void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
                        hipStream_t s);
 void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned char *pal_u8, int k, unsigned char *out,
@@ -692,6 +693,7 @@ struct Pixels {                      // device-resident input image: planar f64 
     const double *f64 = nullptr;
     const unsigned char *u8 = nullptr;
     int channels = 3;
+    bool rows = false;               // f64 as (N,3) row-major instead of planar
 };
 
 static void run_device(Engine &E, size_t width, size_t height, Pixels px, const double *d_weights, size_t K,
@@ -710,6 +712,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     if (opt->color_space == patolette__CIELuv) which = PAMD_SRGB_TO_CIELUV;
     else if (opt->color_space == patolette__ICtCp) which = PAMD_SRGB_TO_ICTCP;
     if (px.u8) launch_convert_u8(which, px.u8, px.channels, E.cvt.p, N, E.cstats.p, s);
+    else if (px.rows) launch_convert_rows(which, px.f64, E.cvt.p, N, E.cstats.p, s);
     else launch_convert(which, px.f64, E.cvt.p, N, E.cstats.p, s);
     if (weighted) {
         HIP_CHECK(hipMemcpyAsync(E.cvt.p + 3 * N, d_weights, N * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -809,7 +812,7 @@ static int map_elem_for(size_t K) { return K <= 256 ? 1 : 4; }
 
 // host-buffer entry: upload, run, download + widen
 static void run_host(Engine &E, size_t width, size_t height, const double *data, const double *weights, double tile_size,
-                     size_t K, const patolette__QuantizationOptions *opt, double *palette, size_t *palette_map) {
+                     size_t K, const patolette__QuantizationOptions *opt, double *palette, size_t *palette_map, bool rows = false) {
     const size_t N = width * height;
     double t0 = now_ms();
     E.src.reserve(3 * N);
@@ -822,11 +825,11 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     const double up = now_ms() - t0;
     const double *d_w = weights ? E.wsrc.p : nullptr;
     E.ms_saliency = 0.0;
-    if (!weights && tile_size > 0.0) d_w = derive_weights(E, E.src.p, nullptr, 3, width, height, tile_size);
+    if (!weights && tile_size > 0.0) d_w = derive_weights(E, E.src.p, nullptr, rows ? -3 : 3, width, height, tile_size);
     const int me = map_elem_for(K);
     if (!opt->palette_only) E.dmap.reserve(N * (size_t)me);
     std::vector<double> pal(3 * K);
-    run_device(E, width, height, Pixels{E.src.p, nullptr, 3}, d_w, K, opt, pal.data(), E.dmap.p, me);
+    run_device(E, width, height, Pixels{E.src.p, nullptr, 3, rows}, d_w, K, opt, pal.data(), E.dmap.p, me);
     E.stats.ms_saliency = E.ms_saliency;
     E.stats.ms_total += E.ms_saliency;
     t0 = now_ms();
@@ -994,6 +997,26 @@ void patolette_amd_quantize(size_t width, size_t height, const double *data, con
         Engine &E = engine();
         E.init();
         run_host(E, width, height, data, weights, tile_size, palette_size, options, palette, palette_map);
+        *exit_code = 0;
+    } catch (const CodeError &ex) {
+        engine().last_error = ex.what();
+        *exit_code = ex.code;
+    } catch (const std::exception &ex) {
+        engine().last_error = ex.what();
+        fprintf(stderr, "patolette: %s\n", ex.what());
+        *exit_code = -1;
+    }
+}
+
+void patolette_amd_quantize_rows(size_t width, size_t height, const double *rows, const double *weights, double tile_size,
+                                 size_t palette_size, const patolette__QuantizationOptions *options, double *palette,
+                                 size_t *palette_map, int *exit_code) {
+    *exit_code = validate(width, height, palette_size);
+    if (*exit_code != 0) return;
+    try {
+        Engine &E = engine();
+        E.init();
+        run_host(E, width, height, rows, weights, tile_size, palette_size, options, palette, palette_map, true);
         *exit_code = 0;
     } catch (const CodeError &ex) {
         engine().last_error = ex.what();

@@ -33,6 +33,7 @@ constexpr int kSalOk = 0, kSalBadShape = -2, kSalSingular = -3;
 
 // Returns kSalBadShape without touching the device when the reference's get_weights cannot process the
 // shape.  On success d_weights (width*height f64, device) holds 1 + sal^2 * N / tile_size^2.
+// d_f64 planar (channels >= 0) or (N,3) row-major (channels < 0); d_u8 interleaved with `channels` bytes per pixel
 int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8, int channels, size_t width, size_t height,
                      double tile_size, double *d_weights, hipStream_t s);
 

@@ -481,6 +481,7 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     {
         KTIME("k_sal_prepare", s, (d_u8 ? (double)channels : 24.0) * n + 40.0 * n);
         if (d_u8) hipLaunchKernelGGL((k_sal_prepare<SrcU8>), g, 256, 0, s, SrcU8{d_u8, channels}, n, rows, cols, w.st.p + kMbdPad, w.lab.p);
+        else if (channels < 0) hipLaunchKernelGGL((k_sal_prepare<SrcF64Rows>), g, 256, 0, s, SrcF64Rows{d_f64}, n, rows, cols, w.st.p + kMbdPad, w.lab.p);
         else hipLaunchKernelGGL((k_sal_prepare<SrcF64>), g, 256, 0, s, SrcF64{d_f64, n}, n, rows, cols, w.st.p + kMbdPad, w.lab.p);
     }
     // border bands in the reference's order and naming (patolette.pyx:215-219): "left" = first bt rows, "right" = bt rows

@@ -334,3 +334,22 @@ def test_device_pow_within_one_ulp_of_libm(gpu, native, y):
     o2 = np.zeros(3)
     native.lib().patolette_amd_pow(_d(neg), y, _d(o2), 3)
     assert np.all(np.isnan(o2)) or float(y).is_integer()
+
+
+@pytest.mark.parametrize("tile_size", [0, 48])
+def test_row_major_and_planar_inputs_agree(gpu, ob, tile_size):
+    """quantize() hands a C-ordered (N,3) array over row-major and an F-ordered one planar: same results either way."""
+    import patolette_amd as p
+    from tests.util import scene
+    rows, cols, K = 70, 90, 20
+    img = scene(rows, cols, 8)
+    c_order = np.ascontiguousarray(img.reshape(-1, 3))
+    f_order = np.asfortranarray(c_order)
+    assert c_order.flags.c_contiguous and f_order.flags.f_contiguous and not f_order.flags.c_contiguous
+    a = p.quantize(cols, rows, c_order, K, dither=True, color_space=1, tile_size=tile_size, kmeans_niter=3, kmeans_max_samples=4096)
+    b = p.quantize(cols, rows, f_order, K, dither=True, color_space=1, tile_size=tile_size, kmeans_niter=3, kmeans_max_samples=4096)
+    c = p.quantize(cols, rows, c_order.astype(np.float32), K, dither=True, color_space=1, tile_size=tile_size, kmeans_niter=3,
+                   kmeans_max_samples=4096)          # another dtype: cast, then row-major
+    assert a[0] and b[0] and c[0]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert c[1].shape == a[1].shape
