@@ -346,6 +346,31 @@ __device__ __forceinline__ double wave_min_f64(double v) {
     return fmin(fmin(r0, r1), fmin(r2, r3));
 }
 
+// unsigned minimum over the 64 lanes, wave-uniform
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x124>(v));
+    v = min(v, dpp_u32<0x128>(v));
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+// lowest lane holding the minimum of a non-negative double: non-negative doubles order like their bit patterns, so the
+// high words decide (one 32-bit DPP minimum) and the low words only among lanes that tie on the high word
+__device__ __forceinline__ int wave_argmin_nonneg_f64(double v) {
+    const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+    const unsigned mh = wave_min_u32(hi);
+    unsigned long long c = __ballot(hi == mh);
+    if (c & (c - 1)) {                                                   // several lanes share the high word (wave-uniform)
+        const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+        c = __ballot(hi == mh && lo == ml);
+    }
+    return (int)__builtin_ctzll(c);
+}
+
 // One wavefront walks one image.  Lanes 0..2 carry the R,G,B error queues (the 16-term weighted sum is a
 // 16-deep chain per channel, evaluated for the three channels at once); all 64 lanes share the palette for
 // the nearest-colour search: lane L owns the contiguous entries [L*PER, (L+1)*PER), so on equal distance the
@@ -357,6 +382,7 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
     extern __shared__ double lds[];
     double *praw = lds;                                              // [3][k] raw palette
     double *pwt = lds + 3 * k;                                       // [3][k] palette scaled by (float)-cast weights (riemersma.c:419-425)
+    double *spx = lds + 6 * k;                                       // [3][64] channels of the current block of pixels
     const int lane = threadIdx.x;
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
     for (int j = lane; j < k; j += 64)
@@ -412,16 +438,9 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
         }
         const unsigned long long mask = __ballot(inb);
         int myidx = 0;
-        for (int t = 0; t < 64; t++) {
-            if (!((mask >> t) & 1ULL)) continue;                       // wave-uniform
-            // pixel t: its channel `lane` lands in lanes 0..2
-            const double pR = readlane_f64(R, t), pG = readlane_f64(G, t), pB = readlane_f64(B, t);
-            const double pc = lane == 0 ? pR : (lane == 1 ? pG : pB);
-            double e = q[0] * qw[0];                                   // riemersma.c:286-296 (0 + x == x)
-#pragma unroll
-            for (int i = 1; i < 16; i++) e = e + q[i] * qw[i];
-            const double qv = Wc * (pc + e);
-            const double qx = readlane_f64(qv, 0), qy = readlane_f64(qv, 1), qz = readlane_f64(qv, 2);
+        // nearest palette entry of the query (qx, qy, qz): per-lane best of its own entries (ascending index, strict '<'),
+        // then the lowest lane among the wave-wide minima = lowest palette index on ties
+        auto nearest = [&](const double qx, const double qy, const double qz) -> int {
             double bd = INFINITY; int bj = 0;
             if constexpr (PER > 0) {
 #pragma unroll
@@ -440,15 +459,57 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
                     }
                 }
             }
-            const double md = wave_min_f64(bd);
-            const unsigned long long win = __ballot(bd == md);
-            const int wl = __builtin_ctzll(win);                       // lowest lane = lowest palette index among ties
-            const int bi = __builtin_amdgcn_readlane(bj, wl);
-            if (lane == t) myidx = bi;
-            const double chosen = praw[ch * k + bi];
+            return __builtin_amdgcn_readlane(bj, wave_argmin_nonneg_f64(bd));
+        };
+        if (mask == ~0ULL) {
+            // the whole block lies inside the image (all but the edges): the pixels go through LDS so that lane c reads its
+            // channel of pixel t directly, and the 16 steps of a turn of the error queue are unrolled so that the queue is a
+            // ring of registers with compile-time positions (no 15-register shift per pixel)
+            spx[lane] = R; spx[64 + lane] = G; spx[128 + lane] = B;
+            __builtin_amdgcn_wave_barrier();
+            double pc_next = spx[ch * 64];
+            // the newest queue entry (previous pixel minus its chosen colour) is materialised only where the sum needs
+            // it -- as the LAST of the 16 terms -- so the LDS read of the chosen colour is in flight during the other 15
+            double pend_pc = q[15], pend_chosen = 0.0;                   // q[15] - 0: the entry as it stands
+#pragma unroll 1
+            for (int t0 = 0; t0 < 64; t0 += 16) {
 #pragma unroll
-            for (int i = 0; i < 15; i++) q[i] = q[i + 1];
-            q[15] = pc - chosen;                                       // original pixel - chosen colour (riemersma.c:333-340)
+                for (int j = 0; j < 16; j++) {
+                    const int t = t0 + j;
+                    const double pc = pc_next;
+                    pc_next = spx[ch * 64 + ((t + 1) & 63)];            // next pixel's channel, in flight during this step
+                    // ring: at step j the oldest entry sits in q[j], the newest (pending) belongs in q[(j + 15) & 15]
+                    double e = q[j] * qw[0];                            // riemersma.c:286-296 (0 + x == x)
+#pragma unroll
+                    for (int i = 1; i < 15; i++) e = e + q[(i + j) & 15] * qw[i];
+                    const double newest = pend_pc - pend_chosen;         // riemersma.c:333-340
+                    q[(j + 15) & 15] = newest;
+                    e = e + newest * qw[15];
+                    const double qv = Wc * (pc + e);
+                    const int bi = nearest(readlane_f64(qv, 0), readlane_f64(qv, 1), readlane_f64(qv, 2));
+                    if (lane == t) myidx = bi;
+                    pend_pc = pc; pend_chosen = praw[ch * k + bi];
+                }
+            }
+            // 64 steps are four full turns of the ring: q[0] is the oldest entry again, only the pending one is missing
+            q[15] = pend_pc - pend_chosen;
+        } else {
+            for (int t = 0; t < 64; t++) {
+                if (!((mask >> t) & 1ULL)) continue;                       // wave-uniform
+                // pixel t: its channel `lane` lands in lanes 0..2
+                const double pR = readlane_f64(R, t), pG = readlane_f64(G, t), pB = readlane_f64(B, t);
+                const double pc = lane == 0 ? pR : (lane == 1 ? pG : pB);
+                double e = q[0] * qw[0];                                   // riemersma.c:286-296 (0 + x == x)
+#pragma unroll
+                for (int i = 1; i < 16; i++) e = e + q[i] * qw[i];
+                const double qv = Wc * (pc + e);
+                const int bi = nearest(readlane_f64(qv, 0), readlane_f64(qv, 1), readlane_f64(qv, 2));
+                if (lane == t) myidx = bi;
+                const double chosen = praw[ch * k + bi];
+#pragma unroll
+                for (int i = 0; i < 15; i++) q[i] = q[i + 1];
+                q[15] = pc - chosen;                                       // original pixel - chosen colour (riemersma.c:333-340)
+            }
         }
         if (inb) out[(size_t)y * width + x] = (OutT)myidx;
         d0 += 64;
@@ -472,7 +533,7 @@ static void launch_dither_t(const double *d_img, size_t plane_stride, size_t wid
 
 void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
                    void *d_out, int elem_bytes, hipStream_t s) {
-    size_t lds = (size_t)6 * k * sizeof(double);
+    size_t lds = ((size_t)6 * k + 3 * 64) * sizeof(double);      // palette (raw + weighted) + one block of pixels
     if (lds > 150 * 1024) throw HipError("patolette_amd: palette too large for the dither kernel (K <= 3200)");
     DitherWeights wts;
     {
