@@ -1181,7 +1181,19 @@ void patolette_amd_batch(size_t count, size_t width, size_t height, const double
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) { for (size_t i = 0; i < count; i++) exit_codes[i] = -1; return; }
     if (engine().device >= 0) device = engine().device;
-    const size_t workers = std::min<size_t>(count, 3);
+    // Images in flight: three keep the GPU busy through one image's host round trips.  With the Riemersma dither each
+    // image ends in a serial chain that occupies ONE wavefront for seconds, so many more are kept in flight (one chain
+    // per CU runs concurrently), bounded by the free HBM: an engine's workspace is ~170 bytes per pixel.
+    size_t workers = std::min<size_t>(count, 3);
+    if (options->dither && !options->palette_only && count > 3) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipSetDevice(device);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t per_engine = (size_t)(170.0 * (double)width * (double)height) + ((size_t)64 << 20);
+            const size_t fit = free_b / 2 / per_engine;          // leave half of what is free alone
+            workers = std::min<size_t>(count, std::max<size_t>(3, std::min<size_t>(fit, 48)));
+        }
+    }
     std::atomic<size_t> next{0};
     auto work = [&]() {
         Engine *E = nullptr;
