@@ -121,12 +121,15 @@ def saliency_weights(width, height, colors, tile_size=512):
 def quantize_u8(image, palette_size, dither=True, palette_only=False, color_space=ColorSpace_ICtCp, tile_size=512,
                 kmeans_niter=32, kmeans_max_samples=512 ** 2, weights=None, want_quantized=True):
     """8-bit adaptor (additive): `image` is an (H, W, 3|4) uint8 sRGB array as an image
-    decoder returns it.  Does on the GPU what callers of the reference do by hand around `quantize`
+    decoder returns it, or a torch CUDA tensor of that shape (then nothing but the palettes crosses PCIe).  Does on the GPU what callers of the reference do by hand around `quantize`
     (README.md:147-194): `colors = img/255`, `palette_u8 = clip(palette*255).astype(uint8)` and
     `quantized = palette_u8[palette_map]`; 3 bytes per pixel cross PCIe instead of 24.
 
     Returns (success, palette_u8 (K,3) uint8, palette_map (H,W) uint8|uint16|uint32 or None,
     quantized (H,W,3) uint8 or None, palette (K,3) float64 as `quantize` returns it, message)."""
+    if hasattr(image, "data_ptr") and getattr(image, "is_cuda", False):
+        return _quantize_u8_torch(image, palette_size, dither, palette_only, color_space, tile_size, kmeans_niter,
+                                  kmeans_max_samples, weights, want_quantized)
     img = np.ascontiguousarray(image)
     if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] not in (3, 4):
         raise ValueError("image must be an (H, W, 3|4) uint8 array")
@@ -149,6 +152,48 @@ def quantize_u8(image, palette_size, dither=True, palette_only=False, color_spac
     vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size > 0 else None   # noqa: E731
     L.patolette_amd_u8(width, height, vp(img), channels, _dp(w), float(tile_size), palette_size, C.byref(opts), _dp(palette),
                        vp(palette_u8), vp(pmap), np.dtype(map_dtype).itemsize, vp(quant), C.byref(code))
+    message = L.get_patolette_exit_code_info_message(code.value).decode('UTF-8')
+    _raise_saliency(code.value, message)
+    if code.value != 0:
+        return (False, None, None, None, None, message)
+    return (True, palette_u8, pmap, quant, palette, message)
+
+
+def _quantize_u8_torch(image, palette_size, dither, palette_only, color_space, tile_size, kmeans_niter, kmeans_max_samples,
+                       weights, want_quantized):
+    """`quantize_u8` for a torch CUDA uint8 tensor (H, W, 3|4): the image, the index map (uint8 for K <= 256, else int32)
+    and the reconstructed image stay in HBM (`patolette_amd_u8_device`); the palettes come back as numpy arrays.
+    torch is only used to allocate the outputs and to order this call after the producer of `image`.
+    Import torch BEFORE patolette_amd in such a process: both link a HIP runtime with the same SONAME and torch does not
+    initialise on the one this library would otherwise load first."""
+    import torch
+    if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] not in (3, 4):
+        raise ValueError("image must be an (H, W, 3|4) uint8 tensor")
+    img = image.contiguous()
+    height, width, channels = (int(v) for v in img.shape)
+    n = width * height
+    dev = img.device
+    w = None
+    if weights is not None:
+        w = torch.as_tensor(weights, dtype=torch.float64, device=dev).reshape(-1).contiguous()
+        if w.numel() != n:
+            raise ValueError("weights must hold width*height values")
+    opts = _native.QuantizationOptions(bool(dither), bool(palette_only), int(color_space), int(kmeans_niter),
+                                       int(kmeans_max_samples), False)
+    palette = np.zeros((palette_size, 3), dtype=np.float64, order='F')
+    palette_u8 = np.zeros((max(palette_size, 0), 3), dtype=np.uint8)
+    me = 1 if palette_size <= 256 else 4
+    pmap = None if palette_only else torch.zeros((height, width), dtype=torch.uint8 if me == 1 else torch.int32, device=dev)
+    quant = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev) if (want_quantized and not palette_only) else None
+    code = C.c_int(0)
+    L = _native.lib()
+    with torch.cuda.device(dev):
+        torch.cuda.current_stream().synchronize()          # the library runs on its own stream
+        L.patolette_amd_u8_device(width, height, C.c_void_p(img.data_ptr()), channels,
+                                  C.c_void_p(w.data_ptr()) if w is not None else None, float(tile_size), palette_size,
+                                  C.byref(opts), _dp(palette), palette_u8.ctypes.data_as(C.c_void_p),
+                                  C.c_void_p(pmap.data_ptr()) if pmap is not None else None, me,
+                                  C.c_void_p(quant.data_ptr()) if quant is not None else None, C.byref(code))
     message = L.get_patolette_exit_code_info_message(code.value).decode('UTF-8')
     _raise_saliency(code.value, message)
     if code.value != 0:

@@ -353,3 +353,30 @@ def test_row_major_and_planar_inputs_agree(gpu, ob, tile_size):
     assert a[0] and b[0] and c[0]
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert c[1].shape == a[1].shape
+
+
+def test_u8_adaptor_accepts_torch_cuda_tensor(gpu):
+    """A torch CUDA uint8 tensor goes through the device entry point: same results as the numpy path, outputs stay in
+    HBM.  Own process: torch has to load its HIP runtime before libpatolette_amd.so does (as bench.py --gpus N does)."""
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+assert torch.cuda.is_available()
+import patolette_amd as p
+from tests.util import scene
+img = np.round(scene(96, 128, 2) * 255).astype(np.uint8)
+ref = p.quantize_u8(img, 32, dither=False, tile_size=32, kmeans_niter=3, kmeans_max_samples=4096)
+got = p.quantize_u8(torch.from_numpy(img).cuda(), 32, dither=False, tile_size=32, kmeans_niter=3, kmeans_max_samples=4096)
+assert ref[0] and got[0]
+assert got[2].is_cuda and got[3].is_cuda
+assert np.array_equal(got[1], ref[1]) and np.array_equal(got[4], ref[4])
+assert np.array_equal(got[2].cpu().numpy(), ref[2]) and np.array_equal(got[3].cpu().numpy(), ref[3])
+print("TORCH-PATH-OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "TORCH-PATH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
