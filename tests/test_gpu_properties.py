@@ -146,3 +146,38 @@ def test_dither_full_size_prefix_matches_oracle(gpu, ob):
     assert int(visited.sum()) == steps
     assert np.array_equal(got[visited], want[visited])
     assert got.max() < k
+
+
+def test_mbd_full_size_bit_exact(gpu, native, ob):
+    """The three raster scans of the saliency map at 4096x4096 (64 strips pipelined through progress flags): bit for bit
+    the sequential scans of the oracle."""
+    from tests.util import scene
+    rows = cols = 4096
+    img = scene(rows, cols, 7).mean(axis=2).astype(np.float32)
+    out = np.zeros_like(img)
+    fp = C.POINTER(C.c_float)
+    assert native.lib().patolette_amd_mbd(rows, cols, img.ctypes.data_as(fp), 3, out.ctypes.data_as(fp)) == 0
+    want = ob.mbd(img, 3)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_u8_full_size_round_trip(gpu):
+    """8-bit adaptor at 4096x4096 with the default saliency weighting: every output consistent with the others."""
+    import patolette_amd as p
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, size=(4096, 4096, 3), dtype=np.uint8)
+    ok, pal8, pmap, quant, pal, msg = p.quantize_u8(img, 256, dither=False)
+    assert ok and pmap.dtype == np.uint8 and pmap.shape == (4096, 4096)
+    assert np.array_equal(pal8, np.clip(pal * 255, 0, 255).astype(np.uint8))
+    assert np.array_equal(quant, pal8[pmap])
+    assert len(np.unique(pmap)) == 256
+    # the map is the nearest palette entry in ICtCp: spot-check a sample of pixels against a brute-force search
+    from oracle import binding as ob
+    idx = rng.integers(0, 4096 * 4096, size=20000)
+    px = img.reshape(-1, 3)[idx].astype(np.float64) / 255
+    ict = ob.convert("srgb_to_ictcp", ob.planar(px)).reshape(3, -1).T
+    pal_ict = ob.convert("srgb_to_ictcp", ob.planar(pal)).reshape(3, -1).T
+    d = ((ict[:, None, :] - pal_ict[None, :, :]) ** 2).sum(-1)
+    got = pmap.reshape(-1)[idx]
+    best = d.min(1)
+    assert np.all(d[np.arange(len(idx)), got] <= best * (1 + 1e-9) + 1e-18)
