@@ -85,6 +85,8 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
         palette_map = np.zeros(width * height, dtype=np.uintp)
     exit_code = C.c_int(0)
     L = _native.lib()
+    if verbose and tile_size > 0 and w is None:
+        print('patolette ======== Generating saliency map')     # patolette.pyx:408-409
     # tile_size > 0 and no explicit weights: saliency weights derived on the device (patolette.pyx:407-414)
     getattr(L, entry)(width, height, _dp(data), _dp(w), float(tile_size), palette_size, C.byref(opts), _dp(palette),
                              palette_map.ctypes.data_as(_native.zp) if palette_map is not None and palette_map.size > 0 else None,

@@ -721,20 +721,26 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     Bounds bnd = read_bounds(E, weighted);
     E.stats.ms_convert = now_ms() - t0;
 
-    // S2 + S3: global + local quantiser
+    // S2 + S3: global + local quantiser (progress lines as patolette.c:209-229 prints them when verbose)
+    if (opt->verbose) printf("patolette ======== Palette generation \n");
     std::vector<double> pal;
     size_t len = 0;
     if (quantize_clusters(E, N, K, weighted, bnd, pal, len) != 0) throw HipError("internal quantization error");
+    if (opt->verbose) printf("patolette ======== Base cluster count: %zu\n", (size_t)E.stats.n_base_clusters);
 
     // S4: optional KMeans refinement
     t0 = now_ms();
-    if (opt->kmeans_niter > 0) kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples);
+    if (opt->kmeans_niter > 0) {
+        if (opt->verbose) printf("patolette ======== KMeans refinement\n");                // patolette.c:249-251
+        kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples);
+    }
     E.stats.ms_kmeans = now_ms() - t0;
 
     // S5: palette map
     t0 = now_ms();
     if (!opt->palette_only) {
         E.dpal.reserve(3 * len);
+        if (opt->verbose) printf(opt->dither ? "patolette ======== Dithering\n" : "patolette ======== NN mapping\n");
         if (opt->dither) {                                                     // patolette.c:268-299
             int pix = PAMD_SRGB_TO_REC2020;
             void (*pf)(double[3]) = hm::color::srgb_to_rec2020;

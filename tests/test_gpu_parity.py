@@ -380,3 +380,22 @@ print("TORCH-PATH-OK")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "TORCH-PATH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_verbose_prints_the_reference_progress_lines(gpu, ob, capfd):
+    """verbose=True prints the stage lines patolette.c:209-303 / patolette.pyx:409 print (faiss' own chatter excepted)."""
+    import ctypes
+    import patolette_amd as p
+    from tests.util import scene
+    rows, cols = 40, 50
+    colors = scene(rows, cols, 3).reshape(-1, 3)
+    ok, *_ = p.quantize(cols, rows, colors, 8, dither=False, tile_size=16, kmeans_niter=2, kmeans_max_samples=1024, verbose=True)
+    assert ok
+    ctypes.CDLL(None).fflush(None)
+    out = capfd.readouterr().out
+    for line in ("patolette ======== Generating saliency map", "patolette ======== Palette generation ",
+                 "patolette ======== Base cluster count: ", "patolette ======== KMeans refinement", "patolette ======== NN mapping"):
+        assert line in out, (line, out)
+    p.quantize(cols, rows, colors, 8, dither=True, tile_size=0, kmeans_niter=0, verbose=True)
+    ctypes.CDLL(None).fflush(None)
+    assert "patolette ======== Dithering" in capfd.readouterr().out
