@@ -399,3 +399,20 @@ def test_verbose_prints_the_reference_progress_lines(gpu, ob, capfd):
     p.quantize(cols, rows, colors, 8, dither=True, tile_size=0, kmeans_niter=0, verbose=True)
     ctypes.CDLL(None).fflush(None)
     assert "patolette ======== Dithering" in capfd.readouterr().out
+
+
+@pytest.mark.parametrize("rows,cols,K,cs,dither,niter", [(768, 1024, 256, 2, False, 4), (300, 420, 96, 1, True, 2), (512, 512, 17, 0, False, 3)])
+def test_photograph_like_image_end_to_end(gpu, ob, rows, cols, K, cs, dither, niter):
+    """Smooth gradients + flat blobs + mild noise (tight clusters, near-degenerate splits): palette and map against the
+    oracle, the map bit for bit."""
+    import patolette_amd as p
+    from tests.util import scene
+    img = scene(rows, cols, 17)
+    colors = img.reshape(-1, 3)
+    ok, pal, pmap, _ = p.quantize(cols, rows, colors, K, dither=dither, color_space=cs, tile_size=0, kmeans_niter=niter,
+                                  kmeans_max_samples=65536)
+    ec, pal_o, pmap_o = ob.patolette(cols, rows, ob.planar(colors), None, K, dither=dither, color_space=cs, kmeans_niter=niter,
+                                     kmeans_max_samples=65536)
+    assert ok and ec == 0
+    assert np.allclose(pal, pal_o, rtol=0, atol=1e-9)
+    assert np.array_equal(pmap, pmap_o)
