@@ -24,7 +24,8 @@ struct SalWork {
     DevBuf<float> tmp;
     DevBuf<double> lab, s;           // CIELAB planes, running saliency map
     DevBuf<SalDev> dev;
-    DevBuf<unsigned int> progress;   // per-strip progress flags of the raster scans
+    DevBuf<unsigned int> progress;   // per-strip progress flags of the raster scans (+ one stall flag)
+    unsigned int *d_stall = nullptr;
     PinBuf<SalDev> host;
 };
 

@@ -307,6 +307,7 @@ struct MbdArgs {
     float4 *st;                      // first record of the image; kMbdPad readable records before and after it
     int rows, cols;
     unsigned int *progress;
+    unsigned int *stalled;           // set when a strip gave up waiting for the one above it
 };
 
 __device__ __forceinline__ float wave_shr1(float from_above, float v) {
@@ -368,13 +369,18 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
             if (!keep) *q = make_float4(ix, t1 ? b1 : b2, outU, outL);
         }
     };
-    auto chunk_begin = [&](int t0) {
+    auto chunk_begin = [&](int t0) -> bool {                             // true: gave up waiting
         // steps t0 .. t0+kChunk-1 of lane 0 consume scan columns t0 .. t0+kChunk-1 of the row above the strip
-        if (t0 >= Cn) return;
+        if (t0 >= Cn) return false;
         if (strip > 0) {
             const unsigned int need = (unsigned int)min(Cn, t0 + kChunk);
-            while (__hip_atomic_load(&a.progress[strip - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
+            // bounded: the strip above always makes progress when all strips are resident (a few hundred single-wave
+            // blocks), but a spin must never be able to hang the device -- past ~2 s the pass gives up and reports it
+            unsigned spins = 0;
+            while (__hip_atomic_load(&a.progress[strip - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { if (lane == 0) atomicExch(a.stalled, 1u); return true; }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         const int col = t0 + lane;
@@ -382,6 +388,7 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
             const float4 f = above[DIR * col];
             bu = f.z; bl = f.w;
         }
+        return false;
     };
     auto chunk_end = [&](int t) {
         // columns of the strip's last row that are complete and stored after step t
@@ -396,7 +403,10 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
 #pragma unroll
     for (int j = 0; j < kChunk; j++) ring[j] = p[DIR * j];
     for (int t0 = 0; t0 < T; t0 += kChunk) {
-        chunk_begin(t0);
+        if (chunk_begin(t0)) {                                           // let the strips below give up quickly too
+            if (lane == 0) __hip_atomic_store(&a.progress[strip], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         float4 next[kChunk];
         float4 *q = p + DIR * t0;
 #pragma unroll
@@ -439,8 +449,10 @@ __global__ __launch_bounds__(256) void k_mbd_extract(const float4 *__restrict__ 
 // pass p of mbd(img, iters) is the forward scan when p is odd, the inverse scan when p is even (patolette.pyx:180-199)
 static void run_mbd_scans(SalWork &w, int rows, int cols, int iters, hipStream_t s) {
     const int strips_f = (int)ceil_div((size_t)rows - 2, 64), strips_i = (int)ceil_div((size_t)rows - 3, 64);
-    w.progress.reserve((size_t)strips_f);
-    MbdArgs ma{w.st.p + kMbdPad, rows, cols, w.progress.p};
+    w.progress.reserve((size_t)strips_f + 1);                // [strips] progress + [1] stall flag
+    MbdArgs ma{w.st.p + kMbdPad, rows, cols, w.progress.p, w.progress.p + strips_f};
+    w.d_stall = w.progress.p + strips_f;
+    HIP_CHECK(hipMemsetAsync(w.d_stall, 0, sizeof(unsigned int), s));
     for (int pass = 0; pass < iters; pass++) {
         HIP_CHECK(hipMemsetAsync(w.progress.p, 0, sizeof(unsigned int) * (size_t)strips_f, s));
         KTIME("k_mbd_scan", s, 32.0 * rows * cols);
@@ -459,7 +471,10 @@ int mbd_device(SalWork &w, const float *h_img, size_t rows, size_t cols, int ite
     run_mbd_scans(w, (int)rows, (int)cols, iters, s);
     hipLaunchKernelGGL(k_mbd_extract, stream_grid(n), 256, 0, s, w.st.p + kMbdPad, n, w.tmp.p);
     HIP_CHECK(hipMemcpyAsync(h_out, w.tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    unsigned int stalled = 0;
+    HIP_CHECK(hipMemcpyAsync(&stalled, w.d_stall, sizeof stalled, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    if (stalled) throw HipError("patolette_amd: the raster scan gave up waiting for a strip (device oversubscribed?)");
     return kSalOk;
 }
 
@@ -535,7 +550,10 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(w.host.p, w.dev.p, sizeof(SalDev), hipMemcpyDeviceToHost, s));
+    unsigned int stalled = 0;
+    HIP_CHECK(hipMemcpyAsync(&stalled, w.d_stall, sizeof stalled, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    if (stalled) throw HipError("patolette_amd: the raster scan gave up waiting for a strip (device oversubscribed?)");
     if (w.host.p->singular) return kSalSingular;
     return kSalOk;
 }
