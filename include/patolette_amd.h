@@ -2,10 +2,12 @@
  * patolette_amd.h -- additive C-ABI extensions of libpatolette_amd.so (not in the reference).
  *
  * The reference exports one monolithic call (include/patolette.h).  The entry points below
- * expose (1) the same call with inputs already resident in HBM, (2) each stage of the path on
- * its own -- every one names the reference function it replaces -- so parity tests can check
- * the HIP path stage by stage against the oracle, (3) a batch call for independent images,
- * and (4) kernel timing / run statistics for bench.py.  Plain pointers and sizes only.
+ * expose (1) the same call with inputs already resident in HBM, (2) the call with the Python
+ * binding's `tile_size` (saliency-derived weights computed on the device) and with row-major
+ * colours, (3) 8-bit adaptors around it, (4) a batch call for independent images, (5) each
+ * stage of the path on its own -- every one names the reference function it replaces -- so
+ * parity tests can check the HIP path stage by stage against the oracle, and (6) kernel
+ * timing / run statistics for bench.py.  Plain pointers and sizes only.
  */
 #ifndef PATOLETTE_AMD_H
 #define PATOLETTE_AMD_H
