@@ -26,10 +26,11 @@
 namespace pamd {
 
 // launchers defined in color.hip
-void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s);
-void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s);
+void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk = BinK{0.0, 0.0});
+void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s,
+                         BinK sumk = BinK{0.0, 0.0});
 void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
-                       hipStream_t s);
+                       hipStream_t s, BinK sumk = BinK{0.0, 0.0});
 void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned char *pal_u8, int k, unsigned char *out,
                         hipStream_t s);
 void launch_weight_stats(const double *w, size_t n, ConvertStats *stats, hipStream_t s);
@@ -136,7 +137,10 @@ __global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup 
     for (size_t i = tid; i < a.nbk; i += stride) { a.hsize[i] = 0ULL; a.hcount[i] = 0u; }
 }
 
-struct Bounds { double cmax, range, wmax; int e_lin, e_quad; double lo[3], hi[3]; };
+struct Bounds {
+    double cmax, range, wmax; int e_lin, e_quad; double lo[3], hi[3];
+    bool have_sum = false; double sum[3] = {0, 0, 0};        // column sums of the converted image, when the conversion took them
+};
 
 static int exp_bound(double v) {                 // smallest E with 2^E > v (v > 0)
     if (!(v > 0) || !std::isfinite(v)) return 1;
@@ -323,13 +327,16 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     // ---------------- global quantiser (global.c:388-443) ----------------
     // unweighted PCA of all pixels: mean, centred covariance, dsyev
     HNode root; root.begin = 0; root.n = N; root.buf = 0; root.sw = (double)N;
-    int rootP = 1; while ((1ULL << rootP) < (N > 1 ? N : 2)) rootP++;
-    E.sum6.reserve(kSum3Slots * 6);
-    launch_sum3(E.cvt.p, N, make_bink(bnd.e_lin, rootP), E.sum6.p, s);
     E.h_dbl.reserve(16 * kBuckets * 2 + 64);
-    HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.sum6.p, kSum3Slots * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
-    E.sync();
-    {
+    if (bnd.have_sum) {
+        const double inv = 1 / (double)N;                       // matrix2D.c:229; the sums came with the conversion pass
+        for (int j = 0; j < 3; j++) root.mean[j] = bnd.sum[j] * inv;
+    } else {
+        int rootP = 1; while ((1ULL << rootP) < (N > 1 ? N : 2)) rootP++;
+        E.sum6.reserve(kSum3Slots * 6);
+        launch_sum3(E.cvt.p, N, make_bink(bnd.e_lin, rootP), E.sum6.p, s);
+        HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.sum6.p, kSum3Slots * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+        E.sync();
         const double inv = 1 / (double)N;                       // matrix2D.c:229
         for (int j = 0; j < 3; j++) {
             double p0 = 0, p1 = 0;                              // slot partials are exact multiples of the bin grids
@@ -683,6 +690,11 @@ static Bounds read_bounds(Engine &E, bool weighted) {
     const double quad = 3.0 * b.wmax * std::max(std::max(b.range, b.cmax), 1e-300) * std::max(std::max(b.range, b.cmax), 1e-300);
     b.e_lin = exp_bound(lin);
     b.e_quad = exp_bound(std::max(quad, 1e-300));
+    for (int p = 0; p < 3; p++) {                              // slot partials are exact multiples of the bin grids
+        double p0 = 0, p1 = 0;
+        for (int t = 0; t < kStatSlots; t++) { p0 += cs.sum[t][p][0]; p1 += cs.sum[t][p][1]; }
+        b.sum[p] = p0 + p1;
+    }
     return b;
 }
 
@@ -711,14 +723,23 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     int which = PAMD_COPY;
     if (opt->color_space == patolette__CIELuv) which = PAMD_SRGB_TO_CIELUV;
     else if (opt->color_space == patolette__ICtCp) which = PAMD_SRGB_TO_ICTCP;
-    if (px.u8) launch_convert_u8(which, px.u8, px.channels, E.cvt.p, N, E.cstats.p, s);
-    else if (px.rows) launch_convert_rows(which, px.f64, E.cvt.p, N, E.cstats.p, s);
-    else launch_convert(which, px.f64, E.cvt.p, N, E.cstats.p, s);
+    // the root mean of the global quantiser (matrix2D.c:229) rides along with the conversion where the colour space bounds
+    // the values a priori: |I| <= 1, |Ct|, |Cp| <= 0.5 (2^1); L <= 100, |u|, |v| < 256 (2^8).  sRGB passes user data through.
+    BinK sumk{0.0, 0.0};
+    {
+        int rootP = 1; while ((1ULL << rootP) < (N > 1 ? N : 2)) rootP++;
+        if (which == PAMD_SRGB_TO_ICTCP) sumk = make_bink(1, rootP);
+        else if (which == PAMD_SRGB_TO_CIELUV) sumk = make_bink(8, rootP);
+    }
+    if (px.u8) launch_convert_u8(which, px.u8, px.channels, E.cvt.p, N, E.cstats.p, s, sumk);
+    else if (px.rows) launch_convert_rows(which, px.f64, E.cvt.p, N, E.cstats.p, s, sumk);
+    else launch_convert(which, px.f64, E.cvt.p, N, E.cstats.p, s, sumk);
     if (weighted) {
         HIP_CHECK(hipMemcpyAsync(E.cvt.p + 3 * N, d_weights, N * sizeof(double), hipMemcpyDeviceToDevice, s));
         launch_weight_stats(d_weights, N, E.cstats.p, s);
     }
     Bounds bnd = read_bounds(E, weighted);
+    bnd.have_sum = sumk.M0 != 0.0;
     E.stats.ms_convert = now_ms() - t0;
 
     // S2 + S3: global + local quantiser (progress lines as patolette.c:209-229 prints them when verbose)
