@@ -50,7 +50,11 @@ __global__ void k_km_prep(const float *__restrict__ cent, int k, float4 *c4) {
 }
 
 // top-1 of one sample against all centroids, exactly as the AVX2 fused kernel orders it
-__device__ __forceinline__ int km_assign_one(const float x0, const float x1, const float x2, const float4 *c4, const int k) {
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) f4_t *scalar_c4_t;      // uniform index -> s_load: the 4 KB table sits in the scalar cache
+
+template <typename TabT>
+__device__ __forceinline__ int km_assign_one(const float x0, const float x1, const float x2, const TabT c4, const int k) {
     const float m0 = -2 * x0, m1 = -2 * x1, m2 = -2 * x2;
     const float xn = __builtin_fmaf(x2, x2, __builtin_fmaf(x0, x0, x1 * x1));
     float ld[8]; unsigned li[8];
@@ -60,7 +64,7 @@ __device__ __forceinline__ int km_assign_one(const float x0, const float x1, con
     for (int j = 0; j < ny_p; j += 8) {
 #pragma unroll
         for (int l = 0; l < 8; l++) {
-            const float4 y = c4[j + l];                    // wave-uniform LDS address -> broadcast ds_read_b128
+            const auto y = c4[j + l];                      // wave-uniform address: LDS broadcast read or scalar load
             float dp = m0 * y.x;
             dp = __builtin_fmaf(m1, y.y, dp);
             dp = __builtin_fmaf(m2, y.z, dp);
@@ -77,7 +81,7 @@ __device__ __forceinline__ int km_assign_one(const float x0, const float x1, con
         else if (cur_d == cand && cur_i > li[l]) cur_i = li[l];
     }
     for (int j0 = ny_p; j0 < k; j0++) {                     // simdlib_based.cpp:201-216
-        const float4 y = c4[j0];
+        const auto y = c4[j0];
         float dp = __builtin_fmaf(x2, y.z, __builtin_fmaf(x1, y.y, x0 * y.x));
         float d = xn + y.w - 2 * dp;
         if (d < 0) d = 0;
@@ -104,9 +108,9 @@ __global__ __launch_bounds__(256) void k_km_assign_count(KmSamples s, size_t nx,
                                                          unsigned int *table /* [k][nchunks] */) {
     extern __shared__ unsigned int lds_u[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float4 *lc4 = (float4 *)lds_u;                                   // [k] centroids + norms, shared by the 4 waves
+    // the centroid table (k x 16 bytes, read-only here) is read through the scalar cache: every lane needs the same
+    // entry at the same time, so the operands arrive in SGPRs and no LDS traffic sits between the FMAs
     unsigned int *cnt = lds_u + 4 * (size_t)k + (size_t)wid * k;
-    for (int j = threadIdx.x; j < k; j += 256) lc4[j] = c4[j];
     for (int j = lane; j < k; j += 64) cnt[j] = 0u;
     __syncthreads();
     const int chunk = blockIdx.x * 4 + wid;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void k_km_assign_count(KmSamples s, size_t nx,
         const size_t i = base + lane;
         const bool v = i < hi;
         int a = 0;
-        if (v) { a = km_assign_one(s.x[i], s.y[i], s.z[i], lc4, k); assign[i] = a; }
+        if (v) { a = km_assign_one(s.x[i], s.y[i], s.z[i], (scalar_c4_t)(unsigned long long)c4, k); assign[i] = a; }
         const unsigned long long valid = __ballot(v);
         const unsigned long long m = match_mask(a, nbits, valid);
         if (v && (m & ((1ULL << lane) - 1ULL)) == 0ULL) cnt[a] += (unsigned)__popcll(m);   // group leader; distinct addresses
