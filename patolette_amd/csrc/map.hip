@@ -59,15 +59,73 @@ struct NNGrid {
     int G;
 };
 
+// Coarse pass of the LUT build: a (G/4)^3 grid whose cells each cover 4x4x4 cells of the final grid.  The entries that
+// survive the pruning rule on a coarse cell are a superset of the survivors on every cell inside it (a larger box has a
+// smaller minimum distance to any entry and a larger upper bound), so the fine pass only tests those -- typically
+// 20-40 of the 256 entries.  A coarse cell keeps up to kCoarseMax entries; more than that marks it "all".
+constexpr int kCoarseMax = 96;
+template <typename CandT>
+__global__ __launch_bounds__(64) void k_nn_lut_coarse(const double *__restrict__ pal, int k, NNGrid g, CandT *__restrict__ clist /* [cells][1 + kCoarseMax] */) {
+    // one wavefront per coarse cell, lanes across the palette entries
+    const int Gc = g.G / 4;
+    const int cell = (int)blockIdx.x, lane = (int)threadIdx.x;
+    const int idx[3] = {cell % Gc, (cell / Gc) % Gc, cell / (Gc * Gc)};
+    double cl[3], ch[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double m = 1e-9 * (g.cw[a] * g.G) + 1e-300;
+        cl[a] = g.lo[a] + (4 * idx[a]) * g.cw[a] - m;
+        ch[a] = g.lo[a] + (4 * idx[a] + 4) * g.cw[a] + m;
+    }
+    const double *px = pal, *py = pal + k, *pz = pal + 2 * k;
+    double U = INFINITY;
+    for (int j = lane; j < k; j += 64) {
+        const double p[3] = {px[j], py[j], pz[j]};
+        double mx = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - cl[a]), fabs(p[a] - ch[a])); mx += d * d; }
+        U = fmin(U, mx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) U = fmin(U, __shfl_xor(U, o, 64));
+    const double thr = U * (1.0 + 1e-12) + 1e-300;
+    CandT *out = clist + (size_t)cell * (1 + kCoarseMax);
+    int cnt = 0;                                                 // wave-uniform
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int j = j0 + lane;
+        bool keep = false;
+        if (j < k) {
+            const double p[3] = {px[j], py[j], pz[j]};
+            double mn = 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0); mn += d * d; }
+            keep = mn <= thr;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = cnt + (int)__popcll(m & ((1ULL << lane) - 1ULL));     // ascending index order is kept
+        if (keep && pos < kCoarseMax) out[1 + pos] = (CandT)j;
+        cnt += (int)__popcll(m);
+    }
+    if (lane == 0) out[0] = (CandT)(cnt <= kCoarseMax ? cnt : (CandT)~(CandT)0);      // all ones: test every entry
+}
+
 // Per cell two records of 16 entries: primary = [count, c0..c14], secondary = [c15..c29, unused].
 // count = 255 marks overflow (full scan).  One 16-byte (u8) / 32-byte (u16) load serves almost every pixel.
 template <typename CandT>
-__global__ __launch_bounds__(256) void k_nn_lut_build(const double *__restrict__ pal, int k, NNGrid g, CandT *__restrict__ lut,
-                                                      CandT *__restrict__ lut2) {
-    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ncell = g.G * g.G * g.G;
-    if (cell >= ncell) return;
-    int idx[3] = {cell % g.G, (cell / g.G) % g.G, cell / (g.G * g.G)};
+__global__ __launch_bounds__(64) void k_nn_lut_build(const double *__restrict__ pal, int k, NNGrid g, CandT *__restrict__ lut,
+                                                      CandT *__restrict__ lut2, const CandT *__restrict__ clist) {
+    // one wavefront per coarse cell, lane t = the fine cell (t & 3, (t >> 2) & 3, t >> 4) inside it: the list of entries
+    // to test is the same for the whole wavefront (uniform loads)
+    const int Gc = g.G / 4;
+    const int cc = (int)blockIdx.x;
+    const int cidx[3] = {cc % Gc, (cc / Gc) % Gc, cc / (Gc * Gc)};
+    const int t64 = (int)threadIdx.x;
+    int idx[3] = {4 * cidx[0] + (t64 & 3), 4 * cidx[1] + ((t64 >> 2) & 3), 4 * cidx[2] + (t64 >> 4)};
+    const int cell = (idx[2] * g.G + idx[1]) * g.G + idx[0];
+    // entries to test: the survivors of the enclosing coarse cell (ascending index), or all of them
+    const CandT *cand = clist + (size_t)cc * (1 + kCoarseMax);
+    const bool all = cand[0] == (CandT)~(CandT)0;
+    const int ntest = all ? k : (int)cand[0];
     double cl[3], ch[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -76,8 +134,9 @@ __global__ __launch_bounds__(256) void k_nn_lut_build(const double *__restrict__
         ch[a] = g.lo[a] + (idx[a] + 1) * g.cw[a] + m;
     }
     const double *px = pal, *py = pal + k, *pz = pal + 2 * k;
-    double U = INFINITY;
-    for (int j = 0; j < k; j++) {
+    double U = INFINITY;                                        // the entry that attains the minimum survives the coarse rule
+    for (int t = 0; t < ntest; t++) {
+        const int j = all ? t : (int)cand[1 + t];
         const double p[3] = {px[j], py[j], pz[j]};
         double mx = 0;
 #pragma unroll
@@ -87,7 +146,8 @@ __global__ __launch_bounds__(256) void k_nn_lut_build(const double *__restrict__
     const double thr = U * (1.0 + 1e-12) + 1e-300;
     CandT *rec = lut + (size_t)cell * 16, *rec2 = lut2 + (size_t)cell * 16;
     int cnt = 0;
-    for (int j = 0; j < k; j++) {
+    for (int t = 0; t < ntest; t++) {
+        const int j = all ? t : (int)cand[1 + t];
         const double p[3] = {px[j], py[j], pz[j]};
         double mn = 0;
 #pragma unroll
@@ -243,13 +303,25 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
     if (k <= 256) {
         w.lut.reserve((size_t)ncell * 32);
         unsigned char *l1 = w.lut.p, *l2 = w.lut.p + (size_t)ncell * 16;
-        { KTIME("k_nn_lut_build", s, 32.0 * ncell); hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, (ncell + 255) / 256, 256, 0, s, d_pal, k, g, l1, l2); }
+        const int ncoarse = ncell / 64;
+        w.clist.reserve((size_t)ncoarse * (1 + kCoarseMax) * 2);
+        {
+            KTIME("k_nn_lut_build", s, 32.0 * ncell);
+            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, w.clist.p);
+            hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, l1, l2, (const unsigned char *)w.clist.p);
+        }
         KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
         hipLaunchKernelGGL((k_nn_map_lut<OutT, unsigned char>), stream_blocks(n, 8), 256, lds, s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned char *)l1, (const unsigned char *)l2, out);
     } else {
         w.lut.reserve((size_t)ncell * 64);
         unsigned short *l16 = (unsigned short *)w.lut.p, *l16b = l16 + (size_t)ncell * 16;
-        { KTIME("k_nn_lut_build", s, 64.0 * ncell); hipLaunchKernelGGL(k_nn_lut_build<unsigned short>, (ncell + 255) / 256, 256, 0, s, d_pal, k, g, l16, l16b); }
+        const int ncoarse = ncell / 64;
+        w.clist.reserve((size_t)ncoarse * (1 + kCoarseMax) * 2);
+        {
+            KTIME("k_nn_lut_build", s, 64.0 * ncell);
+            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, (unsigned short *)w.clist.p);
+            hipLaunchKernelGGL(k_nn_lut_build<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, l16, l16b, (const unsigned short *)w.clist.p);
+        }
         static bool attr = false;
         if (!attr) {
             HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_lut<OutT, unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
