@@ -19,7 +19,7 @@ struct KMeansWork {
     DevBuf<float4> c4;                 // (y0,y1,y2,|y|^2)
     DevBuf<int> perm;                  // subsample indices
     DevBuf<struct DevMT> mt;
-    DevBuf<unsigned char> lut, grid;   // pruned assignment: candidate records per grid cell, sample bounding box
+    DevBuf<unsigned char> lut, grid, clist;   // pruned assignment: candidate records per grid cell, sample bounding box, coarse lists
     DevBuf<unsigned int> bkeys;
     void reserve(size_t nx, int k);
 };

@@ -239,46 +239,107 @@ __device__ __forceinline__ int km_cell(float x0, float x1, float x2, const KmGri
     return (idx[2] * G + idx[1]) * G + idx[0];
 }
 
-__global__ __launch_bounds__(256) void k_km_lut_build(const float4 *__restrict__ c4, int k, const KmGridDev *__restrict__ gp, int G,
-                                                      unsigned char *__restrict__ lut) {
-    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= G * G * G) return;
-    const KmGridDev g = *gp;
-    const int idx[3] = {cell % G, (cell / G) % G, cell / (G * G)};
-    double cl[3], ch[3], cellnorm2 = 0;
+// The rule of one cell: threshold from the box [cl, ch] (already widened) and the list of entries to consider.
+struct KmBox { double cl[3], ch[3], cellnorm2; };
+__device__ __forceinline__ KmBox km_box(const KmGridDev &g, int G, const int idx[3], int span) {
+    KmBox b; b.cellnorm2 = 0;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const double r = (double)g.hi[a] - (double)g.lo[a], cw = r / G, m = 1e-9 * r + 1e-30;
-        cl[a] = (double)g.lo[a] + idx[a] * cw - m;
-        ch[a] = (double)g.lo[a] + (idx[a] + 1) * cw + m;
-        const double f = fmax(fabs(cl[a]), fabs(ch[a]));
-        cellnorm2 += f * f;
+        b.cl[a] = (double)g.lo[a] + idx[a] * cw - m;
+        b.ch[a] = (double)g.lo[a] + (idx[a] + span) * cw + m;
+        const double f = fmax(fabs(b.cl[a]), fabs(b.ch[a]));
+        b.cellnorm2 += f * f;
     }
-    double U = INFINITY, cn2 = 0;
-    for (int j = 0; j < k; j++) {
-        const float4 y = c4[j];
-        const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
-        double mx = 0;
+    return b;
+}
+__device__ __forceinline__ double km_maxd2(const KmBox &b, const float4 y) {
+    const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
+    double mx = 0;
 #pragma unroll
-        for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - cl[a]), fabs(p[a] - ch[a])); mx += d * d; }
-        U = fmin(U, mx);
-        cn2 = fmax(cn2, (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+    for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - b.cl[a]), fabs(p[a] - b.ch[a])); mx += d * d; }
+    return mx;
+}
+__device__ __forceinline__ double km_mind2(const KmBox &b, const float4 y) {
+    const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
+    double mn = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { const double d = fmax(fmax(b.cl[a] - p[a], p[a] - b.ch[a]), 0.0); mn += d * d; }
+    return mn;
+}
+__device__ __forceinline__ double km_threshold(const KmBox &b, double U, double cn2) {
+    const double rr = sqrt(b.cellnorm2) + sqrt(cn2);
+    return U * (1.0 + 1e-12) + 4.0 * (16.0 * 0x1.0p-24) * rr * rr + 1e-300;
+}
+
+// Coarse pass: one wavefront per block of 4x4x4 cells, lanes across the centroids.  The survivors of the rule on the
+// big box are a superset of the survivors on every cell inside (smaller minimum distance, larger upper bound, larger
+// margin), so the fine pass tests only those.  The list is written in the order the fine pass needs: by SIMD lane
+// (j mod 8) of the reference's kernel, ascending j inside a lane, scalar leftovers last.
+constexpr int kKmCoarseMax = 96;
+__global__ __launch_bounds__(64) void k_km_lut_coarse(const float4 *__restrict__ c4, int k, const KmGridDev *__restrict__ gp, int G,
+                                                      unsigned char *__restrict__ clist /* [cells][2 + kKmCoarseMax]: count, flag, entries */,
+                                                      double *__restrict__ cn2_out /* largest squared centroid norm (same from every block) */) {
+    const KmGridDev g = *gp;
+    const int Gc = G / 4, cell = (int)blockIdx.x, lane = (int)threadIdx.x;
+    const int idx[3] = {4 * (cell % Gc), 4 * ((cell / Gc) % Gc), 4 * (cell / (Gc * Gc))};
+    const KmBox b = km_box(g, G, idx, 4);
+    double U = INFINITY, cn2 = 0;
+    for (int j = lane; j < k; j += 64) {
+        const float4 y = c4[j];
+        U = fmin(U, km_maxd2(b, y));
+        cn2 = fmax(cn2, ((double)y.x * y.x + (double)y.y * y.y) + (double)y.z * y.z);
     }
-    const double rr = sqrt(cellnorm2) + sqrt(cn2);
-    const double thr = U * (1.0 + 1e-12) + 4.0 * (16.0 * 0x1.0p-24) * rr * rr + 1e-300;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { U = fmin(U, __shfl_xor(U, o, 64)); cn2 = fmax(cn2, __shfl_xor(cn2, o, 64)); }
+    const double thr = km_threshold(b, U, cn2);
+    if (lane == 0) *cn2_out = cn2;
+    unsigned char *out = clist + (size_t)cell * (2 + kKmCoarseMax);
+    int cnt = 0;                                                 // wave-uniform
+    const int ny_p = (k / 8) * 8;
+    auto sweep = [&](int j, bool valid) {
+        const bool keep = valid && km_mind2(b, c4[valid ? j : 0]) <= thr;
+        const unsigned long long m = __ballot(keep);
+        const int pos = cnt + (int)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (keep && pos < kKmCoarseMax) out[2 + pos] = (unsigned char)j;
+        cnt += (int)__popcll(m);
+    };
+    for (int l = 0; l < 8; l++)
+        for (int q0 = 0; l + 8 * q0 < ny_p; q0 += 64) { const int j = l + 8 * (q0 + lane); sweep(j, j < ny_p); }
+    for (int j0 = ny_p; j0 < k; j0 += 64) sweep(j0 + lane, j0 + lane < k);
+    if (lane == 0) { out[0] = (unsigned char)(cnt <= kKmCoarseMax ? cnt : 0); out[1] = (unsigned char)(cnt <= kKmCoarseMax ? 0 : 1); }   // flag 1: test all
+}
+
+// Fine pass: one wavefront per coarse block, lane = one of its 64 cells (uniform candidate list).
+__global__ __launch_bounds__(64) void k_km_lut_build(const float4 *__restrict__ c4, int k, const KmGridDev *__restrict__ gp, int G,
+                                                     const unsigned char *__restrict__ clist, const double *__restrict__ cn2_in,
+                                                     unsigned char *__restrict__ lut) {
+    const KmGridDev g = *gp;
+    const int Gc = G / 4, cc = (int)blockIdx.x, t64 = (int)threadIdx.x;
+    const int idx[3] = {4 * (cc % Gc) + (t64 & 3), 4 * ((cc / Gc) % Gc) + ((t64 >> 2) & 3), 4 * (cc / (Gc * Gc)) + (t64 >> 4)};
+    const int cell = (idx[2] * G + idx[1]) * G + idx[0];
+    const KmBox b = km_box(g, G, idx, 1);
+    const unsigned char *cand = clist + (size_t)cc * (2 + kKmCoarseMax);
+    const bool all = cand[1] != 0;
+    const int ntest = all ? k : (int)cand[0];
+    const int ny_p = (k / 8) * 8;
+    // position t of the "all" order: by SIMD lane, ascending inside, leftovers last
+    auto entry = [&](int t) -> int {
+        if (!all) return (int)cand[2 + t];
+        if (t >= ny_p) return t;
+        const int per = ny_p / 8;
+        return (t / per) + 8 * (t % per);
+    };
+    double U = INFINITY;
+    const double cn2 = *cn2_in;                                   // over all centroids, from the coarse pass
+    for (int t = 0; t < ntest; t++) U = fmin(U, km_maxd2(b, c4[entry(t)]));
+    const double thr = km_threshold(b, U, cn2);
     unsigned char rec[16];
     int cnt = 0;
-    const int ny_p = (k / 8) * 8;
-    auto test = [&](int j) {
-        const float4 y = c4[j];
-        const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
-        double mn = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++) { const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0); mn += d * d; }
-        if (mn <= thr) { if (cnt < 15) rec[1 + cnt] = (unsigned char)j; cnt++; }
-    };
-    for (int l = 0; l < 8; l++) for (int j = l; j < ny_p; j += 8) test(j);      // ordered by SIMD lane, then index
-    for (int j = ny_p; j < k; j++) test(j);                                     // scalar leftovers last
+    for (int t = 0; t < ntest; t++) {
+        const int j = entry(t);
+        if (km_mind2(b, c4[j]) <= thr) { if (cnt < 15) rec[1 + cnt] = (unsigned char)j; cnt++; }
+    }
     rec[0] = (unsigned char)(cnt <= 15 ? cnt : 255);
     for (int t = cnt < 15 ? cnt + 1 : 16; t < 16; t++) rec[t] = 0;
     uint4 out;
@@ -646,14 +707,22 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_lut, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
             attr2 = true;
         }
-        w.lut.reserve((size_t)G * G * G * 16); w.bkeys.reserve(kKmSlots * 6); w.grid.reserve(sizeof(KmGridDev));
+        w.lut.reserve((size_t)G * G * G * 16); w.bkeys.reserve(kKmSlots * 6); w.grid.reserve(64 + sizeof(double));
+        w.clist.reserve((size_t)(G * G * G / 64) * (2 + kKmCoarseMax));
         hipLaunchKernelGGL(k_km_bounds_init, 1, 256, 0, s, w.bkeys.p);
         { KTIME("k_km_bounds", s, 12.0 * nx); hipLaunchKernelGGL(k_km_bounds, (int)std::min<size_t>(ceil_div(nx, 256), 2048), 256, 0, s, ks, nx, w.bkeys.p); }
         hipLaunchKernelGGL(k_km_bounds_fold, 1, 64, 0, s, w.bkeys.p, (KmGridDev *)w.grid.p);
     }
     for (int it = 0; it < niter; it++) {
         if (use_lut) {
-            { KTIME("k_km_lut_build", s, 16.0 * G * G * G); hipLaunchKernelGGL(k_km_lut_build, (G * G * G + 255) / 256, 256, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, w.lut.p); }
+            {
+                KTIME("k_km_lut_build", s, 16.0 * G * G * G);
+                const int ncoarse = G * G * G / 64;
+                double *cn2 = (double *)(w.grid.p + 64);                  // a scalar next to the bounding box
+                hipLaunchKernelGGL(k_km_lut_coarse, ncoarse, 64, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, w.clist.p, cn2);
+                hipLaunchKernelGGL(k_km_lut_build, ncoarse, 64, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, (const unsigned char *)w.clist.p,
+                                   (const double *)cn2, w.lut.p);
+            }
             KTIME("k_km_assign", s, 16.0 * nx);
             hipLaunchKernelGGL(k_km_assign_lut, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p,
                                (const KmGridDev *)w.grid.p, G, w.lut.p);
