@@ -554,7 +554,14 @@ __device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, siz
         for (int d = 0; d < D; d++) {
             const size_t base = sbase + (size_t)d * 64;
             if (base >= hi) break;                                         // wave-uniform
-            stage[pb][lane] = ring[d];                                     // LDS of this wavefront only: in-order, no barrier
+            // this wavefront's coordinate (and the weight) of the 64 samples, contiguous in its own LDS: one 128-bit
+            // broadcast read then serves four chain steps
+            float *sc = reinterpret_cast<float *>(&stage[pb][0]);          // [64] coordinate, [64] weight
+            {
+                const float4 v = ring[d];
+                sc[lane] = C == 0 ? v.x : (C == 1 ? v.y : (C == 2 ? v.z : v.w));
+                if constexpr (W && C < 3) sc[64 + lane] = v.w;
+            }
             {   // refill this ring slot with the block D steps ahead
                 const size_t nb = base + (size_t)D * 64 + lane;
                 ring[d] = make_float4(0, 0, 0, 0);
@@ -562,20 +569,25 @@ __device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, siz
             }
             __builtin_amdgcn_wave_barrier();
             const int cnt = (int)(hi - base < 64 ? hi - base : 64);
-            const float *sp = reinterpret_cast<const float *>(&stage[pb][0]);
-            auto step = [&](int t) {
-                if constexpr (W) {
-                    const float w = sp[4 * t + 3];
-                    if constexpr (C == 3) acc += w; else acc = __builtin_fmaf(sp[4 * t + C], w, acc);
-                } else {
-                    acc += sp[4 * t + C];
+            const float4 *s4 = reinterpret_cast<const float4 *>(sc), *w4 = reinterpret_cast<const float4 *>(sc + 64);
+            auto step4 = [&](int q, int nvalid) {                           // samples 4q .. 4q+3 (the first nvalid of them)
+                const float4 x = s4[q];
+                float4 w = make_float4(0, 0, 0, 0);
+                if constexpr (W && C < 3) w = w4[q];
+                const float xs[4] = {x.x, x.y, x.z, x.w}, ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (e < nvalid) {
+                        if constexpr (W && C < 3) acc = __builtin_fmaf(xs[e], ws[e], acc);
+                        else acc += xs[e];
+                    }
                 }
             };
             if (cnt == 64) {
-#pragma unroll 16
-                for (int t = 0; t < 64; t++) step(t);
+#pragma unroll
+                for (int q = 0; q < 16; q++) step4(q, 4);
             } else {
-                for (int t = 0; t < cnt; t++) step(t);
+                for (int q = 0; 4 * q < cnt; q++) step4(q, cnt - 4 * q < 4 ? cnt - 4 * q : 4);
             }
             __builtin_amdgcn_wave_barrier();
             pb ^= 1;
