@@ -46,17 +46,25 @@ def quantize_batch_sharded(width, height, images, palette_size, dist=None, quant
     for the whole batch in order, the other ranks return None.  With dist=None it is a plain
     loop.  `quantize_fn` defaults to patolette_amd.quantize (tests inject the CPU oracle to
     exercise the sharding and gather logic without a GPU)."""
+    batch_fn = None
     if quantize_fn is None:
         from . import quantize as quantize_fn
+        from . import quantize_batch as batch_fn          # three images in flight per GPU
     count = len(images) if not callable(images) else kwargs.pop("count")
     get = images if callable(images) else (lambda i: images[i])
     kwargs.setdefault("tile_size", 0)
     rank, world = (0, 1) if dist is None else (dist.get_rank(), dist.get_world_size())
     start, n = shard(count, rank, world)
     local = []
-    for i in range(start, start + n):
-        w = None if weights is None else weights[i]
-        local.append(quantize_fn(width, height, get(i), palette_size, weights=w, **kwargs))
+    if batch_fn is not None:
+        for g0 in range(start, start + n, 6):                 # groups of six bound the host memory held at once
+            idx = list(range(g0, min(g0 + 6, start + n)))
+            ws = None if weights is None else [weights[i] for i in idx]
+            local.extend(batch_fn(width, height, [get(i) for i in idx], palette_size, weights=ws, **kwargs))
+    else:
+        for i in range(start, start + n):
+            w = None if weights is None else weights[i]
+            local.append(quantize_fn(width, height, get(i), palette_size, weights=w, **kwargs))
     if dist is None:
         return local
     npx = width * height
