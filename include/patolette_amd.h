@@ -110,6 +110,12 @@ void patolette_amd_batch(size_t count, size_t width, size_t height, const double
                          const patolette__QuantizationOptions *options, double *const *palettes,
                          size_t *const *palette_maps, int *exit_codes);
 
+/* the same with every image as (width*height, 3) row-major f64 (see patolette_amd_quantize_rows) */
+void patolette_amd_batch_rows(size_t count, size_t width, size_t height, const double *const *rows,
+                              const double *const *weights, double tile_size, size_t palette_size,
+                              const patolette__QuantizationOptions *options, double *const *palettes,
+                              size_t *const *palette_maps, int *exit_codes);
+
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
 /* out[i] = pow(x[i], y) as the colour conversions evaluate it on the device (x >= 0; <= 0.51 ulp) */
 int patolette_amd_pow(const double *x, double y, double *out, size_t n);

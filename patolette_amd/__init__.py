@@ -215,7 +215,10 @@ def quantize_batch(width, height, images, palette_size, weights=None, dither=Tru
         return [(False, None, None, bad_tile_size)] * len(images)
     count = len(images)
     n = width * height
-    datas = [np.asfortranarray(np.asarray(im), dtype=np.float64) for im in images]
+    # all planar (F-ordered float64) -> the planar entry as is; otherwise every image goes row-major (no transposes)
+    arrs = [np.asarray(im) for im in images]
+    planar = all(a.ndim == 2 and a.dtype == np.float64 and a.flags.f_contiguous and not a.flags.c_contiguous for a in arrs)
+    datas = arrs if planar else [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
     for d in datas:
         if d.ndim != 2 or d.shape[1] != 3:
             raise ValueError(bad_channel_count.format(d.shape[1] if d.ndim == 2 else "?"))
@@ -235,7 +238,8 @@ def quantize_batch(width, height, images, palette_size, weights=None, dither=Tru
     m_arr = None if palette_only else PZ(*[m.ctypes.data_as(_native.zp) for m in maps])
     codes = (C.c_int * count)()
     L = _native.lib()
-    L.patolette_amd_batch(count, width, height, d_arr, w_arr, float(tile_size), palette_size, C.byref(opts), p_arr, m_arr, codes)
+    (L.patolette_amd_batch if planar else L.patolette_amd_batch_rows)(count, width, height, d_arr, w_arr, float(tile_size), palette_size,
+                                                                      C.byref(opts), p_arr, m_arr, codes)
     out = []
     for i in range(count):
         msg = L.get_patolette_exit_code_info_message(codes[i]).decode('UTF-8')

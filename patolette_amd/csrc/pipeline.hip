@@ -1200,8 +1200,8 @@ Engine *pool_acquire(int device) {
 void pool_release(Engine *e) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool.push_back(e); }
 }  // namespace
 
-void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
-                         double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
+static void batch_impl(bool rows, size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
+                       double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
                          size_t *const *palette_maps, int *exit_codes) {
     const int v = validate(width, height, palette_size);
     if (v != 0) { for (size_t i = 0; i < count; i++) exit_codes[i] = v; return; }
@@ -1237,7 +1237,7 @@ void patolette_amd_batch(size_t count, size_t width, size_t height, const double
         for (size_t i; (i = next.fetch_add(1)) < count;) {
             try {
                 run_host(*E, width, height, data[i], weights ? weights[i] : nullptr, tile_size, palette_size, options, palettes[i],
-                         palette_maps ? palette_maps[i] : nullptr);
+                         palette_maps ? palette_maps[i] : nullptr, rows);
                 exit_codes[i] = 0;
             } catch (const CodeError &ex) {
                 exit_codes[i] = ex.code;
@@ -1252,6 +1252,17 @@ void patolette_amd_batch(size_t count, size_t width, size_t height, const double
     for (size_t t = 1; t < workers; t++) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+}
+
+void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
+                         double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
+                         size_t *const *palette_maps, int *exit_codes) {
+    batch_impl(false, count, width, height, data, weights, tile_size, palette_size, options, palettes, palette_maps, exit_codes);
+}
+void patolette_amd_batch_rows(size_t count, size_t width, size_t height, const double *const *rows, const double *const *weights,
+                              double tile_size, size_t palette_size, const patolette__QuantizationOptions *options,
+                              double *const *palettes, size_t *const *palette_maps, int *exit_codes) {
+    batch_impl(true, count, width, height, rows, weights, tile_size, palette_size, options, palettes, palette_maps, exit_codes);
 }
 
 int patolette_amd_pow(const double *x, double y, double *out, size_t n) {
