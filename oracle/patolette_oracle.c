@@ -598,6 +598,7 @@ int orc_pca_axis(const double *c, const double *w, size_t n, double axis[3], dou
 void orc_axis_sort(const double *c, size_t n, const double axis[3], size_t bucket_count, size_t *map) {
     const double *p0 = c, *p1 = c + n, *p2 = c + 2 * n;
     double *dots = (double *)malloc(sizeof(double) * (n ? n : 1));
+    dots[0] = 0.0;                                           /* n == 0: nothing to sort, keep the reads below defined */
     /* cblas_dgemv(ColMajor, NoTrans): y = A x.  Evaluation order inside OpenBLAS is not
      * specified; SURVEY.md 7(4): three different orders gave identical buckets. */
     for (size_t i = 0; i < n; i++) dots[i] = (p0[i] * axis[0] + p1[i] * axis[1]) + p2[i] * axis[2];
