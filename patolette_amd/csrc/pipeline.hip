@@ -169,7 +169,7 @@ struct Engine {
     PinBuf<Tile> h_tilesA, h_tilesP;
     PinBuf<int> h_round, h_tile0;
     PinBuf<double> h_dbl;
-    PinBuf<unsigned char> h_bytes, h_packet;
+    PinBuf<unsigned char> h_bytes, h_packet, h_mapstage;
     DevBuf<unsigned char> packet;
     KMeansWork km;
     NNWork nn;
@@ -837,6 +837,68 @@ static int validate(size_t width, size_t height, size_t K) {               // pa
 
 static int map_elem_for(size_t K) { return K <= 256 ? 1 : 4; }
 
+// The C ABI hands the index map back as size_t (patolette.h: `size_t *palette_map`): 8 bytes per pixel on the host for 1 (or
+// 4) on the device.  The narrow map crosses PCIe in chunks through pinned staging while a few host threads widen the
+// previous chunk into the caller's buffer.
+static void download_map_widened(Engine &E, const void *d_map, int me, size_t N, size_t *out) {
+    if (N == 0) return;
+    const size_t chunk = (size_t)2 << 20;                                   // elements per chunk
+    const size_t nchunks = ceil_div(N, chunk);
+    E.h_mapstage.reserve(2 * chunk * (size_t)me);
+    const int T = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), ceil_div(N, (size_t)1 << 18)}));
+    std::atomic<size_t> ready{0};
+    std::vector<std::atomic<int>> done(nchunks);
+    for (auto &d : done) d.store(0);
+    std::atomic<bool> failed{false};
+    auto worker = [&](int tid) {
+        for (size_t c = 0; c < nchunks; c++) {
+            while (ready.load(std::memory_order_acquire) <= c) {
+                if (failed.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const size_t lo = c * chunk, cnt = std::min(chunk, N - lo);
+            const size_t a = cnt * (size_t)tid / (size_t)T, b = cnt * (size_t)(tid + 1) / (size_t)T;
+            const unsigned char *src = E.h_mapstage.p + (c & 1) * chunk * (size_t)me;
+            if (me == 1) for (size_t i = a; i < b; i++) out[lo + i] = (size_t)src[i];
+            else { const unsigned int *s4 = (const unsigned int *)src; for (size_t i = a; i < b; i++) out[lo + i] = (size_t)s4[i]; }
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(worker, t);
+    auto issue = [&](size_t c) {
+        const size_t lo = c * chunk, cnt = std::min(chunk, N - lo);
+        HIP_CHECK(hipMemcpyAsync(E.h_mapstage.p + (c & 1) * chunk * (size_t)me, (const unsigned char *)d_map + lo * (size_t)me, cnt * (size_t)me,
+                                 hipMemcpyDeviceToHost, E.stream));
+    };
+    try {
+        issue(0);
+        for (size_t c = 0; c < nchunks; c++) {
+            HIP_CHECK(hipStreamSynchronize(E.stream));
+            ready.store(c + 1, std::memory_order_release);
+            if (c + 1 < nchunks) {
+                // chunk c+1 reuses the half chunk c-1 was staged in: every thread must be done with c-1 (the calling thread
+                // is worker 0 and widens its share of chunk c only after issuing the copy)
+                if (c >= 1) while (done[c - 1].load(std::memory_order_acquire) < T) std::this_thread::yield();
+                issue(c + 1);
+            }
+            {   // worker 0's share of chunk c
+                const size_t lo = c * chunk, cnt = std::min(chunk, N - lo);
+                const size_t b = cnt / (size_t)T;
+                const unsigned char *src = E.h_mapstage.p + (c & 1) * chunk * (size_t)me;
+                if (me == 1) for (size_t i = 0; i < b; i++) out[lo + i] = (size_t)src[i];
+                else { const unsigned int *s4 = (const unsigned int *)src; for (size_t i = 0; i < b; i++) out[lo + i] = (size_t)s4[i]; }
+                done[c].fetch_add(1, std::memory_order_release);
+            }
+        }
+    } catch (...) {
+        failed.store(true);
+        for (auto &th : pool) th.join();
+        throw;
+    }
+    for (auto &th : pool) th.join();
+}
+
 // host-buffer entry: upload, run, download + widen
 static void run_host(Engine &E, size_t width, size_t height, const double *data, const double *weights, double tile_size,
                      size_t K, const patolette__QuantizationOptions *opt, double *palette, size_t *palette_map, bool rows = false) {
@@ -863,15 +925,7 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     if (!opt->palette_only) {
         const bool touched = !(opt->dither && std::max(width, height) <= 1);   // 1x1 dither visits nothing (riemersma.c:452-456)
         if (touched) {
-            if (me == 1) {
-                std::vector<unsigned char> tmp(N);
-                HIP_CHECK(hipMemcpy(tmp.data(), E.dmap.p, N, hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < N; i++) palette_map[i] = (size_t)tmp[i];
-            } else {
-                std::vector<unsigned int> tmp(N);
-                HIP_CHECK(hipMemcpy(tmp.data(), E.dmap.p, N * 4, hipMemcpyDeviceToHost));
-                for (size_t i = 0; i < N; i++) palette_map[i] = (size_t)tmp[i];
-            }
+            download_map_widened(E, E.dmap.p, me, N, palette_map);
         }
     }
     std::memcpy(palette, pal.data(), 3 * K * sizeof(double));

@@ -76,7 +76,19 @@ __global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__r
     const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
     const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N;
     double mn = INFINITY, mx = -INFINITY;
-    for (unsigned i = threadIdx.x; i < t.count; i += blockDim.x) {
+    unsigned i = threadIdx.x;
+    for (; i + 3 * 256 < t.count; i += 4 * 256) {           // twelve loads in flight per lane
+        const size_t p = t.start + i;
+        double x[4], y[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { x[u] = px[p + u * 256]; y[u] = py[p + u * 256]; z[u] = pz[p + u * 256]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            double d = project(x[u], y[u], z[u], a0, a1, a2);
+            mn = fmin(mn, d); mx = fmax(mx, d);
+        }
+    }
+    for (; i < t.count; i += 256) {
         size_t p = t.start + i;
         double d = project(px[p], py[p], pz[p], a0, a1, a2);
         mn = fmin(mn, d); mx = fmax(mx, d);
