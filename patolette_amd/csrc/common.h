@@ -117,4 +117,13 @@ struct PinBuf {
 
 inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 
+inline int num_cus() {                                      // compute units of the current device (256 on MI355X)
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
 }  // namespace pamd

@@ -11,6 +11,7 @@ struct NNWork {                        // scratch of the pruned NN map
     DevBuf<unsigned char> lut;         // per grid cell: 32 candidate slots (u8 or u16), count in the last
     DevBuf<unsigned long long> keys;   // min/max keys when the caller has no bounds
     DevBuf<unsigned char> clist;       // coarse pass of the LUT build: surviving entries per 4x4x4 block of cells
+    DevBuf<unsigned int> mid;          // (G/2)^3 table of up to four candidates per cell, held in LDS by k_nn_map_mid
 };
 // lo/hi: exact per-plane min/max of the colours if known (else nullptr: computed with one more pass)
 void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k,

@@ -266,6 +266,165 @@ __global__ __launch_bounds__(256) void k_nn_map_lut(const double *__restrict__ c
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Large images: a (G/2)^3 table of FOUR-BYTE entries lives in LDS (32^3 x 4 B = 128 KB of the CU's 160 KB), so the
+// per-pixel lookup never leaves the CU -- on unsorted input the 16-byte records of the G^3 table are one random L2 line
+// per pixel and that gather, not HBM, bounded the kernel.  An entry holds up to four candidates in ascending order
+// (padded by repeating the last one; re-evaluating an entry cannot change a strict-'<' arg-min).  The rule that fills it
+// is the G^3 rule plus a bisector test against q* = the entry with the smallest maxdist: p is dropped when
+// |x-p|^2 - |x-q*|^2 > 0 on the whole (widened) box -- linear in x, so its minimum sits in a corner -- with a 1e-12
+// relative margin; a dropped entry is strictly farther than q* everywhere in the cell, so it can neither win nor tie.
+// About 90 % of the pixels of a noise image resolve there.  Cells with more than four survivors carry a marker
+// (byte 0 > byte 1, impossible for an ascending list); their pixels are queued per wavefront in LDS and taken 64 at a
+// time through the G^3 records, so that path runs with full wavefronts too.
+// --------------------------------------------------------------------------------------------
+constexpr unsigned kMidOverflow = 0x00000001u;                 // bytes {1, 0, 0, 0}
+
+__global__ __launch_bounds__(256) void k_nn_lut_mid(const double *__restrict__ pal, int k, NNGrid g, const unsigned char *__restrict__ clist,
+                                                    unsigned int *__restrict__ mid) {
+    const int Gm = g.G / 2, Gc = g.G / 4;
+    const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (cell >= Gm * Gm * Gm) return;
+    const int idx[3] = {cell % Gm, (cell / Gm) % Gm, cell / (Gm * Gm)};
+    const int cc = ((idx[2] >> 1) * Gc + (idx[1] >> 1)) * Gc + (idx[0] >> 1);
+    const unsigned char *cand = clist + (size_t)cc * (1 + kCoarseMax);
+    const bool all = cand[0] == 0xff;
+    const int ntest = all ? k : (int)cand[0];
+    double cl[3], ch[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double m = 1e-9 * (g.cw[a] * g.G) + 1e-300;
+        cl[a] = g.lo[a] + (2 * idx[a]) * g.cw[a] - m;
+        ch[a] = g.lo[a] + (2 * idx[a] + 2) * g.cw[a] + m;
+    }
+    const double *px = pal, *py = pal + k, *pz = pal + 2 * k;
+    double U = INFINITY; int qs = 0;
+    for (int t = 0; t < ntest; t++) {
+        const int j = all ? t : (int)cand[1 + t];
+        const double p[3] = {px[j], py[j], pz[j]};
+        double mx = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - cl[a]), fabs(p[a] - ch[a])); mx += d * d; }
+        if (mx < U) { U = mx; qs = j; }
+    }
+    const double thr = U * (1.0 + 1e-12) + 1e-300;
+    const double q[3] = {px[qs], py[qs], pz[qs]};
+    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    unsigned entry = 0; int cnt = 0, last = 0;
+    for (int t = 0; t < ntest; t++) {
+        const int j = all ? t : (int)cand[1 + t];
+        const double p[3] = {px[j], py[j], pz[j]};
+        double mn = 0, f = 0, scale = q2;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0);
+            mn += d * d;
+            const double w = q[a] - p[a];
+            f += 2.0 * fmin(cl[a] * w, ch[a] * w);              // min over the box of 2 x.(q - p)
+            f += p[a] * p[a];
+            const double big = fmax(fmax(fabs(cl[a]), fabs(ch[a])), fabs(p[a]));
+            scale += 4.0 * big * big;
+        }
+        f -= q2;                                                 // min over the box of |x-p|^2 - |x-q|^2
+        if (mn <= thr && !(f > 1e-12 * scale + 1e-300)) {
+            if (cnt < 4) entry |= (unsigned)j << (8 * cnt);
+            last = j;
+            cnt++;
+        }
+    }
+    if (cnt > 4) entry = kMidOverflow;
+    else for (int t = cnt; t < 4; t++) entry |= (unsigned)last << (8 * t);
+    mid[cell] = entry;
+}
+
+template <typename OutT, int P>
+__global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ c, size_t N, size_t n, const double *__restrict__ pal, int k,
+                                                     NNGrid g, const unsigned int *__restrict__ mid, const unsigned char *__restrict__ lut,
+                                                     const unsigned char *__restrict__ lut2, OutT *__restrict__ out) {
+    extern __shared__ unsigned char smem_mid[];
+    const int Gm = g.G / 2, ncell = Gm * Gm * Gm;
+    unsigned int *T = (unsigned int *)smem_mid;                                  // [ncell]
+    double4 *spal = (double4 *)(smem_mid + (size_t)ncell * 4);                    // [256]
+    uint2 *queue = (uint2 *)(smem_mid + (size_t)ncell * 4 + 256 * sizeof(double4));
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint2 *q = queue + wid * 128;                                                 // this wavefront's overflow queue: {pixel, G^3 cell}
+    for (int i = threadIdx.x; i < ncell / 4; i += 1024) ((uint4 *)T)[i] = ((const uint4 *)mid)[i];
+    for (int j = threadIdx.x; j < 256; j += 1024) spal[j] = j < k ? make_double4(pal[j], pal[k + j], pal[2 * k + j], 0.0) : make_double4(0, 0, 0, 0);
+    __syncthreads();
+    const int G = g.G;
+    const double lo0 = g.lo[0], lo1 = g.lo[1], lo2 = g.lo[2], in0 = g.inv[0], in1 = g.inv[1], in2 = g.inv[2];
+    const unsigned long long ltmask = (1ULL << lane) - 1ULL;
+    int qn = 0;                                                                   // wave-uniform
+    auto drain = [&](const uint2 *src, int cnt) {
+        if (lane < cnt) {
+            const uint2 it = src[lane];
+            const size_t i = it.x, cell = it.y;
+            LutRec<unsigned char> r;
+            r.load(lut + cell * 16);
+            const double x = c[i], y = c[N + i], z = c[2 * N + i];
+            out[i] = (OutT)nn_eval<unsigned char>(x, y, z, r, cell, lut2, spal, k);
+        }
+    };
+    const size_t tile = (size_t)1024 * P, step = (size_t)gridDim.x * tile;
+    double nx[P], ny[P], nz[P];
+    auto fetch = [&](size_t base) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const size_t i = base + (size_t)p * 1024 + threadIdx.x;
+            const size_t j = i < n ? i : n - 1;
+            nx[p] = c[j]; ny[p] = c[N + j]; nz[p] = c[2 * N + j];
+        }
+    };
+    size_t base = (size_t)blockIdx.x * tile;
+    if (base < n) fetch(base);
+    for (; base < n; base += step) {
+        double x[P], y[P], z[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) { x[p] = nx[p]; y[p] = ny[p]; z[p] = nz[p]; }
+        if (base + step < n) fetch(base + step);                                  // the next tile's pixels are in flight during this one
+        unsigned e[P], fc[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            int ix = (int)((x[p] - lo0) * in0), iy = (int)((y[p] - lo1) * in1), iz = (int)((z[p] - lo2) * in2);
+            ix = max(0, min(ix, G - 1));
+            iy = max(0, min(iy, G - 1));
+            iz = max(0, min(iz, G - 1));
+            fc[p] = (unsigned)((iz * G + iy) * G + ix);
+            e[p] = T[((iz >> 1) * Gm + (iy >> 1)) * Gm + (ix >> 1)];
+        }
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const size_t i = base + (size_t)p * 1024 + threadIdx.x;
+            const bool ok = i < n;
+            const int j0 = (int)(e[p] & 0xffu), j1 = (int)((e[p] >> 8) & 0xffu), j2 = (int)((e[p] >> 16) & 0xffu), j3 = (int)(e[p] >> 24);
+            const bool ov = ok && j0 > j1;
+            int best = j0;
+            {
+                double4 pp = spal[j0];
+                double d0 = x[p] - pp.x, d1 = y[p] - pp.y, d2 = z[p] - pp.z;
+                double bd = (d0 * d0 + d1 * d1) + d2 * d2;
+                pp = spal[j1]; d0 = x[p] - pp.x; d1 = y[p] - pp.y; d2 = z[p] - pp.z;
+                double d = (d0 * d0 + d1 * d1) + d2 * d2;
+                if (d < bd) { bd = d; best = j1; }
+                pp = spal[j2]; d0 = x[p] - pp.x; d1 = y[p] - pp.y; d2 = z[p] - pp.z;
+                d = (d0 * d0 + d1 * d1) + d2 * d2;
+                if (d < bd) { bd = d; best = j2; }
+                pp = spal[j3]; d0 = x[p] - pp.x; d1 = y[p] - pp.y; d2 = z[p] - pp.z;
+                d = (d0 * d0 + d1 * d1) + d2 * d2;
+                if (d < bd) { bd = d; best = j3; }
+            }
+            if (ok && !ov) out[i] = (OutT)best;
+            const unsigned long long m = __ballot(ov);
+            if (m) {                                                              // wave-uniform
+                if (ov) q[qn + (int)__popcll(m & ltmask)] = make_uint2((unsigned int)i, fc[p]);
+                qn += (int)__popcll(m);
+                if (qn >= 64) { qn -= 64; drain(q + qn, 64); }
+            }
+        }
+    }
+    if (qn > 0) drain(q, qn);
+}
+
 __global__ __launch_bounds__(256) void k_minmax3(const double *__restrict__ c, size_t N, size_t n, unsigned long long *keys /* min[3], max[3] */) {
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -309,6 +468,27 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
             KTIME("k_nn_lut_build", s, 32.0 * ncell);
             hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, w.clist.p);
             hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, l1, l2, (const unsigned char *)w.clist.p);
+        }
+        static const bool use_mid = !(getenv("PAMD_NN_MID") && atoi(getenv("PAMD_NN_MID")) == 0);
+        if (g.G == 64 && use_mid) {
+            const int nmid = (g.G / 2) * (g.G / 2) * (g.G / 2);
+            w.mid.reserve((size_t)nmid);
+            {
+                KTIME("k_nn_lut_build", s, 4.0 * nmid);
+                hipLaunchKernelGGL(k_nn_lut_mid, (nmid + 255) / 256, 256, 0, s, d_pal, k, g, (const unsigned char *)w.clist.p, w.mid.p);
+            }
+            constexpr int P = 2;
+            const size_t lds_mid = (size_t)nmid * 4 + 256 * sizeof(double4) + 16 * 128 * sizeof(uint2);
+            static bool attr_mid = false;
+            if (!attr_mid) {
+                HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_mid<OutT, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+                attr_mid = true;
+            }
+            const int blocks = (int)std::min<size_t>((size_t)num_cus(), ceil_div(n, (size_t)1024 * P));
+            KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
+            hipLaunchKernelGGL((k_nn_map_mid<OutT, P>), blocks, 1024, lds_mid, s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned int *)w.mid.p,
+                               (const unsigned char *)l1, (const unsigned char *)l2, out);
+            return;
         }
         KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
         hipLaunchKernelGGL((k_nn_map_lut<OutT, unsigned char>), stream_blocks(n, 8), 256, lds, s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned char *)l1, (const unsigned char *)l2, out);

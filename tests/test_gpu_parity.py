@@ -169,6 +169,28 @@ def test_nn_map_pruned_path_edge_cases(gpu, ob):
         assert np.array_equal(got, want), int(np.sum(got != want))
 
 
+def test_nn_map_lds_table_path_is_exact(gpu, ob):
+    """From 4 Mpx on (and K <= 256) the map kernel keeps a 32^3 table of four-candidate entries in LDS and sends the
+    pixels of crowded cells through a per-wavefront queue: every pixel of a 4.2 Mpx image against the oracle's brute
+    force, for a quantiser's palette with duplicates, a palette crowded into one corner (every pixel overflows), and a
+    constant plane with half of the palette far outside the pixel box."""
+    n = (1 << 22) + 777
+    base = ob.convert("srgb_to_ictcp", ob.image(n, 21))
+    small = ob.convert("srgb_to_ictcp", ob.image(256 * 256, 22))
+    pal = ob.quantize_clusters(small, None, 256 * 256, 256, want_membership=False)["centers"].copy()
+    pal[200] = pal[17]                                                             # exact duplicate: the lower index must win
+    crowded = np.tile(np.array([[0.05, 0.0, 0.01]]), (256, 1)) + 1e-5 * ob.image(256, 5).reshape(3, 256).T
+    flat2 = base.copy(); flat2[n:2 * n] = 0.0125
+    far = ob.convert("srgb_to_ictcp", ob.image(200, 7)).reshape(3, 200).T.copy()
+    far[::2] += 5.0
+    for flat, p in ((base, pal), (base, crowded), (flat2, far)):
+        kk = p.shape[0]
+        want = ob.nn_map(flat, n, p)
+        got = np.zeros(n, dtype=np.uintp)
+        assert gpu.patolette_amd_nn_map(_d(flat), n, _d(np.ascontiguousarray(p.T).reshape(-1)), kk, got.ctypes.data_as(zp)) == 0
+        assert np.array_equal(got, want), int(np.sum(got != want))
+
+
 @pytest.mark.parametrize("wh", [(64, 64), (37, 23), (5, 40), (1, 9), (130, 70), (256, 3)])
 def test_dither_bit_exact(gpu, ob, wh):
     w, h = wh
