@@ -20,6 +20,7 @@ struct KMeansWork {
     DevBuf<int> perm;                  // subsample indices
     DevBuf<struct DevMT> mt;
     DevBuf<unsigned char> lut, grid, clist;   // pruned assignment: candidate records per grid cell, sample bounding box, coarse lists
+    DevBuf<unsigned int> mid;                 // 32^3 table of four-candidate entries (held in LDS by k_km_assign_mid)
     DevBuf<unsigned int> bkeys;
     void reserve(size_t nx, int k);
 };

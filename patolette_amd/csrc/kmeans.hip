@@ -428,6 +428,203 @@ __global__ __launch_bounds__(256) void k_km_assign_lut(KmSamples s, size_t nx, c
     for (int j = lane; j < k; j += 64) table[(size_t)j * nchunks + chunk] = cnt[j];
 }
 
+// --------------------------------------------------------------------------------------------
+// Many samples (G = 64): like the palette map, the per-sample lookup is served from LDS.  A 32^3 table of four-byte
+// entries (up to four candidates in the order the reference visits them: SIMD lane, then index, leftovers last; padded by
+// repeating the last one, which changes nothing) is filled by the rule above plus a bisector test against q* = the
+// centroid with the smallest maxdist: p is dropped when |x-p|^2 - |x-q*|^2 exceeds the rounding margin on the whole box,
+// i.e. its COMPUTED distance is strictly larger than q*'s everywhere in the cell, so it loses every comparison that
+// matters (it can never be the winner, and whatever it displaces inside its SIMD lane was no winner either).  Samples of
+// cells with more than four survivors are parked (coordinates + index, 16 bytes) in a per-wavefront LDS queue and go
+// through the 16-byte records of the G^3 table with full wavefronts.
+// --------------------------------------------------------------------------------------------
+constexpr unsigned kKmMidOverflow = 0x00010000u;               // bytes {0, 0, 1, 0}: impossible for a padded list
+__device__ __forceinline__ bool km_mid_is_overflow(unsigned e) { return (e & 0xffu) == ((e >> 8) & 0xffu) && ((e >> 8) & 0xffu) != ((e >> 16) & 0xffu); }
+
+__global__ __launch_bounds__(256) void k_km_lut_mid(const float4 *__restrict__ c4, int k, const KmGridDev *__restrict__ gp, int G,
+                                                    const unsigned char *__restrict__ clist, const double *__restrict__ cn2_in,
+                                                    unsigned int *__restrict__ mid) {
+    const KmGridDev g = *gp;
+    const int Gm = G / 2, Gc = G / 4;
+    const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (cell >= Gm * Gm * Gm) return;
+    const int midx[3] = {cell % Gm, (cell / Gm) % Gm, cell / (Gm * Gm)};
+    const int cc = ((midx[2] >> 1) * Gc + (midx[1] >> 1)) * Gc + (midx[0] >> 1);
+    const int idx[3] = {2 * midx[0], 2 * midx[1], 2 * midx[2]};
+    const KmBox b = km_box(g, G, idx, 2);
+    const unsigned char *cand = clist + (size_t)cc * (2 + kKmCoarseMax);
+    const bool all = cand[1] != 0;
+    const int ntest = all ? k : (int)cand[0];
+    const int ny_p = (k / 8) * 8;
+    auto entry = [&](int t) -> int {
+        if (!all) return (int)cand[2 + t];
+        if (t >= ny_p) return t;
+        const int per = ny_p / 8;
+        return (t / per) + 8 * (t % per);
+    };
+    double U = INFINITY; int qs = 0;
+    const double cn2 = *cn2_in;
+    for (int t = 0; t < ntest; t++) { const int j = entry(t); const double m = km_maxd2(b, c4[j]); if (m < U) { U = m; qs = j; } }
+    const double thr = km_threshold(b, U, cn2);
+    const double margin = thr - U;                              // the absolute rounding margin of the rule (plus 1e-12 U)
+    const float4 yq = c4[qs];
+    const double q[3] = {(double)yq.x, (double)yq.y, (double)yq.z};
+    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    unsigned e = 0; int cnt = 0, last = 0;
+    for (int t = 0; t < ntest; t++) {
+        const int j = entry(t);
+        const float4 y = c4[j];
+        if (km_mind2(b, y) > thr) continue;
+        const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
+        double f = -q2, scale = q2;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double w = q[a] - p[a];
+            f += 2.0 * fmin(b.cl[a] * w, b.ch[a] * w) + p[a] * p[a];
+            const double big = fmax(fmax(fabs(b.cl[a]), fabs(b.ch[a])), fabs(p[a]));
+            scale += 4.0 * big * big;
+        }
+        if (f > margin + 1e-12 * scale) continue;                // strictly farther than q* on the whole box, beyond rounding
+        if (cnt < 4) e |= (unsigned)j << (8 * cnt);
+        last = j;
+        cnt++;
+    }
+    if (cnt > 4) e = kKmMidOverflow;
+    else for (int t = cnt; t < 4; t++) e |= (unsigned)last << (8 * t);
+    mid[cell] = e;
+}
+
+constexpr int kKmQueue = 48;                                   // parked samples per wavefront (16 B each)
+__global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k,
+                                                        int chunk_len, int nchunks, int *__restrict__ assign, unsigned int *table,
+                                                        const KmGridDev *__restrict__ gp, const unsigned int *__restrict__ mid,
+                                                        const unsigned char *__restrict__ lut) {
+    extern __shared__ unsigned int lds_u[];
+    constexpr int G = 64, Gm = 32, ncell = Gm * Gm * Gm, P = 4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned int *T = lds_u;                                                      // [ncell]
+    float4 *lc4 = (float4 *)(lds_u + ncell);                                      // [256]
+    unsigned int *cnt = lds_u + ncell + 4 * 256 + (size_t)wid * 256;              // this wavefront's counters
+    uint4 *q = (uint4 *)(lds_u + ncell + 4 * 256 + 16 * 256) + wid * kKmQueue;    // this wavefront's parked samples
+    for (int i = threadIdx.x; i < ncell / 4; i += 1024) ((uint4 *)T)[i] = ((const uint4 *)mid)[i];
+    for (int j = threadIdx.x; j < 256; j += 1024) lc4[j] = j < k ? c4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = lane; j < 256; j += 64) cnt[j] = 0u;
+    __syncthreads();
+    const KmGridDev g = *gp;
+    double glo[3], ginv[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double r = (double)g.hi[a] - (double)g.lo[a];
+        glo[a] = (double)g.lo[a];
+        ginv[a] = r > 0 ? (double)G / r : 0.0;                                    // km_cell's arithmetic
+    }
+    auto cell3 = [&](const float a0, const float a1, const float a2, int &ix, int &iy, int &iz) {
+        ix = (int)(((double)a0 - glo[0]) * ginv[0]); iy = (int)(((double)a1 - glo[1]) * ginv[1]); iz = (int)(((double)a2 - glo[2]) * ginv[2]);
+        ix = max(0, min(ix, G - 1)); iy = max(0, min(iy, G - 1)); iz = max(0, min(iz, G - 1));
+    };
+    const unsigned long long ltmask = (1ULL << lane) - 1ULL;
+    for (int chunk = blockIdx.x * 16 + wid; chunk < nchunks; chunk += gridDim.x * 16) {
+        const size_t lo = (size_t)chunk * chunk_len;
+        const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
+        int qn = 0;                                                               // wave-uniform
+        auto drain = [&]() {                                                      // parked samples through the G^3 records
+            if (lane < qn) {
+                const uint4 it = q[lane];
+                const float a0 = __uint_as_float(it.x), a1 = __uint_as_float(it.y), a2 = __uint_as_float(it.z);
+                int ix, iy, iz;
+                cell3(a0, a1, a2, ix, iy, iz);
+                const uint4 rec = reinterpret_cast<const uint4 *>(lut)[(iz * G + iy) * G + ix];
+                const int a = km_assign_pruned(a0, a1, a2, lc4, k, rec);
+                assign[lo + it.w] = a;
+                atomicAdd(&cnt[a], 1u);
+            }
+            qn = 0;
+        };
+        for (size_t base = lo; base < hi; base += 64 * P) {
+            float x0[P], x1[P], x2[P];
+            bool v[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const size_t i = base + (size_t)p * 64 + lane;
+                v[p] = i < hi;
+                const size_t j = v[p] ? i : lo;
+                x0[p] = s.x[j]; x1[p] = s.y[j]; x2[p] = s.z[j];
+            }
+            unsigned e[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                int ix, iy, iz;
+                cell3(x0[p], x1[p], x2[p], ix, iy, iz);
+                e[p] = T[((iz >> 1) * Gm + (iy >> 1)) * Gm + (ix >> 1)];
+            }
+            unsigned ovbits = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const size_t i = base + (size_t)p * 64 + lane;
+                const bool ov = v[p] && km_mid_is_overflow(e[p]);
+                ovbits |= ov ? (1u << p) : 0u;
+                // The four candidates (k % 8 == 0: no scalar leftovers), branch-free.  The reference keeps one strict-'<'
+                // tracker per SIMD lane (j & 7) over the raw dot-product form, then merges the lane minima by
+                // (clamped distance, index).  The entry is sorted by lane, so the members of a lane are adjacent: a running
+                // tracker is merged whenever the lane changes.  (distance >= 0, so its bit pattern orders like the value
+                // and {distance bits : index} compares as one 64-bit key.)
+                const float m0 = -2 * x0[p], m1 = -2 * x1[p], m2 = -2 * x2[p];
+                const float xn = __builtin_fmaf(x2[p], x2[p], __builtin_fmaf(x0[p], x0[p], x1[p] * x1[p]));
+                unsigned jj[4]; float dp[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    jj[t] = (e[p] >> (8 * t)) & 0xffu;
+                    const float4 y = lc4[jj[t]];
+                    float d = m0 * y.x;
+                    d = __builtin_fmaf(m1, y.y, d);
+                    d = __builtin_fmaf(m2, y.z, d);
+                    dp[t] = d + y.w;
+                }
+                unsigned long long key = ~0ULL;                                   // {cur_d = FLT_MAX.., cur_i = 0xFFFFFFFF}
+                float trd = dp[0]; unsigned tri = jj[0];
+                auto merge = [&](const bool doit) {
+                    float cand = trd + xn;
+                    cand = cand < 0 ? 0.f : cand;
+                    const unsigned long long kk = ((unsigned long long)__float_as_uint(cand) << 32) | tri;
+                    key = (doit && kk < key) ? kk : key;
+                };
+#pragma unroll
+                for (int t = 1; t < 4; t++) {
+                    const bool newlane = ((jj[t] ^ jj[t - 1]) & 7u) != 0u;
+                    merge(newlane);
+                    const bool better = newlane || dp[t] < trd;
+                    trd = better ? dp[t] : trd; tri = better ? jj[t] : tri;
+                }
+                merge(true);
+                const unsigned cur_i = (unsigned)key;
+                if (v[p] && !ov) { assign[i] = (int)cur_i; atomicAdd(&cnt[cur_i], 1u); }
+            }
+            if (__ballot(ovbits != 0u)) {                                         // rare enough per slot; one copy of the slow code
+#pragma unroll 1
+                for (int p = 0; p < P; p++) {
+                    const bool ov = (ovbits >> p) & 1u;
+                    const unsigned long long m = __ballot(ov);
+                    if (!m) continue;
+                    const float a0 = p == 0 ? x0[0] : p == 1 ? x0[1] : p == 2 ? x0[2] : x0[3];
+                    const float a1 = p == 0 ? x1[0] : p == 1 ? x1[1] : p == 2 ? x1[2] : x1[3];
+                    const float a2 = p == 0 ? x2[0] : p == 1 ? x2[1] : p == 2 ? x2[2] : x2[3];
+                    const unsigned rel = (unsigned)(base - lo) + (unsigned)p * 64u + (unsigned)lane;
+                    const int rank = (int)__popcll(m & ltmask), b = (int)__popcll(m);
+                    int done = 0;
+                    while (done < b) {                                            // wave-uniform
+                        const int take = min(kKmQueue - qn, b - done);
+                        if (ov && rank >= done && rank < done + take) q[qn + rank - done] = make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), rel);
+                        qn += take; done += take;
+                        if (qn == kKmQueue) drain();
+                    }
+                }
+            }
+        }
+        drain();
+        for (int j = lane; j < k; j += 64) { table[(size_t)j * nchunks + chunk] = cnt[j]; cnt[j] = 0u; }
+    }
+}
+
 // second half of the sort: samples -> (x,y,z,w) records grouped by centroid, sample order kept
 template <bool W>
 __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__restrict__ assign, size_t nx, int k, int nbits,
@@ -712,7 +909,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     // 16 M samples); few samples (the default 512^2): the full scan is cheaper than building the grid
     const size_t lut_min = getenv("PAMD_KM_LUT_MIN") ? (size_t)atoll(getenv("PAMD_KM_LUT_MIN")) : ((size_t)1 << 21);
     const bool use_lut = nx >= lut_min && k >= 16 && k <= 256;
-    const int G = nx >= ((size_t)1 << 23) ? 64 : 32;
+    const size_t g64_min = getenv("PAMD_KM_G64_MIN") ? (size_t)atoll(getenv("PAMD_KM_G64_MIN")) : ((size_t)1 << 23);
+    const int G = nx >= g64_min ? 64 : 32;
     if (use_lut) {
         static bool attr2 = false;
         if (!attr2) {
@@ -735,9 +933,30 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
                 hipLaunchKernelGGL(k_km_lut_build, ncoarse, 64, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, (const unsigned char *)w.clist.p,
                                    (const double *)cn2, w.lut.p);
             }
+            static const bool use_mid = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
+            if (G == 64 && use_mid && k % 8 == 0) {
+                const int nmid = 32 * 32 * 32;
+                w.mid.reserve(nmid);
+                {
+                    KTIME("k_km_lut_build", s, 4.0 * nmid);
+                    hipLaunchKernelGGL(k_km_lut_mid, nmid / 256, 256, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, (const unsigned char *)w.clist.p,
+                                       (const double *)(w.grid.p + 64), w.mid.p);
+                }
+                const size_t lds_mid = ((size_t)nmid + 4 * 256 + 16 * 256) * 4 + (size_t)16 * kKmQueue * 16;
+                static bool attr3 = false;
+                if (!attr3) {
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+                    attr3 = true;
+                }
+                const int mblocks = std::min(num_cus(), (nchunks + 15) / 16);
+                KTIME("k_km_assign", s, 16.0 * nx);
+                hipLaunchKernelGGL(k_km_assign_mid, mblocks, 1024, lds_mid, s, ks, nx, w.c4.p, k, chunk_len, nchunks, w.assign.p, w.table.p,
+                                   (const KmGridDev *)w.grid.p, (const unsigned int *)w.mid.p, (const unsigned char *)w.lut.p);
+            } else {
             KTIME("k_km_assign", s, 16.0 * nx);
             hipLaunchKernelGGL(k_km_assign_lut, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p,
                                (const KmGridDev *)w.grid.p, G, w.lut.p);
+            }
         } else {
             KTIME("k_km_assign", s, 16.0 * nx);
             hipLaunchKernelGGL(k_km_assign_count, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p);

@@ -337,92 +337,137 @@ __global__ __launch_bounds__(256) void k_nn_lut_mid(const double *__restrict__ p
     mid[cell] = entry;
 }
 
+// palette as three f64 arrays in LDS (6 KB): leaves room for the overflow queues next to the 128 KB table
+struct PalSoA { const double *x, *y, *z; };
+
+__device__ __forceinline__ int nn_eval_rec(const double x, const double y, const double z, LutRec<unsigned char> rec, const size_t cell,
+                                           const unsigned char *__restrict__ lut2, const PalSoA sp, const int k) {
+    const int cnt = rec.next();
+    double bd = INFINITY; int best = 0;
+    auto test = [&](const int j) {
+        const double d0 = x - sp.x[j], d1 = y - sp.y[j], d2 = z - sp.z[j];
+        const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+        if (d < bd) { bd = d; best = j; }                       // ascending j + strict '<' = lowest index on ties
+    };
+    if (cnt != 255) {
+        const int n1 = cnt < 15 ? cnt : 15;
+        for (int t = 0; t < n1; t++) test(rec.next());
+        if (cnt > 15) {
+            LutRec<unsigned char> r2;
+            r2.load(lut2 + cell * 16);
+            for (int t = 15; t < cnt; t++) test(r2.next());
+        }
+    } else {
+        for (int j = 0; j < k; j++) test(j);
+    }
+    return best;
+}
+
+constexpr int kMidQueue = 56;                                  // overflow pixels parked per wavefront (28 B each)
+constexpr size_t kMidLds = 131072 + 3 * 256 * 8 + 16 * kMidQueue * 28;
+
 template <typename OutT, int P>
 __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ c, size_t N, size_t n, const double *__restrict__ pal, int k,
                                                      NNGrid g, const unsigned int *__restrict__ mid, const unsigned char *__restrict__ lut,
                                                      const unsigned char *__restrict__ lut2, OutT *__restrict__ out) {
     extern __shared__ unsigned char smem_mid[];
-    const int Gm = g.G / 2, ncell = Gm * Gm * Gm;
+    constexpr int Gm = 32, ncell = Gm * Gm * Gm;                                  // g.G == 64
     unsigned int *T = (unsigned int *)smem_mid;                                  // [ncell]
-    double4 *spal = (double4 *)(smem_mid + (size_t)ncell * 4);                    // [256]
-    uint2 *queue = (uint2 *)(smem_mid + (size_t)ncell * 4 + 256 * sizeof(double4));
+    double *spx = (double *)(smem_mid + (size_t)ncell * 4), *spy = spx + 256, *spz = spy + 256;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint2 *q = queue + wid * 128;                                                 // this wavefront's overflow queue: {pixel, G^3 cell}
+    // this wavefront's overflow queue: coordinates and pixel index of up to kMidQueue pixels
+    double *qx = spz + 256 + wid * 3 * kMidQueue, *qy = qx + kMidQueue, *qz = qy + kMidQueue;
+    unsigned int *qi = (unsigned int *)(spz + 256 + 16 * 3 * kMidQueue) + wid * kMidQueue;
+    const PalSoA sp{spx, spy, spz};
+
+    const size_t tile = (size_t)1024 * P, step = (size_t)gridDim.x * tile;
+    double nx[P], ny[P], nz[P];
+    auto fetch = [&](size_t base) {
+        const double *cb = c + base;                                              // wave-uniform base + 32-bit lane offset
+        if (base + tile <= n) {
+#pragma unroll
+            for (int p = 0; p < P; p++) { const unsigned t = p * 1024u + threadIdx.x; nx[p] = cb[t]; ny[p] = cb[N + t]; nz[p] = cb[2 * N + t]; }
+        } else {
+            const unsigned last = (unsigned)(n - base - 1);
+#pragma unroll
+            for (int p = 0; p < P; p++) { const unsigned t = min(p * 1024u + threadIdx.x, last); nx[p] = cb[t]; ny[p] = cb[N + t]; nz[p] = cb[2 * N + t]; }
+        }
+    };
+    size_t base = (size_t)blockIdx.x * tile;
+    if (base < n) fetch(base);                                                    // in flight while the table is copied in
     for (int i = threadIdx.x; i < ncell / 4; i += 1024) ((uint4 *)T)[i] = ((const uint4 *)mid)[i];
-    for (int j = threadIdx.x; j < 256; j += 1024) spal[j] = j < k ? make_double4(pal[j], pal[k + j], pal[2 * k + j], 0.0) : make_double4(0, 0, 0, 0);
+    for (int j = threadIdx.x; j < 256; j += 1024) {
+        const bool in = j < k;
+        spx[j] = in ? pal[j] : 0.0; spy[j] = in ? pal[k + j] : 0.0; spz[j] = in ? pal[2 * k + j] : 0.0;
+    }
     __syncthreads();
     const int G = g.G;
     const double lo0 = g.lo[0], lo1 = g.lo[1], lo2 = g.lo[2], in0 = g.inv[0], in1 = g.inv[1], in2 = g.inv[2];
     const unsigned long long ltmask = (1ULL << lane) - 1ULL;
+    auto slow = [&](const double x, const double y, const double z, const size_t i) {      // through the G^3 records
+        const size_t cell = nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2);
+        LutRec<unsigned char> r;
+        r.load(lut + cell * 16);
+        out[i] = (OutT)nn_eval_rec(x, y, z, r, cell, lut2, sp, k);
+    };
     int qn = 0;                                                                   // wave-uniform
-    auto drain = [&](const uint2 *src, int cnt) {
-        if (lane < cnt) {
-            const uint2 it = src[lane];
-            const size_t i = it.x, cell = it.y;
-            LutRec<unsigned char> r;
-            r.load(lut + cell * 16);
-            const double x = c[i], y = c[N + i], z = c[2 * N + i];
-            out[i] = (OutT)nn_eval<unsigned char>(x, y, z, r, cell, lut2, spal, k);
-        }
-    };
-    const size_t tile = (size_t)1024 * P, step = (size_t)gridDim.x * tile;
-    double nx[P], ny[P], nz[P];
-    auto fetch = [&](size_t base) {
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const size_t i = base + (size_t)p * 1024 + threadIdx.x;
-            const size_t j = i < n ? i : n - 1;
-            nx[p] = c[j]; ny[p] = c[N + j]; nz[p] = c[2 * N + j];
-        }
-    };
-    size_t base = (size_t)blockIdx.x * tile;
-    if (base < n) fetch(base);
     for (; base < n; base += step) {
         double x[P], y[P], z[P];
 #pragma unroll
         for (int p = 0; p < P; p++) { x[p] = nx[p]; y[p] = ny[p]; z[p] = nz[p]; }
         if (base + step < n) fetch(base + step);                                  // the next tile's pixels are in flight during this one
-        unsigned e[P], fc[P];
+        const unsigned left = (unsigned)min((size_t)tile, n - base);
+        OutT *ob = out + base;
+        unsigned e[P];
 #pragma unroll
         for (int p = 0; p < P; p++) {
             int ix = (int)((x[p] - lo0) * in0), iy = (int)((y[p] - lo1) * in1), iz = (int)((z[p] - lo2) * in2);
             ix = max(0, min(ix, G - 1));
             iy = max(0, min(iy, G - 1));
             iz = max(0, min(iz, G - 1));
-            fc[p] = (unsigned)((iz * G + iy) * G + ix);
             e[p] = T[((iz >> 1) * Gm + (iy >> 1)) * Gm + (ix >> 1)];
         }
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            const size_t i = base + (size_t)p * 1024 + threadIdx.x;
-            const bool ok = i < n;
+            const unsigned t = p * 1024u + threadIdx.x;
+            const size_t i = base + t;
+            const bool ok = t < left;
             const int j0 = (int)(e[p] & 0xffu), j1 = (int)((e[p] >> 8) & 0xffu), j2 = (int)((e[p] >> 16) & 0xffu), j3 = (int)(e[p] >> 24);
             const bool ov = ok && j0 > j1;
             int best = j0;
             {
-                double4 pp = spal[j0];
-                double d0 = x[p] - pp.x, d1 = y[p] - pp.y, d2 = z[p] - pp.z;
+                double d0 = x[p] - spx[j0], d1 = y[p] - spy[j0], d2 = z[p] - spz[j0];
                 double bd = (d0 * d0 + d1 * d1) + d2 * d2;
-                pp = spal[j1]; d0 = x[p] - pp.x; d1 = y[p] - pp.y; d2 = z[p] - pp.z;
+                d0 = x[p] - spx[j1]; d1 = y[p] - spy[j1]; d2 = z[p] - spz[j1];
                 double d = (d0 * d0 + d1 * d1) + d2 * d2;
                 if (d < bd) { bd = d; best = j1; }
-                pp = spal[j2]; d0 = x[p] - pp.x; d1 = y[p] - pp.y; d2 = z[p] - pp.z;
+                d0 = x[p] - spx[j2]; d1 = y[p] - spy[j2]; d2 = z[p] - spz[j2];
                 d = (d0 * d0 + d1 * d1) + d2 * d2;
                 if (d < bd) { bd = d; best = j2; }
-                pp = spal[j3]; d0 = x[p] - pp.x; d1 = y[p] - pp.y; d2 = z[p] - pp.z;
+                d0 = x[p] - spx[j3]; d1 = y[p] - spy[j3]; d2 = z[p] - spz[j3];
                 d = (d0 * d0 + d1 * d1) + d2 * d2;
                 if (d < bd) { bd = d; best = j3; }
             }
-            if (ok && !ov) out[i] = (OutT)best;
+            if (ok && !ov) ob[t] = (OutT)best;
             const unsigned long long m = __ballot(ov);
             if (m) {                                                              // wave-uniform
-                if (ov) q[qn + (int)__popcll(m & ltmask)] = make_uint2((unsigned int)i, fc[p]);
-                qn += (int)__popcll(m);
-                if (qn >= 64) { qn -= 64; drain(q + qn, 64); }
+                const int b = (int)__popcll(m);
+                if (qn + b > kMidQueue) {                                         // make room: the parked pixels go now
+                    if (lane < qn) slow(qx[lane], qy[lane], qz[lane], qi[lane]);
+                    qn = 0;
+                }
+                if (b > kMidQueue) { if (ov) slow(x[p], y[p], z[p], i); }        // a crowded palette: nothing to gain from parking
+                else {
+                    if (ov) {
+                        const int s = qn + (int)__popcll(m & ltmask);
+                        qx[s] = x[p]; qy[s] = y[p]; qz[s] = z[p]; qi[s] = (unsigned int)i;
+                    }
+                    qn += b;
+                }
             }
         }
     }
-    if (qn > 0) drain(q, qn);
+    if (lane < qn) slow(qx[lane], qy[lane], qz[lane], qi[lane]);
 }
 
 __global__ __launch_bounds__(256) void k_minmax3(const double *__restrict__ c, size_t N, size_t n, unsigned long long *keys /* min[3], max[3] */) {
@@ -478,7 +523,7 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
                 hipLaunchKernelGGL(k_nn_lut_mid, (nmid + 255) / 256, 256, 0, s, d_pal, k, g, (const unsigned char *)w.clist.p, w.mid.p);
             }
             constexpr int P = 2;
-            const size_t lds_mid = (size_t)nmid * 4 + 256 * sizeof(double4) + 16 * 128 * sizeof(uint2);
+            const size_t lds_mid = kMidLds;
             static bool attr_mid = false;
             if (!attr_mid) {
                 HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_mid<OutT, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));

@@ -96,12 +96,15 @@ def test_quantize_clusters_matches_oracle(gpu, ob, case):
     assert np.allclose(got, ref, rtol=0, atol=1e-9 * scale, equal_nan=True), np.nanmax(np.abs(got - ref))
 
 
-@pytest.mark.parametrize("pruned", [False, True])
+@pytest.mark.parametrize("pruned", [0, 1, 2])
 def test_kmeans_bit_exact_vs_reference_faiss_golden(gpu, monkeypatch, pruned):
-    """Centroids bit-identical to the reference's faiss; `pruned` forces the grid-pruned assignment (normally used
-    from 2 M samples on) onto these small cases (k < 16 keeps the full scan)."""
+    """Centroids bit-identical to the reference's faiss; `pruned` = 1 forces the grid-pruned assignment (normally used
+    from 2 M samples on) onto these small cases (k < 16 keeps the full scan), 2 also forces the 64^3 grid with the
+    four-candidate table held in LDS (normally from 8 M samples on)."""
     if pruned:
         monkeypatch.setenv("PAMD_KM_LUT_MIN", "1")
+    if pruned == 2:
+        monkeypatch.setenv("PAMD_KM_G64_MIN", "1")
     g = golden("kmeans_ref.npz")
     for ci, (n, k, niter, max_samples, weighted, seed, plant) in enumerate(g["cases"]):
         n, k = int(n), int(k)
@@ -114,9 +117,13 @@ def test_kmeans_bit_exact_vs_reference_faiss_golden(gpu, monkeypatch, pruned):
             ci, int(np.sum(got.view(np.uint32) != ref.view(np.uint32))))
 
 
-@pytest.mark.parametrize("cs,k,weighted", [("srgb_to_ictcp", 256, False), ("srgb_to_cieluv", 200, True), ("srgb_to_ictcp", 61, False)])
-def test_kmeans_pruned_assignment_many_samples(gpu, ob, cs, k, weighted):
-    """2.2 M samples, all clustered: the grid-pruned assignment (automatic at this size) against the oracle's full scans."""
+@pytest.mark.parametrize("cs,k,weighted,g64", [("srgb_to_ictcp", 256, False, False), ("srgb_to_cieluv", 200, True, False), ("srgb_to_ictcp", 61, False, False),
+                                               ("srgb_to_ictcp", 256, False, True), ("srgb_to_cieluv", 203, True, True)])
+def test_kmeans_pruned_assignment_many_samples(gpu, ob, monkeypatch, cs, k, weighted, g64):
+    """2.2 M samples, all clustered: the grid-pruned assignment (automatic at this size) against the oracle's full scans;
+    `g64` takes the path of 8 M samples and more (64^3 grid, four-candidate table in LDS, parked overflow samples)."""
+    if g64:
+        monkeypatch.setenv("PAMD_KM_G64_MIN", "1")
     n = 2200000
     flat = ob.convert(cs, ob.image(n, 31))
     w = ob.weights(n, 31) if weighted else None
