@@ -330,18 +330,37 @@ __global__ __launch_bounds__(64) void k_km_lut_build(const float4 *__restrict__ 
         const int per = ny_p / 8;
         return (t / per) + 8 * (t % per);
     };
-    double U = INFINITY;
+    double U = INFINITY; int qs = 0;
     const double cn2 = *cn2_in;                                   // over all centroids, from the coarse pass
-    for (int t = 0; t < ntest; t++) U = fmin(U, km_maxd2(b, c4[entry(t)]));
+    for (int t = 0; t < ntest; t++) { const int j = entry(t); const double m = km_maxd2(b, c4[j]); if (m < U) { U = m; qs = j; } }
     const double thr = km_threshold(b, U, cn2);
+    const double margin = thr - U;
+    const float4 yq = c4[qs];
+    const double q[3] = {(double)yq.x, (double)yq.y, (double)yq.z};
+    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
     unsigned char rec[16];
-    int cnt = 0;
+    int cnt = 0, last = 0;
     for (int t = 0; t < ntest; t++) {
         const int j = entry(t);
-        if (km_mind2(b, c4[j]) <= thr) { if (cnt < 15) rec[1 + cnt] = (unsigned char)j; cnt++; }
+        const float4 y = c4[j];
+        if (km_mind2(b, y) > thr) continue;
+        // second rule (see k_km_lut_mid): its computed distance exceeds q*'s on the whole box
+        const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
+        double f = -q2, scale = q2;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double w = q[a] - p[a];
+            f += 2.0 * fmin(b.cl[a] * w, b.ch[a] * w) + p[a] * p[a];
+            const double big = fmax(fmax(fabs(b.cl[a]), fabs(b.ch[a])), fabs(p[a]));
+            scale += 4.0 * big * big;
+        }
+        if (f > margin + 1e-12 * scale) continue;
+        if (cnt < 15) rec[1 + cnt] = (unsigned char)j;
+        last = j;
+        cnt++;
     }
     rec[0] = (unsigned char)(cnt <= 15 ? cnt : 255);
-    for (int t = cnt < 15 ? cnt + 1 : 16; t < 16; t++) rec[t] = 0;
+    for (int t = cnt < 15 ? cnt + 1 : 16; t < 16; t++) rec[t] = (unsigned char)last;   // padding repeats the last entry
     uint4 out;
     out.x = rec[0] | (rec[1] << 8) | (rec[2] << 16) | ((unsigned)rec[3] << 24);
     out.y = rec[4] | (rec[5] << 8) | (rec[6] << 16) | ((unsigned)rec[7] << 24);
@@ -494,6 +513,53 @@ __global__ __launch_bounds__(256) void k_km_lut_mid(const float4 *__restrict__ c
     mid[cell] = e;
 }
 
+// A record of the G^3 table for k % 8 == 0, without branches per candidate: the first four entries unconditionally (the
+// record is padded with its last entry), the rest only if some lane of the wavefront holds more.  Same arithmetic and
+// merge rule as km_assign_pruned.
+__device__ __forceinline__ int km_assign_rec4(const float x0, const float x1, const float x2, const float4 *c4, const int k, const uint4 rec) {
+    const int cnt = (int)(rec.x & 0xffu);
+    if (cnt == 255) return km_assign_one(x0, x1, x2, c4, k);
+    const float m0 = -2 * x0, m1 = -2 * x1, m2 = -2 * x2;
+    const float xn = __builtin_fmaf(x2, x2, __builtin_fmaf(x0, x0, x1 * x1));
+    auto dot = [&](const unsigned j) {
+        const float4 y = c4[j];
+        float d = m0 * y.x;
+        d = __builtin_fmaf(m1, y.y, d);
+        d = __builtin_fmaf(m2, y.z, d);
+        return d + y.w;
+    };
+    unsigned long long key = ~0ULL;
+    unsigned prev = (rec.x >> 8) & 0xffu, tri = prev;
+    float trd = dot(prev);
+    auto merge = [&](const bool doit) {
+        float cand = trd + xn;
+        cand = cand < 0 ? 0.f : cand;
+        const unsigned long long kk = ((unsigned long long)__float_as_uint(cand) << 32) | tri;
+        key = (doit && kk < key) ? kk : key;
+    };
+    auto step = [&](const unsigned j) {
+        const bool newlane = ((j ^ prev) & 7u) != 0u;
+        merge(newlane);
+        const float d = dot(j);
+        const bool better = newlane || d < trd;
+        trd = better ? d : trd; tri = better ? j : tri;
+        prev = j;
+    };
+    step((rec.x >> 16) & 0xffu); step(rec.x >> 24); step(rec.y & 0xffu);
+    if (__any(cnt > 4)) {
+        unsigned long long w0 = ((unsigned long long)rec.z << 32) | rec.y, w1 = rec.w;     // bytes 4.. of the record
+        w0 = (w0 >> 8) | ((w1 & 0xffULL) << 56); w1 >>= 8;                                 // byte 4 (entry 3) is done
+        for (int t = 4; t < 15; t++) {
+            if (!__any(t < cnt)) break;
+            const unsigned j = (unsigned)(w0 & 0xffULL);
+            w0 = (w0 >> 8) | ((w1 & 0xffULL) << 56); w1 >>= 8;
+            if (t < cnt) step(j);
+        }
+    }
+    merge(true);
+    return (int)(unsigned)key;
+}
+
 constexpr int kKmQueue = 48;                                   // parked samples per wavefront (16 B each)
 __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k,
                                                         int chunk_len, int nchunks, int *__restrict__ assign, unsigned int *table,
@@ -527,28 +593,31 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
         const size_t lo = (size_t)chunk * chunk_len;
         const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
         int qn = 0;                                                               // wave-uniform
-        auto drain = [&]() {                                                      // parked samples through the G^3 records
-            if (lane < qn) {
-                const uint4 it = q[lane];
+        auto count = [&](const unsigned a) { atomicAdd(&cnt[a], 1u); };
+        auto drain = [&](const int first, const int n) {                          // parked samples through the G^3 records
+            if (lane < n) {
+                const uint4 it = q[first + lane];
                 const float a0 = __uint_as_float(it.x), a1 = __uint_as_float(it.y), a2 = __uint_as_float(it.z);
                 int ix, iy, iz;
                 cell3(a0, a1, a2, ix, iy, iz);
                 const uint4 rec = reinterpret_cast<const uint4 *>(lut)[(iz * G + iy) * G + ix];
-                const int a = km_assign_pruned(a0, a1, a2, lc4, k, rec);
+                const int a = km_assign_rec4(a0, a1, a2, lc4, k, rec);
                 assign[lo + it.w] = a;
-                atomicAdd(&cnt[a], 1u);
+                count((unsigned)a);
             }
-            qn = 0;
         };
         for (size_t base = lo; base < hi; base += 64 * P) {
             float x0[P], x1[P], x2[P];
             bool v[P];
+            const unsigned left = (unsigned)min((size_t)(64 * P), hi - base);    // wave-uniform base + 32-bit lane offsets
+            const float *bx = s.x + base, *by = s.y + base, *bz = s.z + base;
+            int *ba = assign + base;
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                const size_t i = base + (size_t)p * 64 + lane;
-                v[p] = i < hi;
-                const size_t j = v[p] ? i : lo;
-                x0[p] = s.x[j]; x1[p] = s.y[j]; x2[p] = s.z[j];
+                const unsigned t = (unsigned)p * 64u + (unsigned)lane;
+                v[p] = t < left;
+                const unsigned j = min(t, left - 1u);
+                x0[p] = bx[j]; x1[p] = by[j]; x2[p] = bz[j];
             }
             unsigned e[P];
 #pragma unroll
@@ -560,7 +629,6 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
             unsigned ovbits = 0;
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                const size_t i = base + (size_t)p * 64 + lane;
                 const bool ov = v[p] && km_mid_is_overflow(e[p]);
                 ovbits |= ov ? (1u << p) : 0u;
                 // The four candidates (k % 8 == 0: no scalar leftovers), branch-free.  The reference keeps one strict-'<'
@@ -597,10 +665,10 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
                 }
                 merge(true);
                 const unsigned cur_i = (unsigned)key;
-                if (v[p] && !ov) { assign[i] = (int)cur_i; atomicAdd(&cnt[cur_i], 1u); }
+                if (v[p] && !ov) { ba[(unsigned)p * 64u + (unsigned)lane] = (int)cur_i; count(cur_i); }
             }
             if (__ballot(ovbits != 0u)) {                                         // rare enough per slot; one copy of the slow code
-#pragma unroll 1
+#pragma unroll
                 for (int p = 0; p < P; p++) {
                     const bool ov = (ovbits >> p) & 1u;
                     const unsigned long long m = __ballot(ov);
@@ -615,12 +683,12 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
                         const int take = min(kKmQueue - qn, b - done);
                         if (ov && rank >= done && rank < done + take) q[qn + rank - done] = make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), rel);
                         qn += take; done += take;
-                        if (qn == kKmQueue) drain();
+                        if (qn == kKmQueue) { drain(0, qn); qn = 0; }
                     }
                 }
             }
         }
-        drain();
+        drain(0, qn);
         for (int j = lane; j < k; j += 64) { table[(size_t)j * nchunks + chunk] = cnt[j]; cnt[j] = 0u; }
     }
 }

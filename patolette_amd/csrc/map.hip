@@ -134,30 +134,42 @@ __global__ __launch_bounds__(64) void k_nn_lut_build(const double *__restrict__ 
         ch[a] = g.lo[a] + (idx[a] + 1) * g.cw[a] + m;
     }
     const double *px = pal, *py = pal + k, *pz = pal + 2 * k;
-    double U = INFINITY;                                        // the entry that attains the minimum survives the coarse rule
+    double U = INFINITY; int qs = 0;                            // the entry that attains the minimum survives the coarse rule
     for (int t = 0; t < ntest; t++) {
         const int j = all ? t : (int)cand[1 + t];
         const double p[3] = {px[j], py[j], pz[j]};
         double mx = 0;
 #pragma unroll
         for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - cl[a]), fabs(p[a] - ch[a])); mx += d * d; }
-        U = fmin(U, mx);
+        if (mx < U) { U = mx; qs = j; }
     }
     const double thr = U * (1.0 + 1e-12) + 1e-300;
+    const double q[3] = {px[qs], py[qs], pz[qs]};
+    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
     CandT *rec = lut + (size_t)cell * 16, *rec2 = lut2 + (size_t)cell * 16;
-    int cnt = 0;
+    int cnt = 0, last = 0;
     for (int t = 0; t < ntest; t++) {
         const int j = all ? t : (int)cand[1 + t];
         const double p[3] = {px[j], py[j], pz[j]};
-        double mn = 0;
+        // second rule (see k_nn_lut_mid): dropped when strictly farther than q* on the whole box
+        double mn = 0, f = -q2, scale = q2;
 #pragma unroll
-        for (int a = 0; a < 3; a++) { const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0); mn += d * d; }
-        if (mn <= thr) {
+        for (int a = 0; a < 3; a++) {
+            const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0);
+            mn += d * d;
+            const double w = q[a] - p[a];
+            f += 2.0 * fmin(cl[a] * w, ch[a] * w) + p[a] * p[a];
+            const double big = fmax(fmax(fabs(cl[a]), fabs(ch[a])), fabs(p[a]));
+            scale += 4.0 * big * big;
+        }
+        if (mn <= thr && !(f > 1e-12 * scale + 1e-300)) {
             if (cnt < 15) rec[1 + cnt] = (CandT)j;
             else if (cnt < kLutMax) rec2[cnt - 15] = (CandT)j;
+            last = j;
             cnt++;
         }
     }
+    for (int t = cnt; t < 15; t++) rec[1 + t] = (CandT)last;     // padding repeats the last entry: harmless to evaluate
     rec[0] = (CandT)(cnt <= kLutMax ? cnt : 255);              // 255 = overflow -> full scan
 }
 
@@ -350,8 +362,12 @@ __device__ __forceinline__ int nn_eval_rec(const double x, const double y, const
         if (d < bd) { bd = d; best = j; }                       // ascending j + strict '<' = lowest index on ties
     };
     if (cnt != 255) {
+        // the first four unconditionally (records are padded with their last entry; 99 % of them hold no more), the rest
+        // only if some lane of the wavefront has more
+        test(rec.next()); test(rec.next()); test(rec.next()); test(rec.next());
+        if (!__any(cnt > 4)) return best;
         const int n1 = cnt < 15 ? cnt : 15;
-        for (int t = 0; t < n1; t++) test(rec.next());
+        for (int t = 4; t < n1; t++) test(rec.next());
         if (cnt > 15) {
             LutRec<unsigned char> r2;
             r2.load(lut2 + cell * 16);
