@@ -310,10 +310,89 @@ __global__ __launch_bounds__(64) void k_km_lut_coarse(const float4 *__restrict__
     if (lane == 0) { out[0] = (unsigned char)(cnt <= kKmCoarseMax ? cnt : 0); out[1] = (unsigned char)(cnt <= kKmCoarseMax ? 0 : 1); }   // flag 1: test all
 }
 
+// --------------------------------------------------------------------------------------------
+// Many samples (G = 64): like the palette map, the per-sample lookup is served from LDS.  A 32^3 table of four-byte
+// entries (up to four candidates in the order the reference visits them: SIMD lane, then index, leftovers last; padded by
+// repeating the last one, which changes nothing) is filled by the rule above plus a bisector test against q* = the
+// centroid with the smallest maxdist: p is dropped when |x-p|^2 - |x-q*|^2 exceeds the rounding margin on the whole box,
+// i.e. its COMPUTED distance is strictly larger than q*'s everywhere in the cell, so it loses every comparison that
+// matters (it can never be the winner, and whatever it displaces inside its SIMD lane was no winner either).  Samples of
+// cells with more than four survivors are parked (coordinates + index, 16 bytes) in a per-wavefront LDS queue and go
+// through the 16-byte records of the G^3 table with full wavefronts.
+// --------------------------------------------------------------------------------------------
+constexpr unsigned kKmMidOverflow = 0x00010000u;               // bytes {0, 0, 1, 0}: impossible for a padded list
+__device__ __forceinline__ bool km_mid_is_overflow(unsigned e) { return (e & 0xffu) == ((e >> 8) & 0xffu) && ((e >> 8) & 0xffu) != ((e >> 16) & 0xffu); }
+
+// One wavefront fills the eight cells of the 32^3 table inside one coarse block: lane = (cell << 3) | slice, the eight lanes
+// of a cell share the list (slice s takes positions s, s + 8, ...); list order is kept through the ballots.
+__device__ __forceinline__ void km_mid_entries(const float4 *__restrict__ c4, const int k, const KmGridDev &g, const int G,
+                                               const unsigned char *__restrict__ cand, const double cn2, const int c0, const int c1, const int c2,
+                                               unsigned int *__restrict__ mid) {
+    const int lane = (int)threadIdx.x, m = lane >> 3, sl = lane & 7;
+    const int midx[3] = {2 * c0 + (m & 1), 2 * c1 + ((m >> 1) & 1), 2 * c2 + (m >> 2)};
+    const int idx[3] = {2 * midx[0], 2 * midx[1], 2 * midx[2]};
+    const KmBox b = km_box(g, G, idx, 2);
+    const bool all = cand[1] != 0;
+    const int ntest = all ? k : (int)cand[0];
+    const int ny_p = (k / 8) * 8;
+    auto entry = [&](int t) -> int {
+        if (!all) return (int)cand[2 + t];
+        if (t >= ny_p) return t;
+        const int per = ny_p / 8;
+        return (t / per) + 8 * (t % per);
+    };
+    double U = INFINITY; int qs = 0x7fffffff;
+    for (int t = sl; t < ntest; t += 8) { const int j = entry(t); const double mx = km_maxd2(b, c4[j]); if (mx < U) { U = mx; qs = j; } }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const double u2 = __shfl_xor(U, o, 64); const int q2i = __shfl_xor(qs, o, 64);
+        if (u2 < U || (u2 == U && q2i < qs)) { U = u2; qs = q2i; }
+    }
+    const double thr = km_threshold(b, U, cn2);
+    const double margin = thr - U;                              // the absolute rounding margin of the rule (plus 1e-12 U)
+    const float4 yq = c4[qs];
+    const double q[3] = {(double)yq.x, (double)yq.y, (double)yq.z};
+    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    unsigned e = 0; int cnt = 0;
+    for (int t0 = 0; t0 < ntest; t0 += 8) {
+        const int t = t0 + sl;
+        bool keep = false; int j = 0;
+        if (t < ntest) {
+            j = entry(t);
+            const float4 y = c4[j];
+            if (km_mind2(b, y) <= thr) {
+                const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
+                double f = -q2, scale = q2;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const double w = q[a] - p[a];
+                    f += 2.0 * fmin(b.cl[a] * w, b.ch[a] * w) + p[a] * p[a];
+                    const double big = fmax(fmax(fabs(b.cl[a]), fabs(b.ch[a])), fabs(p[a]));
+                    scale += 4.0 * big * big;
+                }
+                keep = !(f > margin + 1e-12 * scale);            // else: strictly farther than q* on the whole box, beyond rounding
+            }
+        }
+        const unsigned bits = (unsigned)((__ballot(keep) >> (8 * m)) & 0xffULL);
+        const int pos = cnt + __popc(bits & ((1u << sl) - 1u));
+        if (keep && pos < 4) e |= (unsigned)j << (8 * pos);
+        cnt += __popc(bits);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) e |= (unsigned)__shfl_xor((int)e, o, 64);
+    if (cnt > 4) e = kKmMidOverflow;
+    else {
+        const unsigned last = (e >> (8 * (cnt - 1))) & 0xffu;
+        for (int t = cnt; t < 4; t++) e |= last << (8 * t);
+    }
+    const int Gm = G / 2;
+    if (sl == 0) mid[(midx[2] * Gm + midx[1]) * Gm + midx[0]] = e;
+}
+
 // Fine pass: one wavefront per coarse block, lane = one of its 64 cells (uniform candidate list).
 __global__ __launch_bounds__(64) void k_km_lut_build(const float4 *__restrict__ c4, int k, const KmGridDev *__restrict__ gp, int G,
                                                      const unsigned char *__restrict__ clist, const double *__restrict__ cn2_in,
-                                                     unsigned char *__restrict__ lut) {
+                                                     unsigned char *__restrict__ lut, unsigned int *__restrict__ mid) {
     const KmGridDev g = *gp;
     const int Gc = G / 4, cc = (int)blockIdx.x, t64 = (int)threadIdx.x;
     const int idx[3] = {4 * (cc % Gc) + (t64 & 3), 4 * ((cc / Gc) % Gc) + ((t64 >> 2) & 3), 4 * (cc / (Gc * Gc)) + (t64 >> 4)};
@@ -367,6 +446,7 @@ __global__ __launch_bounds__(64) void k_km_lut_build(const float4 *__restrict__ 
     out.z = rec[8] | (rec[9] << 8) | (rec[10] << 16) | ((unsigned)rec[11] << 24);
     out.w = rec[12] | (rec[13] << 8) | (rec[14] << 16) | ((unsigned)rec[15] << 24);
     reinterpret_cast<uint4 *>(lut)[cell] = out;
+    if (mid != nullptr) km_mid_entries(c4, k, g, G, cand, cn2, cc % Gc, (cc / Gc) % Gc, cc / (Gc * Gc), mid);
 }
 
 __device__ __forceinline__ int km_assign_pruned(const float x0, const float x1, const float x2, const float4 *c4, const int k, const uint4 rec) {
@@ -445,72 +525,6 @@ __global__ __launch_bounds__(256) void k_km_assign_lut(KmSamples s, size_t nx, c
         if (v && (m & ((1ULL << lane) - 1ULL)) == 0ULL) cnt[a] += (unsigned)__popcll(m);   // group leader; distinct addresses
     }
     for (int j = lane; j < k; j += 64) table[(size_t)j * nchunks + chunk] = cnt[j];
-}
-
-// --------------------------------------------------------------------------------------------
-// Many samples (G = 64): like the palette map, the per-sample lookup is served from LDS.  A 32^3 table of four-byte
-// entries (up to four candidates in the order the reference visits them: SIMD lane, then index, leftovers last; padded by
-// repeating the last one, which changes nothing) is filled by the rule above plus a bisector test against q* = the
-// centroid with the smallest maxdist: p is dropped when |x-p|^2 - |x-q*|^2 exceeds the rounding margin on the whole box,
-// i.e. its COMPUTED distance is strictly larger than q*'s everywhere in the cell, so it loses every comparison that
-// matters (it can never be the winner, and whatever it displaces inside its SIMD lane was no winner either).  Samples of
-// cells with more than four survivors are parked (coordinates + index, 16 bytes) in a per-wavefront LDS queue and go
-// through the 16-byte records of the G^3 table with full wavefronts.
-// --------------------------------------------------------------------------------------------
-constexpr unsigned kKmMidOverflow = 0x00010000u;               // bytes {0, 0, 1, 0}: impossible for a padded list
-__device__ __forceinline__ bool km_mid_is_overflow(unsigned e) { return (e & 0xffu) == ((e >> 8) & 0xffu) && ((e >> 8) & 0xffu) != ((e >> 16) & 0xffu); }
-
-__global__ __launch_bounds__(256) void k_km_lut_mid(const float4 *__restrict__ c4, int k, const KmGridDev *__restrict__ gp, int G,
-                                                    const unsigned char *__restrict__ clist, const double *__restrict__ cn2_in,
-                                                    unsigned int *__restrict__ mid) {
-    const KmGridDev g = *gp;
-    const int Gm = G / 2, Gc = G / 4;
-    const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (cell >= Gm * Gm * Gm) return;
-    const int midx[3] = {cell % Gm, (cell / Gm) % Gm, cell / (Gm * Gm)};
-    const int cc = ((midx[2] >> 1) * Gc + (midx[1] >> 1)) * Gc + (midx[0] >> 1);
-    const int idx[3] = {2 * midx[0], 2 * midx[1], 2 * midx[2]};
-    const KmBox b = km_box(g, G, idx, 2);
-    const unsigned char *cand = clist + (size_t)cc * (2 + kKmCoarseMax);
-    const bool all = cand[1] != 0;
-    const int ntest = all ? k : (int)cand[0];
-    const int ny_p = (k / 8) * 8;
-    auto entry = [&](int t) -> int {
-        if (!all) return (int)cand[2 + t];
-        if (t >= ny_p) return t;
-        const int per = ny_p / 8;
-        return (t / per) + 8 * (t % per);
-    };
-    double U = INFINITY; int qs = 0;
-    const double cn2 = *cn2_in;
-    for (int t = 0; t < ntest; t++) { const int j = entry(t); const double m = km_maxd2(b, c4[j]); if (m < U) { U = m; qs = j; } }
-    const double thr = km_threshold(b, U, cn2);
-    const double margin = thr - U;                              // the absolute rounding margin of the rule (plus 1e-12 U)
-    const float4 yq = c4[qs];
-    const double q[3] = {(double)yq.x, (double)yq.y, (double)yq.z};
-    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-    unsigned e = 0; int cnt = 0, last = 0;
-    for (int t = 0; t < ntest; t++) {
-        const int j = entry(t);
-        const float4 y = c4[j];
-        if (km_mind2(b, y) > thr) continue;
-        const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
-        double f = -q2, scale = q2;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const double w = q[a] - p[a];
-            f += 2.0 * fmin(b.cl[a] * w, b.ch[a] * w) + p[a] * p[a];
-            const double big = fmax(fmax(fabs(b.cl[a]), fabs(b.ch[a])), fabs(p[a]));
-            scale += 4.0 * big * big;
-        }
-        if (f > margin + 1e-12 * scale) continue;                // strictly farther than q* on the whole box, beyond rounding
-        if (cnt < 4) e |= (unsigned)j << (8 * cnt);
-        last = j;
-        cnt++;
-    }
-    if (cnt > 4) e = kKmMidOverflow;
-    else for (int t = cnt; t < 4; t++) e |= (unsigned)last << (8 * t);
-    mid[cell] = e;
 }
 
 // A record of the G^3 table for k % 8 == 0, without branches per candidate: the first four entries unconditionally (the
@@ -991,6 +1005,9 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         { KTIME("k_km_bounds", s, 12.0 * nx); hipLaunchKernelGGL(k_km_bounds, (int)std::min<size_t>(ceil_div(nx, 256), 2048), 256, 0, s, ks, nx, w.bkeys.p); }
         hipLaunchKernelGGL(k_km_bounds_fold, 1, 64, 0, s, w.bkeys.p, (KmGridDev *)w.grid.p);
     }
+    static const bool mid_enabled = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
+    const bool use_mid = use_lut && G == 64 && mid_enabled && k % 8 == 0;    // four-candidate table in LDS
+    if (use_mid) w.mid.reserve(32 * 32 * 32);
     for (int it = 0; it < niter; it++) {
         if (use_lut) {
             {
@@ -999,17 +1016,10 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
                 double *cn2 = (double *)(w.grid.p + 64);                  // a scalar next to the bounding box
                 hipLaunchKernelGGL(k_km_lut_coarse, ncoarse, 64, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, w.clist.p, cn2);
                 hipLaunchKernelGGL(k_km_lut_build, ncoarse, 64, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, (const unsigned char *)w.clist.p,
-                                   (const double *)cn2, w.lut.p);
+                                   (const double *)cn2, w.lut.p, use_mid ? w.mid.p : (unsigned int *)nullptr);
             }
-            static const bool use_mid = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
-            if (G == 64 && use_mid && k % 8 == 0) {
+            if (use_mid) {
                 const int nmid = 32 * 32 * 32;
-                w.mid.reserve(nmid);
-                {
-                    KTIME("k_km_lut_build", s, 4.0 * nmid);
-                    hipLaunchKernelGGL(k_km_lut_mid, nmid / 256, 256, 0, s, w.c4.p, k, (const KmGridDev *)w.grid.p, G, (const unsigned char *)w.clist.p,
-                                       (const double *)(w.grid.p + 64), w.mid.p);
-                }
                 const size_t lds_mid = ((size_t)nmid + 4 * 256 + 16 * 256) * 4 + (size_t)16 * kKmQueue * 16;
                 static bool attr3 = false;
                 if (!attr3) {

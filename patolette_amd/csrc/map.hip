@@ -109,11 +109,93 @@ __global__ __launch_bounds__(64) void k_nn_lut_coarse(const double *__restrict__
     if (lane == 0) out[0] = (CandT)(cnt <= kCoarseMax ? cnt : (CandT)~(CandT)0);      // all ones: test every entry
 }
 
+// --------------------------------------------------------------------------------------------
+// Large images: a (G/2)^3 table of FOUR-BYTE entries lives in LDS (32^3 x 4 B = 128 KB of the CU's 160 KB), so the
+// per-pixel lookup never leaves the CU -- on unsorted input the 16-byte records of the G^3 table are one random L2 line
+// per pixel and that gather, not HBM, bounded the kernel.  An entry holds up to four candidates in ascending order
+// (padded by repeating the last one; re-evaluating an entry cannot change a strict-'<' arg-min).  The rule that fills it
+// is the G^3 rule plus a bisector test against q* = the entry with the smallest maxdist: p is dropped when
+// |x-p|^2 - |x-q*|^2 > 0 on the whole (widened) box -- linear in x, so its minimum sits in a corner -- with a 1e-12
+// relative margin; a dropped entry is strictly farther than q* everywhere in the cell, so it can neither win nor tie.
+// About 90 % of the pixels of a noise image resolve there.  Cells with more than four survivors carry a marker
+// (byte 0 > byte 1, impossible for an ascending list); their pixels are queued per wavefront in LDS and taken 64 at a
+// time through the G^3 records, so that path runs with full wavefronts too.
+// --------------------------------------------------------------------------------------------
+constexpr unsigned kMidOverflow = 0x00000001u;                 // bytes {1, 0, 0, 0}
+
+// One wavefront fills the eight cells of the (G/2)^3 table that lie in one coarse block: lane = (cell << 3) | slice, the
+// eight lanes of a cell share the list (slice s takes entries s, s + 8, ...); list order is kept through the ballots.
+__device__ __forceinline__ void nn_mid_entries(const double *__restrict__ pal, const int k, const NNGrid &g, const unsigned char *__restrict__ cand,
+                                               const int cidx0, const int cidx1, const int cidx2, unsigned int *__restrict__ mid) {
+    const int lane = (int)threadIdx.x, m = lane >> 3, sl = lane & 7;
+    const bool all = cand[0] == 0xff;
+    const int ntest = all ? k : (int)cand[0];
+    const int idx[3] = {2 * cidx0 + (m & 1), 2 * cidx1 + ((m >> 1) & 1), 2 * cidx2 + (m >> 2)};
+    double cl[3], ch[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double mg = 1e-9 * (g.cw[a] * g.G) + 1e-300;
+        cl[a] = g.lo[a] + (2 * idx[a]) * g.cw[a] - mg;
+        ch[a] = g.lo[a] + (2 * idx[a] + 2) * g.cw[a] + mg;
+    }
+    const double *px = pal, *py = pal + k, *pz = pal + 2 * k;
+    double U = INFINITY; int qs = 0x7fffffff;
+    for (int t = sl; t < ntest; t += 8) {
+        const int j = all ? t : (int)cand[1 + t];
+        const double p[3] = {px[j], py[j], pz[j]};
+        double mx = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - cl[a]), fabs(p[a] - ch[a])); mx += d * d; }
+        if (mx < U) { U = mx; qs = j; }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {                           // (min maxdist, lowest index) over the eight slices of the cell
+        const double u2 = __shfl_xor(U, o, 64); const int q2i = __shfl_xor(qs, o, 64);
+        if (u2 < U || (u2 == U && q2i < qs)) { U = u2; qs = q2i; }
+    }
+    const double thr = U * (1.0 + 1e-12) + 1e-300;
+    const double q[3] = {px[qs], py[qs], pz[qs]};
+    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+    unsigned entry = 0; int cnt = 0;                             // cnt: uniform over the eight lanes of a cell
+    for (int t0 = 0; t0 < ntest; t0 += 8) {                      // wave-uniform trip count (ntest is)
+        const int t = t0 + sl;
+        bool keep = false; int j = 0;
+        if (t < ntest) {
+            j = all ? t : (int)cand[1 + t];
+            const double p[3] = {px[j], py[j], pz[j]};
+            double mn = 0, f = -q2, scale = q2;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0);
+                mn += d * d;
+                const double w = q[a] - p[a];
+                f += 2.0 * fmin(cl[a] * w, ch[a] * w) + p[a] * p[a];      // min over the box of |x-p|^2 - |x-q|^2, term by term
+                const double big = fmax(fmax(fabs(cl[a]), fabs(ch[a])), fabs(p[a]));
+                scale += 4.0 * big * big;
+            }
+            keep = mn <= thr && !(f > 1e-12 * scale + 1e-300);
+        }
+        const unsigned bits = (unsigned)((__ballot(keep) >> (8 * m)) & 0xffULL);
+        const int pos = cnt + __popc(bits & ((1u << sl) - 1u));
+        if (keep && pos < 4) entry |= (unsigned)j << (8 * pos);
+        cnt += __popc(bits);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) entry |= (unsigned)__shfl_xor((int)entry, o, 64);
+    if (cnt > 4) entry = kMidOverflow;
+    else {
+        const unsigned last = (entry >> (8 * (cnt - 1))) & 0xffu;
+        for (int t = cnt; t < 4; t++) entry |= last << (8 * t);
+    }
+    const int Gm = g.G / 2;
+    if (sl == 0) mid[(idx[2] * Gm + idx[1]) * Gm + idx[0]] = entry;
+}
+
 // Per cell two records of 16 entries: primary = [count, c0..c14], secondary = [c15..c29, unused].
 // count = 255 marks overflow (full scan).  One 16-byte (u8) / 32-byte (u16) load serves almost every pixel.
 template <typename CandT>
 __global__ __launch_bounds__(64) void k_nn_lut_build(const double *__restrict__ pal, int k, NNGrid g, CandT *__restrict__ lut,
-                                                      CandT *__restrict__ lut2, const CandT *__restrict__ clist) {
+                                                      CandT *__restrict__ lut2, const CandT *__restrict__ clist, unsigned int *__restrict__ mid) {
     // one wavefront per coarse cell, lane t = the fine cell (t & 3, (t >> 2) & 3, t >> 4) inside it: the list of entries
     // to test is the same for the whole wavefront (uniform loads)
     const int Gc = g.G / 4;
@@ -171,6 +253,10 @@ __global__ __launch_bounds__(64) void k_nn_lut_build(const double *__restrict__ 
     }
     for (int t = cnt; t < 15; t++) rec[1 + t] = (CandT)last;     // padding repeats the last entry: harmless to evaluate
     rec[0] = (CandT)(cnt <= kLutMax ? cnt : 255);              // 255 = overflow -> full scan
+    // the eight cells of the (G/2)^3 table inside this block, from the same list (k_nn_map_mid)
+    if constexpr (sizeof(CandT) == 1) {
+        if (mid != nullptr) nn_mid_entries(pal, k, g, (const unsigned char *)cand, cidx[0], cidx[1], cidx[2], mid);
+    }
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -276,77 +362,6 @@ __global__ __launch_bounds__(256) void k_nn_map_lut(const double *__restrict__ c
         const int b1 = nn_eval<CandT>(x1, y1, z1, r1, c1, lut2, spal, k);
         if (ok1) out[i1] = (OutT)b1;
     }
-}
-
-// --------------------------------------------------------------------------------------------
-// Large images: a (G/2)^3 table of FOUR-BYTE entries lives in LDS (32^3 x 4 B = 128 KB of the CU's 160 KB), so the
-// per-pixel lookup never leaves the CU -- on unsorted input the 16-byte records of the G^3 table are one random L2 line
-// per pixel and that gather, not HBM, bounded the kernel.  An entry holds up to four candidates in ascending order
-// (padded by repeating the last one; re-evaluating an entry cannot change a strict-'<' arg-min).  The rule that fills it
-// is the G^3 rule plus a bisector test against q* = the entry with the smallest maxdist: p is dropped when
-// |x-p|^2 - |x-q*|^2 > 0 on the whole (widened) box -- linear in x, so its minimum sits in a corner -- with a 1e-12
-// relative margin; a dropped entry is strictly farther than q* everywhere in the cell, so it can neither win nor tie.
-// About 90 % of the pixels of a noise image resolve there.  Cells with more than four survivors carry a marker
-// (byte 0 > byte 1, impossible for an ascending list); their pixels are queued per wavefront in LDS and taken 64 at a
-// time through the G^3 records, so that path runs with full wavefronts too.
-// --------------------------------------------------------------------------------------------
-constexpr unsigned kMidOverflow = 0x00000001u;                 // bytes {1, 0, 0, 0}
-
-__global__ __launch_bounds__(256) void k_nn_lut_mid(const double *__restrict__ pal, int k, NNGrid g, const unsigned char *__restrict__ clist,
-                                                    unsigned int *__restrict__ mid) {
-    const int Gm = g.G / 2, Gc = g.G / 4;
-    const int cell = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (cell >= Gm * Gm * Gm) return;
-    const int idx[3] = {cell % Gm, (cell / Gm) % Gm, cell / (Gm * Gm)};
-    const int cc = ((idx[2] >> 1) * Gc + (idx[1] >> 1)) * Gc + (idx[0] >> 1);
-    const unsigned char *cand = clist + (size_t)cc * (1 + kCoarseMax);
-    const bool all = cand[0] == 0xff;
-    const int ntest = all ? k : (int)cand[0];
-    double cl[3], ch[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const double m = 1e-9 * (g.cw[a] * g.G) + 1e-300;
-        cl[a] = g.lo[a] + (2 * idx[a]) * g.cw[a] - m;
-        ch[a] = g.lo[a] + (2 * idx[a] + 2) * g.cw[a] + m;
-    }
-    const double *px = pal, *py = pal + k, *pz = pal + 2 * k;
-    double U = INFINITY; int qs = 0;
-    for (int t = 0; t < ntest; t++) {
-        const int j = all ? t : (int)cand[1 + t];
-        const double p[3] = {px[j], py[j], pz[j]};
-        double mx = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++) { const double d = fmax(fabs(p[a] - cl[a]), fabs(p[a] - ch[a])); mx += d * d; }
-        if (mx < U) { U = mx; qs = j; }
-    }
-    const double thr = U * (1.0 + 1e-12) + 1e-300;
-    const double q[3] = {px[qs], py[qs], pz[qs]};
-    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-    unsigned entry = 0; int cnt = 0, last = 0;
-    for (int t = 0; t < ntest; t++) {
-        const int j = all ? t : (int)cand[1 + t];
-        const double p[3] = {px[j], py[j], pz[j]};
-        double mn = 0, f = 0, scale = q2;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0);
-            mn += d * d;
-            const double w = q[a] - p[a];
-            f += 2.0 * fmin(cl[a] * w, ch[a] * w);              // min over the box of 2 x.(q - p)
-            f += p[a] * p[a];
-            const double big = fmax(fmax(fabs(cl[a]), fabs(ch[a])), fabs(p[a]));
-            scale += 4.0 * big * big;
-        }
-        f -= q2;                                                 // min over the box of |x-p|^2 - |x-q|^2
-        if (mn <= thr && !(f > 1e-12 * scale + 1e-300)) {
-            if (cnt < 4) entry |= (unsigned)j << (8 * cnt);
-            last = j;
-            cnt++;
-        }
-    }
-    if (cnt > 4) entry = kMidOverflow;
-    else for (int t = cnt; t < 4; t++) entry |= (unsigned)last << (8 * t);
-    mid[cell] = entry;
 }
 
 // palette as three f64 arrays in LDS (6 KB): leaves room for the overflow queues next to the 128 KB table
@@ -523,21 +538,17 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
     if (k <= 256) {
         w.lut.reserve((size_t)ncell * 32);
         unsigned char *l1 = w.lut.p, *l2 = w.lut.p + (size_t)ncell * 16;
+        static const bool mid_enabled = !(getenv("PAMD_NN_MID") && atoi(getenv("PAMD_NN_MID")) == 0);
+        const bool use_mid = g.G == 64 && mid_enabled;                      // large images: four-candidate table in LDS
+        if (use_mid) w.mid.reserve((size_t)(ncell / 8));
         const int ncoarse = ncell / 64;
         w.clist.reserve((size_t)ncoarse * (1 + kCoarseMax) * 2);
         {
             KTIME("k_nn_lut_build", s, 32.0 * ncell);
             hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, w.clist.p);
-            hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, l1, l2, (const unsigned char *)w.clist.p);
+            hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, l1, l2, (const unsigned char *)w.clist.p, use_mid ? w.mid.p : nullptr);
         }
-        static const bool use_mid = !(getenv("PAMD_NN_MID") && atoi(getenv("PAMD_NN_MID")) == 0);
-        if (g.G == 64 && use_mid) {
-            const int nmid = (g.G / 2) * (g.G / 2) * (g.G / 2);
-            w.mid.reserve((size_t)nmid);
-            {
-                KTIME("k_nn_lut_build", s, 4.0 * nmid);
-                hipLaunchKernelGGL(k_nn_lut_mid, (nmid + 255) / 256, 256, 0, s, d_pal, k, g, (const unsigned char *)w.clist.p, w.mid.p);
-            }
+        if (use_mid) {
             constexpr int P = 2;
             const size_t lds_mid = kMidLds;
             static bool attr_mid = false;
@@ -561,7 +572,7 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
         {
             KTIME("k_nn_lut_build", s, 64.0 * ncell);
             hipLaunchKernelGGL(k_nn_lut_coarse<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, (unsigned short *)w.clist.p);
-            hipLaunchKernelGGL(k_nn_lut_build<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, l16, l16b, (const unsigned short *)w.clist.p);
+            hipLaunchKernelGGL(k_nn_lut_build<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, l16, l16b, (const unsigned short *)w.clist.p, (unsigned int *)nullptr);
         }
         static bool attr = false;
         if (!attr) {
