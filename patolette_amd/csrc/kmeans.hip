@@ -819,57 +819,92 @@ __device__ void km_split_clusters(float *cent, float *hassign, int k, unsigned l
 // block of four wavefronts runs them side by side -- per sample one LDS broadcast read and one add on each chain.
 template <bool W, int C>
 __device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, size_t lo, size_t hi, float4 (*stage)[64], int lane) {
-    constexpr int D = 8;                                                   // 1-KiB loads kept in flight
+    // A dependent f32 add issues every ~8 cycles (3.3 ns) on a lone wavefront; an LDS read takes ~130.  So the 64 samples
+    // of block n+1 are staged and their sixteen 128-bit broadcast reads issued BEFORE the 64 adds of block n: two register
+    // sets, nothing but the chain itself on the critical path.
+    constexpr int D = 8;                                                   // 1-KiB global loads kept in flight
+    constexpr bool WX = W && C < 3;                                        // weighted coordinate chain: acc = fma(x, w, acc)
+    constexpr int NR = WX ? 32 : 16;
     float acc = 0.f;
+    const size_t nfull = (hi - lo) / 64;
+    const int tail = (int)((hi - lo) - nfull * 64);
+    auto comp = [](const float4 v) { return C == 0 ? v.x : (C == 1 ? v.y : (C == 2 ? v.z : v.w)); };
     float4 ring[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         ring[d] = make_float4(0, 0, 0, 0);
-        if (lo + (size_t)d * 64 + lane < hi) ring[d] = sorted[lo + (size_t)d * 64 + lane];
+        if ((size_t)d < nfull) ring[d] = sorted[lo + (size_t)d * 64 + lane];
     }
-    int pb = 0;
-    for (size_t sbase = lo; sbase < hi; sbase += (size_t)D * 64) {
+    float4 tv = make_float4(0, 0, 0, 0);                                   // the partial last block, fetched up front
+    if (lane < tail) tv = sorted[lo + nfull * 64 + lane];
+    auto put = [&](const int buf, const float4 v) {                        // this wavefront's coordinate (and weight) of 64 samples
+        float *sc = reinterpret_cast<float *>(&stage[buf][0]);
+        sc[lane] = comp(v);
+        if constexpr (WX) sc[64 + lane] = v.w;
+    };
+    float4 xa[NR], xb[NR];
+    auto issue = [&](const int buf, float4 (&x)[NR]) {
+        const float4 *s4 = &stage[buf][0];
+#pragma unroll
+        for (int q = 0; q < NR; q++) x[q] = s4[q];
+    };
+    auto consume = [&](const float4 (&x)[NR]) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if constexpr (WX) {
+                acc = __builtin_fmaf(x[q].x, x[16 + q].x, acc); acc = __builtin_fmaf(x[q].y, x[16 + q].y, acc);
+                acc = __builtin_fmaf(x[q].z, x[16 + q].z, acc); acc = __builtin_fmaf(x[q].w, x[16 + q].w, acc);
+            } else {
+                acc += x[q].x; acc += x[q].y; acc += x[q].z; acc += x[q].w;
+            }
+        }
+    };
+    if (nfull > 0) {
+        put(0, ring[0]);
+        ring[0] = make_float4(0, 0, 0, 0);
+        if ((size_t)D < nfull) ring[0] = sorted[lo + (size_t)D * 64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        issue(0, xa);
+    }
+    for (size_t n0 = 0; n0 < nfull; n0 += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            const size_t base = sbase + (size_t)d * 64;
-            if (base >= hi) break;                                         // wave-uniform
-            // this wavefront's coordinate (and the weight) of the 64 samples, contiguous in its own LDS: one 128-bit
-            // broadcast read then serves four chain steps
-            float *sc = reinterpret_cast<float *>(&stage[pb][0]);          // [64] coordinate, [64] weight
-            {
-                const float4 v = ring[d];
-                sc[lane] = C == 0 ? v.x : (C == 1 ? v.y : (C == 2 ? v.z : v.w));
-                if constexpr (W && C < 3) sc[64 + lane] = v.w;
+            const size_t n = n0 + d;
+            if (n >= nfull) break;                                         // wave-uniform
+            if (n + 1 < nfull) {                                           // stage block n+1 and start its reads
+                constexpr int dn = 0;
+                (void)dn;
+                const int rd = (d + 1) % D;
+                put((d + 1) & 1, ring[rd]);
+                ring[rd] = make_float4(0, 0, 0, 0);
+                if (n + 1 + D < nfull) ring[rd] = sorted[lo + (n + 1 + D) * 64 + lane];
+                __builtin_amdgcn_wave_barrier();
+                if ((d & 1) == 0) issue(1, xb); else issue(0, xa);
             }
-            {   // refill this ring slot with the block D steps ahead
-                const size_t nb = base + (size_t)D * 64 + lane;
-                ring[d] = make_float4(0, 0, 0, 0);
-                if (nb < hi) ring[d] = sorted[nb];
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int cnt = (int)(hi - base < 64 ? hi - base : 64);
-            const float4 *s4 = reinterpret_cast<const float4 *>(sc), *w4 = reinterpret_cast<const float4 *>(sc + 64);
-            auto step4 = [&](int q, int nvalid) {                           // samples 4q .. 4q+3 (the first nvalid of them)
-                const float4 x = s4[q];
-                float4 w = make_float4(0, 0, 0, 0);
-                if constexpr (W && C < 3) w = w4[q];
-                const float xs[4] = {x.x, x.y, x.z, x.w}, ws[4] = {w.x, w.y, w.z, w.w};
+            __builtin_amdgcn_sched_barrier(0);                             // keep the reads above the chain
+            if ((d & 1) == 0) consume(xa); else consume(xb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (tail > 0) {
+        __builtin_amdgcn_wave_barrier();
+        const int buf = (int)(nfull & 1);
+        put(buf, tv);
+        __builtin_amdgcn_wave_barrier();
+        const float *sc = reinterpret_cast<const float *>(&stage[buf][0]);
+        const float4 *s4 = reinterpret_cast<const float4 *>(sc), *w4 = reinterpret_cast<const float4 *>(sc + 64);
+        for (int q = 0; 4 * q < tail; q++) {
+            const float4 x = s4[q];
+            float4 w = make_float4(0, 0, 0, 0);
+            if constexpr (WX) w = w4[q];
+            const float xs[4] = {x.x, x.y, x.z, x.w}, ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (e < nvalid) {
-                        if constexpr (W && C < 3) acc = __builtin_fmaf(xs[e], ws[e], acc);
-                        else acc += xs[e];
-                    }
+            for (int e = 0; e < 4; e++) {
+                if (4 * q + e < tail) {
+                    if constexpr (WX) acc = __builtin_fmaf(xs[e], ws[e], acc);
+                    else acc += xs[e];
                 }
-            };
-            if (cnt == 64) {
-#pragma unroll
-                for (int q = 0; q < 16; q++) step4(q, 4);
-            } else {
-                for (int q = 0; 4 * q < cnt; q++) step4(q, cnt - 4 * q < 4 ? cnt - 4 * q : 4);
             }
-            __builtin_amdgcn_wave_barrier();
-            pb ^= 1;
         }
     }
     return acc;
