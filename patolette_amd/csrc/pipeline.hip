@@ -290,10 +290,10 @@ static void get_nodes(Engine &E, const std::vector<int> &ids, std::vector<NodeOu
 static void get_nodes_dev(Engine &E, const int *d_ids, int n, std::vector<NodeOut> &recs) {
     recs.resize(n);
     if (!n) return;
-    E.stage_out.reserve(n); E.h_stage_out.reserve(n);
-    hipLaunchKernelGGL(k_get_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.stage_out.p, d_ids, n);
+    E.h_stage_out.reserve(n);
+    // the kernel stores the records straight into pinned host memory (device-visible): no copy engine round trip
+    hipLaunchKernelGGL(k_get_nodes, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, E.h_stage_out.p, d_ids, n);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(E.h_stage_out.p, E.stage_out.p, n * sizeof(NodeOut), hipMemcpyDeviceToHost, E.stream));
     E.sync();
     std::memcpy(recs.data(), E.h_stage_out.p, n * sizeof(NodeOut));
 }

@@ -139,11 +139,8 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
         const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
         if (threadIdx.x == 0) nd.degenerate = degenerate ? 1 : 0;
 
-        for (unsigned i = threadIdx.x; i < t.count; i += blockDim.x) {
-            const size_t p = t.start + i;
-            const double x = px[p], y = py[p], z = pz[p];
-            double w = 1.0;
-            if constexpr (W) w = pw[p];
+        // two pixels per trip: both sets of loads are issued before either is consumed
+        auto one = [&](const size_t p, const double x, const double y, const double z, const double w) {
             unsigned b;
             if (degenerate) {
                 b = (unsigned)((p - nd.begin) % kBuckets);
@@ -175,6 +172,21 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
                 if constexpr (W) { HADD(10, x * w, klin); HADD(11, y * w, klin); HADD(12, z * w, klin); HADD(13, w, klin); }
             }
 #undef HADD
+        };
+        unsigned i = threadIdx.x;
+        for (; i + 512 < t.count; i += 1024) {
+            const size_t p0 = t.start + i, p1 = p0 + 512;
+            const double x0 = px[p0], y0 = py[p0], z0 = pz[p0], x1 = px[p1], y1 = py[p1], z1 = pz[p1];
+            double w0 = 1.0, w1 = 1.0;
+            if constexpr (W) { w0 = pw[p0]; w1 = pw[p1]; }
+            one(p0, x0, y0, z0, w0);
+            one(p1, x1, y1, z1, w1);
+        }
+        for (; i < t.count; i += 512) {
+            const size_t p = t.start + i;
+            double w = 1.0;
+            if constexpr (W) w = pw[p];
+            one(p, px[p], py[p], pz[p], w);
         }
         const bool flush = (ti + 1 == tlast) || tiles[ti + 1].node != t.node;           // block-uniform
         if (!flush) continue;
