@@ -313,12 +313,29 @@ __global__ __launch_bounds__(256) void k_count(QuantBuffers qb, const Tile *__re
     const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
     if (threadIdx.x < kMaxChildren) c[threadIdx.x] = 0;
     const int nch = nd.nchild;
-    if (nch == 2) {
-        // binary split (every local-quantiser round): 8 buckets per thread in one 16-byte load, the child looked up in an
-        // LDS copy of the bucket -> child table, one LDS atomic per wavefront
+    typedef unsigned short us8 __attribute__((ext_vector_type(8), aligned(2)));
+    const int split = nd.split;
+    if (nch == 2 && split >= 0) {
+        // a local-quantiser round (k_cut's table is "bucket > split"): 8 buckets per thread in one 16-byte load, no table
+        const unsigned i0 = threadIdx.x * 8u;
+        unsigned right = 0;
+        if (i0 + 8u <= t.count) {
+            const us8 v = *reinterpret_cast<const us8 *>(qb.bkt + t.start + i0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) right += (int)v[j] > split ? 1u : 0u;
+        } else {
+            for (unsigned i = i0; i < t.count && i < i0 + 8u; i++) right += (int)qb.bkt[t.start + i] > split ? 1u : 0u;
+        }
+        __syncthreads();                                         // c[] is zeroed
+        right = wave_sum_u32(right);
+        if ((threadIdx.x & 63) == 0 && right) atomicAdd(&c[1], right);
+        __syncthreads();
+        if (threadIdx.x == 0) c[0] = t.count - c[1];
+        __syncthreads();
+    } else if (nch == 2) {
+        // two base clusters out of the global quantiser: the child comes from an LDS copy of the bucket -> child table
         for (int b = threadIdx.x; b < kBuckets; b += blockDim.x) sl[b] = l[b];
         __syncthreads();
-        typedef unsigned short us8 __attribute__((ext_vector_type(8), aligned(2)));
         const unsigned i0 = threadIdx.x * 8u;
         unsigned right = 0;
         if (i0 + 8u <= t.count) {
@@ -395,12 +412,17 @@ __global__ __launch_bounds__(256, 5) void k_scatter(QuantBuffers qb, const Tile 
         const Tile t = tiles[ti];
         const NodeDev &nd = nodes[t.node];
         const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
-        const int nch = nd.nchild;
+        const int nch = nd.nchild, split = nd.split;
         unsigned cr[R];                                      // child (low byte) | rank within the wave << 8
 #pragma unroll
         for (int r = 0; r < R; r++) {
             unsigned i = r * 256 + threadIdx.x;
-            const int ch = i < t.count ? (int)l[qb.bkt[t.start + i]] : 255;
+            int ch = 255;
+            if (i < t.count) {
+                const unsigned short b = qb.bkt[t.start + i];
+                if constexpr (COV) ch = (int)b > split ? 1 : 0;              // binary split: k_cut's table is b > split
+                else ch = (int)l[b];
+            }
             unsigned rk = 0;
             for (int k = 0; k < nch; k++) {
                 unsigned long long m = __ballot(ch == k);
