@@ -15,6 +15,7 @@ import sys
 tag, cfg = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof", tag)
+outtag = tag[:-len(cfg) - 1] if tag.endswith("_" + cfg) else tag      # collect_kernels.sh: prof/<tag>_<cfg>
 
 
 def short(name):
@@ -26,9 +27,9 @@ def short(name):
         return "k_scatter_cov" if ", true>" in n else "k_scatter"
     if base in ("k_cov_children", "k_cov_nodes"):
         return "k_cov"
-    if base == "k_nn_map_lut":
+    if base in ("k_nn_map_lut", "k_nn_map_mid"):
         return "k_nn_map"
-    if base == "k_km_assign_count":
+    if base in ("k_km_assign_count", "k_km_assign_lut", "k_km_assign_mid"):
         return "k_km_assign"
     return base
 
@@ -39,7 +40,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recurs
     for r in csv.DictReader(open(f)):
         rows[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in rows.values())
-with open(os.path.join(root, "profiles", "%s_%s_kernel_stats.txt" % (tag, cfg)), "w") as out:
+with open(os.path.join(root, "profiles", "%s_%s_kernel_stats.txt" % (outtag, cfg)), "w") as out:
     out.write("rocprofv3 --kernel-trace --stats -- python bench.py --config %s --no-cpu-baseline --extra-streams 0\n" % cfg)
     out.write("%-86s %7s %12s %10s %10s %10s %6s\n" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
     for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
@@ -76,5 +77,5 @@ json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (sep
 for f in ("bench_%s.json" % cfg, "bench_%s_traced.json" % cfg):
     p = os.path.join(src, f)
     if os.path.exists(p):
-        open(os.path.join(root, "profiles", "%s_%s" % (tag, f)), "w").write(open(p).read())
+        open(os.path.join(root, "profiles", "%s_%s" % (outtag, f)), "w").write(open(p).read())
 print("written profiles/%s_%s_kernel_stats.txt, profiles/traffic_%s.json" % (tag, cfg, cfg))

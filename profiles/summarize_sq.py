@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 tag, cfg = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof", tag)
+outtag = tag[:-len(cfg) - 1] if tag.endswith("_" + cfg) else tag      # collect_kernels.sh: prof/<tag>_<cfg>
 
 
 def short(name):
@@ -42,7 +43,7 @@ for k, c in agg.items():
                  g("SQ_INSTS_VALU"), g("SQ_INSTS_VMEM"), g("SQ_INSTS_LDS"), g("SQ_INSTS_LDS_ATOMIC"),
                  (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")) if g("SQ_LDS_IDX_ACTIVE") else 0.0, g("SQ_VMEM_TA_ADDR_FIFO_FULL")))
 rows.sort(reverse=True)
-out = os.path.join(root, "profiles", "%s_%s_sq_counters.txt" % (tag, cfg))
+out = os.path.join(root, "profiles", "%s_%s_sq_counters.txt" % (outtag, cfg))
 with open(out, "w") as f:
     f.write("rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes), bench.py --config %s --steps 2 --warmup 1; per launch averages\n" % cfg)
     f.write("shares of wavefront time: parked = SQ_WAIT_ANY, stall = SQ_WAIT_INST_ANY, issue = SQ_ACTIVE_INST_ANY (valu / vmem / lds are parts of it)\n")
