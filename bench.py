@@ -206,17 +206,24 @@ def main():
     barrier()
     if not args.no_profile:
         _native.profile(True, only=dom_name)
+    gathered, works = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
         run.step(args.warmup + i)
+        if dist is not None:
+            # The only collective of the job: the results go to rank 0 over RCCL/xGMI.  The u8 maps of step i (complete: the
+            # library call has returned) are gathered asynchronously on RCCL's own stream while step i+1 computes.
+            part = maps_t[i * S:(i + 1) * S]
+            gl = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
+            gathered.append(gl)
+            works.append(dist.gather(part, gl, dst=0, async_op=True))
     L.patolette_amd_synchronize()
     if dist is not None:
-        # the only collective of the job: final gather of the results to rank 0 over RCCL/xGMI
         pal_t = torch.from_numpy(pals[args.warmup * S:]).to("cuda")
-        gl_m = [torch.empty_like(maps_t) for _ in range(world)] if rank == 0 else None
         gl_p = [torch.empty_like(pal_t) for _ in range(world)] if rank == 0 else None
-        dist.gather(maps_t, gl_m, dst=0)
-        dist.gather(pal_t, gl_p, dst=0)
+        works.append(dist.gather(pal_t, gl_p, dst=0, async_op=True))
+        for w in works:
+            w.wait()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     stats = _native.last_stats()
@@ -319,15 +326,21 @@ def main():
                    "kernel_events_in_timed_region": ("none" if args.no_profile else
                                                      ("dominant kernel only (%s); per-kernel table from one extra untimed step" % dom_name
                                                       if dom_name else "all kernels")),
-                   "final_gather": ("RCCL gather of u8 maps + f64 palettes to rank 0, inside the timed region" if dist is not None else "none (1 GPU)")},
+                   "final_gather": ("RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region" if dist is not None else "none (1 GPU)")},
         "roofline": roofline, "cpu_baseline": cpu, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
     }
-    print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    # the JSON line is the last thing on stdout: RCCL's banner sits in the C library's stdout buffer until it is flushed
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
