@@ -181,3 +181,35 @@ def test_u8_full_size_round_trip(gpu):
     got = pmap.reshape(-1)[idx]
     best = d.min(1)
     assert np.all(d[np.arange(len(idx)), got] <= best * (1 + 1e-9) + 1e-18)
+
+
+@pytest.mark.parametrize("K", [256, 300])
+def test_host_entry_map_equals_device_entry_map(gpu, native, K):
+    """The C ABI hands the map back as size_t: the narrow device map (u8 for K <= 256, else u32) crosses PCIe in chunks and is
+    widened by host threads.  5 Mpx (three chunks, the last one partial): patolette() must return exactly the map the
+    device-resident entry leaves in HBM, and the same palette."""
+    import patolette_amd as p
+    w, h = 2560, 2048 + 3
+    n = w * h
+    L = native.lib()
+    img = L.patolette_amd_malloc(3 * n * 8)
+    dmap = L.patolette_amd_malloc(n * 4)
+    try:
+        assert img and dmap and L.patolette_amd_fill_image(img, n, 11) == 0
+        host = np.empty(3 * n)
+        assert L.patolette_amd_memcpy_d2h(host.ctypes.data_as(C.c_void_p), img, host.nbytes) == 0
+        opts = native.QuantizationOptions(False, False, 2, 0, 512 ** 2, False)
+        pal_d = np.zeros((K, 3), dtype=np.float64, order="F")
+        code = C.c_int(9)
+        me = 1 if K <= 256 else 4
+        L.patolette_amd_device(w, h, img, None, K, C.byref(opts), pal_d.ctypes.data_as(dp), dmap, me, C.byref(code))
+        assert code.value == 0, native.last_error()
+        want = np.empty(n, dtype=np.uint8 if me == 1 else np.uint32)
+        assert L.patolette_amd_memcpy_d2h(want.ctypes.data_as(C.c_void_p), dmap, want.nbytes) == 0
+        ok, pal_h, map_h, _ = p.quantize(w, h, np.asfortranarray(host.reshape(3, n).T), K, dither=False, tile_size=0, kmeans_niter=0)
+        assert ok and map_h.dtype == np.uintp
+        assert np.array_equal(pal_h, pal_d)
+        assert np.array_equal(map_h, want.astype(np.uintp))
+    finally:
+        L.patolette_amd_free(img)
+        L.patolette_amd_free(dmap)
