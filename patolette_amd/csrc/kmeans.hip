@@ -58,8 +58,9 @@ __device__ __forceinline__ int km_assign_one(const float x0, const float x1, con
     const float m0 = -2 * x0, m1 = -2 * x1, m2 = -2 * x2;
     const float xn = __builtin_fmaf(x2, x2, __builtin_fmaf(x0, x0, x1 * x1));
     float ld[8]; unsigned li[8];
+    int lb[8];                                             // group (j) of the lane's current minimum: index = group + lane
 #pragma unroll
-    for (int l = 0; l < 8; l++) { ld[l] = 3.402823466e+38F - xn; li[l] = 0u; }
+    for (int l = 0; l < 8; l++) { ld[l] = 3.402823466e+38F - xn; lb[l] = -l; }
     const int ny_p = (k / 8) * 8;
     for (int j = 0; j < ny_p; j += 8) {
 #pragma unroll
@@ -69,9 +70,11 @@ __device__ __forceinline__ int km_assign_one(const float x0, const float x1, con
             dp = __builtin_fmaf(m1, y.y, dp);
             dp = __builtin_fmaf(m2, y.z, dp);
             dp = dp + y.w;
-            if (dp < ld[l]) { ld[l] = dp; li[l] = (unsigned)(j + l); }
+            if (dp < ld[l]) { ld[l] = dp; lb[l] = j; }     // one copy of the (uniform) j serves the eight lanes
         }
     }
+#pragma unroll
+    for (int l = 0; l < 8; l++) li[l] = (unsigned)(lb[l] + l);
     float cur_d = 3.402823466e+38F; unsigned cur_i = 0xFFFFFFFFu;
 #pragma unroll
     for (int l = 0; l < 8; l++) {
