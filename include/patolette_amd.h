@@ -116,6 +116,15 @@ void patolette_amd_batch_rows(size_t count, size_t width, size_t height, const d
                               const patolette__QuantizationOptions *options, double *const *palettes,
                               size_t *const *palette_maps, int *exit_codes);
 
+/* the 8-bit entry for a batch: pixels[i] / palettes[i] / palettes_u8[i] / palette_maps[i] / quantized[i] as for
+ * patolette_amd_u8() (palettes_u8, palette_maps, quantized or single entries of them may be NULL); 3 bytes per pixel cross
+ * PCIe instead of 24, so a host-fed batch is no longer bound by the upload */
+void patolette_amd_batch_u8(size_t count, size_t width, size_t height, const unsigned char *const *pixels, int channels,
+                            const double *const *weights, double tile_size, size_t palette_size,
+                            const patolette__QuantizationOptions *options, double *const *palettes,
+                            unsigned char *const *palettes_u8, void *const *palette_maps, int map_elem_bytes,
+                            unsigned char *const *quantized, int *exit_codes);
+
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
 /* out[i] = pow(x[i], y) as the colour conversions evaluate it on the device (x >= 0; <= 0.51 ulp) */
 int patolette_amd_pow(const double *x, double y, double *out, size_t n);

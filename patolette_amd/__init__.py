@@ -8,7 +8,8 @@ constants.  The work behind it runs in hand-written HIP kernels on gfx950 throug
 
 `tile_size > 0` derives the saliency weights on the GPU as the reference's binding does on the CPU
 (patolette.pyx:203-313).  Additive (not in the reference): the `weights=` keyword (explicit
-per-pixel weights instead of the saliency-derived ones), `saliency_weights`, `quantize_batch` and the 8-bit adaptor `quantize_u8`.
+per-pixel weights instead of the saliency-derived ones), `saliency_weights`, `quantize_batch`, the 8-bit adaptor `quantize_u8` and its
+batch form `quantize_u8_batch`.
 """
 import ctypes as C
 
@@ -251,12 +252,63 @@ def quantize_batch(width, height, images, palette_size, weights=None, dither=Tru
     return out
 
 
+def quantize_u8_batch(images, palette_size, weights=None, dither=True, palette_only=False, color_space=ColorSpace_ICtCp,
+                      tile_size=512, kmeans_niter=32, kmeans_max_samples=512 ** 2, want_quantized=True):
+    """`quantize_u8` for a list of (H, W, 3|4) uint8 images of identical shape through `patolette_amd_batch_u8`: up to three
+    images in flight on the current GPU, and 3 bytes per pixel over PCIe instead of 24, so a host-fed batch is bound by the
+    kernels rather than by the upload.  Per-image results are identical to separate `quantize_u8` calls.
+    Returns a list of `quantize_u8` tuples."""
+    if tile_size < 0:
+        return [(False, None, None, None, None, bad_tile_size)] * len(images)
+    imgs = [np.ascontiguousarray(im) for im in images]
+    count = len(imgs)
+    if count == 0:
+        return []
+    shape = imgs[0].shape
+    for im in imgs:
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] not in (3, 4) or im.shape != shape:
+            raise ValueError("images must be (H, W, 3|4) uint8 arrays of one shape")
+    height, width, channels = shape
+    n = width * height
+    ws = [None] * count if weights is None else [None if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(-1) for w in weights]
+    for w in ws:
+        if w is not None and w.size != n:
+            raise ValueError("weights must hold width*height values")
+    opts = _native.QuantizationOptions(bool(dither), bool(palette_only), int(color_space), int(kmeans_niter),
+                                       int(kmeans_max_samples), False)
+    map_dtype = np.uint8 if palette_size <= 256 else (np.uint16 if palette_size <= 65536 else np.uint32)
+    pals = [np.zeros((palette_size, 3), dtype=np.float64, order='F') for _ in range(count)]
+    pal8 = [np.zeros((max(palette_size, 0), 3), dtype=np.uint8) for _ in range(count)]
+    maps = [None if palette_only else np.zeros((height, width), dtype=map_dtype) for _ in range(count)]
+    quants = [np.zeros((height, width, 3), dtype=np.uint8) if (want_quantized and not palette_only) else None for _ in range(count)]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size > 0 else C.c_void_p()   # noqa: E731
+    PV = C.c_void_p * count
+    PD = _native.dp * count
+    codes = (C.c_int * count)()
+    L = _native.lib()
+    L.patolette_amd_batch_u8(count, width, height, PV(*[vp(im) for im in imgs]), channels,
+                             None if weights is None else PD(*[_dp(w) if w is not None else _native.dp() for w in ws]),
+                             float(tile_size), palette_size, C.byref(opts), PD(*[_dp(p) for p in pals]), PV(*[vp(p) for p in pal8]),
+                             None if palette_only else PV(*[vp(m) for m in maps]), np.dtype(map_dtype).itemsize,
+                             PV(*[vp(q) for q in quants]) if (want_quantized and not palette_only) else None, codes)
+    out = []
+    for i in range(count):
+        msg = L.get_patolette_exit_code_info_message(codes[i]).decode('UTF-8')
+        _raise_saliency(codes[i], msg)
+        if codes[i] != 0:
+            out.append((False, None, None, None, None, msg))
+        else:
+            out.append((True, pal8[i], maps[i], quants[i], pals[i], msg))
+    return out
+
+
 __all__ = [
     "__doc__",
     "__version__",
     "quantize",
     "quantize_batch",
     "quantize_u8",
+    "quantize_u8_batch",
     "saliency_weights",
     "ColorSpace_sRGB",
     "ColorSpace_CIELuv",

@@ -66,6 +66,9 @@ SYMBOLS = {
                                    C.POINTER(QuantizationOptions), C.POINTER(dp), C.POINTER(zp), C.POINTER(C.c_int)]),
     "patolette_amd_batch_rows": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(dp), C.POINTER(dp), C.c_double, C.c_size_t,
                                         C.POINTER(QuantizationOptions), C.POINTER(dp), C.POINTER(zp), C.POINTER(C.c_int)]),
+    "patolette_amd_batch_u8": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.POINTER(dp), C.c_double, C.c_size_t,
+                                      C.POINTER(QuantizationOptions), C.POINTER(dp), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "patolette_amd_pow": (C.c_int, [dp, C.c_double, dp, C.c_size_t]),
     "patolette_amd_convert": (C.c_int, [C.c_int, dp, C.c_size_t]),
     "patolette_amd_quantize_clusters": (C.c_int, [dp, dp, C.c_size_t, C.c_size_t, dp, zp]),

@@ -1254,11 +1254,9 @@ Engine *pool_acquire(int device) {
 void pool_release(Engine *e) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool.push_back(e); }
 }  // namespace
 
-static void batch_impl(bool rows, size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
-                       double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
-                         size_t *const *palette_maps, int *exit_codes) {
-    const int v = validate(width, height, palette_size);
-    if (v != 0) { for (size_t i = 0; i < count; i++) exit_codes[i] = v; return; }
+// run item(E, i) for i in [0, count) on pooled engines, `workers` of them in flight
+static void batch_run(size_t count, size_t width, size_t height, const patolette__QuantizationOptions *options, int *exit_codes,
+                      const std::function<void(Engine &, size_t)> &item) {
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) { for (size_t i = 0; i < count; i++) exit_codes[i] = -1; return; }
     if (engine().device >= 0) device = engine().device;
@@ -1290,8 +1288,7 @@ static void batch_impl(bool rows, size_t count, size_t width, size_t height, con
         }
         for (size_t i; (i = next.fetch_add(1)) < count;) {
             try {
-                run_host(*E, width, height, data[i], weights ? weights[i] : nullptr, tile_size, palette_size, options, palettes[i],
-                         palette_maps ? palette_maps[i] : nullptr, rows);
+                item(*E, i);
                 exit_codes[i] = 0;
             } catch (const CodeError &ex) {
                 exit_codes[i] = ex.code;
@@ -1306,6 +1303,34 @@ static void batch_impl(bool rows, size_t count, size_t width, size_t height, con
     for (size_t t = 1; t < workers; t++) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+}
+
+static void batch_impl(bool rows, size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
+                       double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
+                       size_t *const *palette_maps, int *exit_codes) {
+    const int v = validate(width, height, palette_size);
+    if (v != 0) { for (size_t i = 0; i < count; i++) exit_codes[i] = v; return; }
+    batch_run(count, width, height, options, exit_codes, [&](Engine &E, size_t i) {
+        run_host(E, width, height, data[i], weights ? weights[i] : nullptr, tile_size, palette_size, options, palettes[i],
+                 palette_maps ? palette_maps[i] : nullptr, rows);
+    });
+}
+
+void patolette_amd_batch_u8(size_t count, size_t width, size_t height, const unsigned char *const *pixels, int channels,
+                            const double *const *weights, double tile_size, size_t palette_size,
+                            const patolette__QuantizationOptions *options, double *const *palettes, unsigned char *const *palettes_u8,
+                            void *const *palette_maps, int map_elem_bytes, unsigned char *const *quantized, int *exit_codes) {
+    int v = validate(width, height, palette_size);
+    if (v == 0 && validate_u8(palette_size, channels, palette_maps ? (const void *)palette_maps : nullptr, map_elem_bytes) != 0) {
+        fprintf(stderr, "patolette_amd: bad channels / map_elem_bytes for the u8 entry point\n");
+        v = -1;
+    }
+    if (v != 0) { for (size_t i = 0; i < count; i++) exit_codes[i] = v; return; }
+    batch_run(count, width, height, options, exit_codes, [&](Engine &E, size_t i) {
+        run_u8(E, width, height, pixels[i], channels, weights ? weights[i] : nullptr, tile_size, palette_size, options, palettes[i],
+               palettes_u8 ? palettes_u8[i] : nullptr, palette_maps ? palette_maps[i] : nullptr, map_elem_bytes,
+               quantized ? quantized[i] : nullptr, false);
+    });
 }
 
 void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,

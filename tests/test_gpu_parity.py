@@ -137,6 +137,25 @@ def test_kmeans_pruned_assignment_many_samples(gpu, ob, monkeypatch, cs, k, weig
     assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
 
 
+def test_u8_batch_equals_separate_u8_calls(gpu):
+    """`quantize_u8_batch` (three engines in flight, 3 B/px over PCIe) returns per image exactly what `quantize_u8` returns:
+    mixed with / without explicit weights, with the saliency weights (tile_size > 0), K <= 256 and K > 256, RGBA input."""
+    import patolette_amd as p
+    rng = np.random.default_rng(8)
+    for (h, w, ch, K, tile, niter) in [(96, 128, 3, 64, 0, 4), (120, 100, 4, 300, 0, 0), (128, 128, 3, 32, 64, 2)]:
+        imgs = [rng.integers(0, 256, size=(h, w, ch), dtype=np.uint8) for _ in range(5)]
+        wts = None if tile else [None, 1.0 + rng.random(h * w), None, 1.0 + 3.0 * rng.random(h * w), None]
+        got = p.quantize_u8_batch(imgs, K, weights=wts, dither=False, tile_size=tile, kmeans_niter=niter)
+        assert len(got) == 5
+        for i, g in enumerate(got):
+            one = p.quantize_u8(imgs[i], K, weights=None if wts is None else wts[i], dither=False, tile_size=tile, kmeans_niter=niter)
+            assert g[0] and one[0]
+            for a, b in zip(g[1:5], one[1:5]):
+                assert a.dtype == b.dtype and np.array_equal(a, b)
+    only = p.quantize_u8_batch(imgs[:2], 16, dither=False, palette_only=True, tile_size=0)
+    assert all(o[0] and o[2] is None and o[3] is None and o[1].shape == (16, 3) for o in only)
+
+
 def test_nn_map_bit_exact(gpu, ob):
     for n, k, seed in [(100000, 256, 1), (5000, 7, 2), (333, 1, 3), (70000, 300, 4)]:
         flat = ob.convert("srgb_to_ictcp", ob.image(n, seed))
