@@ -41,7 +41,7 @@ def gather_to_root(local, dist, root=0, device=None):
 
 
 def quantize_batch_sharded(width, height, images, palette_size, dist=None, quantize_fn=None, weights=None, **kwargs):
-    """Quantise `images` (a list, identical on every rank, or a callable i -> (N,3) array) with
+    """Quantise `images` (a list, identical on every rank, or a callable i -> (N,3) float64 array or (H,W,3|4) uint8 image) with
     the batch sharded over the ranks of `dist`; rank 0 returns [(success, palette, map, message)]
     for the whole batch in order, the other ranks return None.  With dist=None it is a plain
     loop.  `quantize_fn` defaults to patolette_amd.quantize (tests inject the CPU oracle to
@@ -60,7 +60,15 @@ def quantize_batch_sharded(width, height, images, palette_size, dist=None, quant
         for g0 in range(start, start + n, 6):                 # groups of six bound the host memory held at once
             idx = list(range(g0, min(g0 + 6, start + n)))
             ws = None if weights is None else [weights[i] for i in idx]
-            local.extend(batch_fn(width, height, [get(i) for i in idx], palette_size, weights=ws, **kwargs))
+            group = [get(i) for i in idx]
+            if all(getattr(im, "dtype", None) == np.uint8 and getattr(im, "ndim", 0) == 3 for im in group):
+                # 8-bit images as decoded, (H, W, 3|4): 3 bytes per pixel over PCIe instead of 24
+                from . import quantize_u8_batch
+                kw = {k: v for k, v in kwargs.items() if k != "verbose"}
+                for r in quantize_u8_batch(group, palette_size, weights=ws, want_quantized=False, **kw):
+                    local.append((r[0], r[4], None if r[2] is None else r[2].reshape(-1), r[5]))
+            else:
+                local.extend(batch_fn(width, height, group, palette_size, weights=ws, **kwargs))
     else:
         for i in range(start, start + n):
             w = None if weights is None else weights[i]
