@@ -156,6 +156,21 @@ def test_u8_batch_equals_separate_u8_calls(gpu):
     assert all(o[0] and o[2] is None and o[3] is None and o[1].shape == (16, 3) for o in only)
 
 
+def test_sharded_batch_takes_8bit_images(gpu):
+    """patolette_amd.dist.quantize_batch_sharded (single process here) routes (H, W, 3) uint8 images through the 8-bit batch
+    entry and returns the `quantize` tuple: same palette and map as `quantize_u8`."""
+    import patolette_amd as p
+    from patolette_amd.dist import quantize_batch_sharded
+    rng = np.random.default_rng(9)
+    h, w, K = 64, 96, 40
+    imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(7)]
+    out = quantize_batch_sharded(w, h, imgs, K, dither=False, tile_size=0, kmeans_niter=3)
+    assert len(out) == 7
+    for im, r in zip(imgs, out):
+        one = p.quantize_u8(im, K, dither=False, tile_size=0, kmeans_niter=3)
+        assert r[0] and np.array_equal(r[1], one[4]) and np.array_equal(r[2], one[2].reshape(-1))
+
+
 def test_nn_map_bit_exact(gpu, ob):
     for n, k, seed in [(100000, 256, 1), (5000, 7, 2), (333, 1, 3), (70000, 300, 4)]:
         flat = ob.convert("srgb_to_ictcp", ob.image(n, seed))
