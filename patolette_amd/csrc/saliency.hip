@@ -316,6 +316,12 @@ __device__ __forceinline__ float wave_shr1(float from_above, float v) {
                                                                  0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
+__device__ __forceinline__ float wave_shl1(float v) {
+    // lane i receives lane i+1's v; lane 63 keeps its own
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 constexpr int kChunk = 32;           // columns of the row above a strip fetched / published at a time
 
 // DIR = +1: forward scan (rows 1..rows-2, cols 1..cols-2, neighbours above / left);
@@ -352,21 +358,29 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
     float bu = 0.f, bl = 0.f;                                // row above the strip: lane j holds column chunk0 + j
     const int last = rowok ? lane + Cn - 1 : -1;             // this lane visits at steps lane .. last
 
-    auto visit = [&](int t, float4 *q, const float4 cur) {
-        const int idx = t & (kChunk - 1);
-        const float fu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bu), idx));
-        const float fl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bl), idx));
-        const float u1 = wave_shr1(fu, outU), l1 = wave_shr1(fl, outL);
+    // One visit (patolette.pyx:84-119), without branches: b1 / b2 are the barriers through the neighbour above and the one
+    // before; the pixel keeps its state when d <= min(b1, b2), else takes the smaller barrier (the first on a tie) and is
+    // written back.  bu / bl hold the row above the strip, one column per lane, and rotate down one lane per step so that
+    // lane 0 -- whose "lane above" is that row -- always finds its column in its own register (no readlane round trip
+    // through the scalar unit).  The loop-carried chain is shift -> max/min -> sub -> min -> compare -> two selects.
+    auto visit = [&](int t, float4 *q, const float4 cur, const bool steady) {
+        const float u1 = wave_shr1(bu, outU), l1 = wave_shr1(bl, outL);
+        bu = wave_shl1(bu); bl = wave_shl1(bl);
         const float ix = cur.x, d = cur.y;
         const float hu1 = hw_max(u1, ix), hl1 = hw_min(l1, ix);
         const float hu2 = hw_max(outU, ix), hl2 = hw_min(outL, ix);
         const float b1 = hu1 - hl1, b2 = hu2 - hl2;
-        const bool keep = (d <= b1) && (d <= b2);
-        const bool t1 = (b1 < d) && (b1 <= b2);
-        if (t >= lane && t <= last) {
-            outU = keep ? cur.z : (t1 ? hu1 : hu2);
-            outL = keep ? cur.w : (t1 ? hl1 : hl2);
-            if (!keep) *q = make_float4(ix, t1 ? b1 : b2, outU, outL);
+        const float m = hw_min(b1, b2);
+        const bool keep = d <= m;
+        const bool t1 = b1 <= b2;                               // given !keep this is (b1 < d) && (b1 <= b2)
+        const float nu = keep ? cur.z : (t1 ? hu1 : hu2), nl = keep ? cur.w : (t1 ? hl1 : hl2);
+        if (steady) {
+            outU = nu; outL = nl;
+            if (!keep && rowok) *q = make_float4(ix, m, nu, nl);
+        } else {
+            const bool active = t >= lane && t <= last;
+            outU = active ? nu : outU; outL = active ? nl : outL;
+            if (active && !keep) *q = make_float4(ix, m, nu, nl);
         }
     };
     auto chunk_begin = [&](int t0) -> bool {                             // true: gave up waiting
@@ -409,10 +423,20 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
         }
         float4 next[kChunk];
         float4 *q = p + DIR * t0;
+        // every valid lane visits at every step of the block: after the ramp-up (t0 >= 63) and before lane 0 runs out of columns
+        const bool steady = t0 >= 64 && t0 + kChunk <= Cn;
+        if (steady) {
 #pragma unroll
-        for (int j = 0; j < kChunk; j++) {
-            if (j < kChunk / 2) { next[2 * j] = q[DIR * (kChunk + 2 * j)]; next[2 * j + 1] = q[DIR * (kChunk + 2 * j + 1)]; }
-            visit(t0 + j, q + DIR * j, ring[j]);
+            for (int j = 0; j < kChunk; j++) {
+                if (j < kChunk / 2) { next[2 * j] = q[DIR * (kChunk + 2 * j)]; next[2 * j + 1] = q[DIR * (kChunk + 2 * j + 1)]; }
+                visit(t0 + j, q + DIR * j, ring[j], true);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kChunk; j++) {
+                if (j < kChunk / 2) { next[2 * j] = q[DIR * (kChunk + 2 * j)]; next[2 * j + 1] = q[DIR * (kChunk + 2 * j + 1)]; }
+                visit(t0 + j, q + DIR * j, ring[j], false);
+            }
         }
         chunk_end(t0 + kChunk - 1);
 #pragma unroll
