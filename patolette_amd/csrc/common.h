@@ -117,13 +117,22 @@ struct PinBuf {
 
 inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute applies to the current device: a once-flag per device (one process may drive several GPUs)
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 inline int num_cus() {                                      // compute units of the current device (256 on MI355X)
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
 }
 
 }  // namespace pamd

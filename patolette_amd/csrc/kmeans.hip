@@ -1017,12 +1017,11 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     const int cblocks = (nchunks + 3) / 4;
     const size_t lds_cnt = (size_t)8 * k * sizeof(unsigned int);     // k float4 + 4 x k counters
     const size_t lds_sct = (size_t)5 * k * sizeof(unsigned int);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_count, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
-        attr = true;
     }
     { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (k + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p); }
     // many samples: exact candidate pruning (the grid is rebuilt per iteration, ~0.1 ms, against ~1 ms of full scans per
@@ -1032,10 +1031,9 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     const size_t g64_min = getenv("PAMD_KM_G64_MIN") ? (size_t)atoll(getenv("PAMD_KM_G64_MIN")) : ((size_t)1 << 23);
     const int G = nx >= g64_min ? 64 : 32;
     if (use_lut) {
-        static bool attr2 = false;
-        if (!attr2) {
+        static PerDeviceOnce attr2;
+        if (attr2.first()) {
             HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_lut, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
-            attr2 = true;
         }
         w.lut.reserve((size_t)G * G * G * 16); w.bkeys.reserve(kKmSlots * 6); w.grid.reserve(64 + sizeof(double));
         w.clist.reserve((size_t)(G * G * G / 64) * (2 + kKmCoarseMax));
@@ -1059,10 +1057,9 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             if (use_mid) {
                 const int nmid = 32 * 32 * 32;
                 const size_t lds_mid = ((size_t)nmid + 4 * 256 + 16 * 256) * 4 + (size_t)16 * kKmQueue * 16;
-                static bool attr3 = false;
-                if (!attr3) {
+                static PerDeviceOnce attr3;
+                if (attr3.first()) {
                     HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
-                    attr3 = true;
                 }
                 const int mblocks = std::min(num_cus(), (nchunks + 15) / 16);
                 KTIME("k_km_assign", s, 16.0 * nx);

@@ -551,10 +551,9 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
         if (use_mid) {
             constexpr int P = 2;
             const size_t lds_mid = kMidLds;
-            static bool attr_mid = false;
-            if (!attr_mid) {
+            static PerDeviceOnce attr_mid;
+            if (attr_mid.first()) {
                 HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_mid<OutT, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
-                attr_mid = true;
             }
             const int blocks = (int)std::min<size_t>((size_t)num_cus(), ceil_div(n, (size_t)1024 * P));
             KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
@@ -574,10 +573,9 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
             hipLaunchKernelGGL(k_nn_lut_coarse<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, (unsigned short *)w.clist.p);
             hipLaunchKernelGGL(k_nn_lut_build<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, l16, l16b, (const unsigned short *)w.clist.p, (unsigned int *)nullptr);
         }
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce attr;
+        if (attr.first()) {
             HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_lut<OutT, unsigned short>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 8));
-            attr = true;
         }
         KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
         hipLaunchKernelGGL((k_nn_map_lut<OutT, unsigned short>), stream_blocks(n, 8), 256, lds, s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned short *)l16, (const unsigned short *)l16b, out);

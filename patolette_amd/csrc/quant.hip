@@ -586,11 +586,8 @@ static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntile
                           unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s) {
     constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
     size_t lds = (size_t)NQ * 2 * kBuckets * sizeof(double) + 2 * kBuckets * sizeof(unsigned int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_hist<W, GQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) HIP_CHECK(hipFuncSetAttribute((const void *)k_hist<W, GQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KTIME(GQ ? "k_hist_gq" : "k_hist_lq", s, (W ? 34.0 : 26.0) * px);
     // resident blocks per CU by LDS footprint (4 for the local quantiser's 29 KB, 1 for the global quantiser's 82+ KB);
     // each block walks its run of tiles and flushes once per node run
