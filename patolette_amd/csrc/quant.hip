@@ -365,28 +365,46 @@ __global__ __launch_bounds__(256) void k_count(QuantBuffers qb, const Tile *__re
 }
 __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ round_nodes, const int *__restrict__ node_tile0, NodeDev *nodes,
                                               const unsigned int *__restrict__ tilecnt, unsigned long long *tileoff) {
+    // Exclusive prefix of the per-tile child counts of one node (one block per node).  Every thread owns a run of
+    // consecutive tiles: it sums them (eight independent loads in flight at a time), ONE block scan per child orders the
+    // thread totals, and the thread writes the offsets of its tiles -- two block scans for a binary split instead of one
+    // per 1024 tiles with a global load on the carry chain.
     __shared__ unsigned long long su[16];
-    __shared__ unsigned long long carry;
+    __shared__ unsigned long long total;
     NodeDev &nd = nodes[round_nodes[blockIdx.x]];
     const int t0 = node_tile0[blockIdx.x], t1 = node_tile0[blockIdx.x + 1];
+    const int C = (t1 - t0 + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int a = t0 + (int)threadIdx.x * C, b = min(t1, a + C);
     unsigned long long base = nd.begin;
-    for (int k = 0; k < nd.nchild; k++) {
-        if (threadIdx.x == 0) { carry = base; nd.cbegin[k] = base; }
-        __syncthreads();
-        for (int c0 = t0; c0 < t1; c0 += blockDim.x) {
-            int ti = c0 + threadIdx.x;
-            unsigned long long v = ti < t1 ? (unsigned long long)tilecnt[(size_t)ti * kMaxChildren + k] : 0ULL;
-            unsigned long long inc = block_scan_incl<unsigned long long>(v, su);
-            unsigned long long cr = carry;
-            if (ti < t1) tileoff[(size_t)ti * kMaxChildren + k] = cr + inc - v;
-            __syncthreads();
-            if (threadIdx.x == blockDim.x - 1) carry = cr + inc;
-            __syncthreads();
+    const int nch = nd.nchild;
+    for (int k = 0; k < nch; k++) {
+        unsigned long long sum = 0;
+        for (int g = a; g < b; g += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = g + q < b ? tilecnt[(size_t)(g + q) * kMaxChildren + k] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; q++) sum += v[q];
         }
-        base = carry;
+        const unsigned long long inc = block_scan_incl<unsigned long long>(sum, su);
+        if (threadIdx.x == blockDim.x - 1) total = inc;
+        unsigned long long run = base + inc - sum;
+        for (int g = a; g < b; g += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = g + q < b ? tilecnt[(size_t)(g + q) * kMaxChildren + k] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (g + q < b) tileoff[(size_t)(g + q) * kMaxChildren + k] = run;
+                run += v[q];
+            }
+        }
+        if (threadIdx.x == 0) nd.cbegin[k] = base;
+        __syncthreads();
+        base += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) nd.cbegin[nd.nchild] = base;
+    if (threadIdx.x == 0) nd.cbegin[nch] = base;
 }
 
 template <bool W, bool COV>
