@@ -450,7 +450,19 @@ __global__ __launch_bounds__(256, 5) void k_scatter(QuantBuffers qb, const Tile 
             cr[r] = (unsigned)ch | (rk << 8);
         }
         __syncthreads();
-        if ((int)threadIdx.x < nch) {
+        if constexpr (COV) {
+            // binary split: the 2 x (R x 4) per-wave counts are turned into offsets by one wavefront (lane = child * 32 + entry,
+            // 32-lane prefix) instead of two threads walking 32 LDS entries each while the block waits
+            static_assert(R * 4 == 32, "one 32-lane group per child");
+            if (threadIdx.x < 64) {
+                const int k = lane >> 5, e = lane & 31;
+                const unsigned long long c = off[e >> 2][e & 3][k];
+                unsigned long long inc = c;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { const unsigned long long t2 = __shfl_up(inc, o, 32); if (e >= o) inc += t2; }
+                off[e >> 2][e & 3][k] = tileoff[(size_t)ti * kMaxChildren + k] + inc - c;
+            }
+        } else if ((int)threadIdx.x < nch) {
             unsigned long long run = tileoff[(size_t)ti * kMaxChildren + threadIdx.x];
             for (int r = 0; r < R; r++)
                 for (int w = 0; w < 4; w++) { unsigned long long c = off[r][w][threadIdx.x]; off[r][w][threadIdx.x] = run; run += c; }
