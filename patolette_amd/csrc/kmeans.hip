@@ -913,11 +913,152 @@ __device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, siz
     return acc;
 }
 
+// Long chains (many samples per centroid) without waiting a dependent-add latency per sample -- and still bit-exact.
+// While the accumulator s keeps its sign and binade [2^E, 2^(E+1)), every value it takes is a multiple of u = 2^(E-23), and
+//     RN(s + x) = s + u * round_to_nearest(x / u)        unless x / u falls exactly half-way between two integers
+// (then the parity of s decides).  So the sum over a block of samples is the INTEGER sum of rn(x_i / u) -- any order, any
+// grouping -- provided (a) no addend is an exact tie and (b) no partial sum can leave the binade, which holds whatever the
+// order if  M0 + (sum of the negative integers) > 2^23  and  M0 + (sum of the positive ones) < 2^24  (M0 = |s| / u).  A block
+// of 64 x K samples is therefore reduced by the whole wavefront at once; when (a) or (b) fails (early in the chain, at the
+// ~20 binade changes, at a tie every few hundred thousand samples) the same block is replayed in order, 64 adds at a time,
+// from the registers it was loaded into.  For the weighted coordinate sums the addend is the exact product x * w
+// (48 significant bits in f64), as in fma(x, w, s).
+// sum over the wavefront of an f64 (exact integers here), result in every lane: quad butterflies and row mirrors through DPP,
+// the four rows through readlane -- no LDS round trips (ds_bpermute) on the per-block critical path
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(const double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double readlane_f64(const double v, const int l) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_f64<0xB1>(v);                                   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);                                   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);                                  // row_half_mirror
+    v += dpp_f64<0x140>(v);                                  // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+template <bool W, int C>
+__device__ __forceinline__ float km_chain_long(const float4 *__restrict__ sorted, size_t lo, size_t hi, float *replay, int lane) {
+    constexpr int K = 16;                                                  // 1024 samples per block
+    constexpr bool WX = W && C < 3;
+    auto comp = [](const float4 v) { return C == 0 ? v.x : (C == 1 ? v.y : (C == 2 ? v.z : v.w)); };
+    float acc = 0.f;
+    constexpr int D = 4;                                                   // blocks in flight (64 KB per wavefront)
+    constexpr size_t BS = (size_t)64 * K;
+    float4 r0[K], r1[K], r2[K], r3[K];                                     // four separate arrays: stay in registers
+    static_assert(D == 4, "four ring buffers");
+    auto fetch = [&](float4 (&b)[K], const size_t pos) {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const size_t i = pos + (size_t)j * 64 + lane;
+            b[j] = make_float4(0, 0, 0, 0);
+            if (i < hi) b[j] = sorted[i];
+        }
+    };
+    auto process = [&](const float4 (&cur)[K], const size_t pos) {
+        const size_t bend = pos + BS < hi ? pos + BS : hi;
+        bool done = false;
+        const float aa = fabsf(acc);
+        if (aa >= 1e-30f && aa < 1e30f) {                                  // normal, far from the ends of the exponent range
+            int ex;
+            (void)frexpf(aa, &ex);                                         // aa in [2^(ex-1), 2^ex)
+            const double scale = ldexp(acc < 0.f ? -1.0 : 1.0, 24 - ex);   // +-1/u with u = 2^(ex-1-23)
+            const double M0 = (double)aa * fabs(scale);                    // integer in [2^23, 2^24)
+            double tot = 0.0, mag = 0.0, dev = 0.0;                        // sum r, sum |r|, max |t - r|
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const double x = WX ? (double)comp(cur[j]) * (double)cur[j].w : (double)comp(cur[j]);   // samples past hi are zeros
+                const double t = x * scale;                                // exact (power-of-two scaling)
+                const double r = rint(t);
+                dev = fmax(dev, fabs(t - r));                              // 0.5 exactly = a tie somewhere
+                tot += r; mag += fabs(r);
+            }
+            tot = wave_sum_dpp(tot); mag = wave_sum_dpp(mag);              // integers below 2^53: exact in any order
+            const double pp = 0.5 * (tot + mag), nn = 0.5 * (tot - mag);   // sums of the positive / negative integers
+            // (an infinite or NaN addend makes mag non-finite and the comparisons false)
+            if (!__any(dev >= 0.5) && M0 + nn >= 8388609.0 && M0 + pp <= 16777215.0) {
+                acc = (float)(ldexp(M0 + tot, ex - 24) * (acc < 0.f ? -1.0 : 1.0));        // exact: < 2^24 on the same grid
+                done = true;
+            }
+        }
+        if (!done) {
+            // replay the block in order: the lane's sixteen values go to LDS (sample order = j * 64 + lane), then every group
+            // of 64 is sixteen 128-bit broadcast reads followed by its 64 dependent adds
+            float *sc = replay;                                             // [64 * K] component, [64 * K] weight
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                sc[j * 64 + lane] = comp(cur[j]);
+                if constexpr (WX) sc[64 * K + j * 64 + lane] = cur[j].w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (size_t base = pos; base < bend; base += 64) {
+                const int cnt = (int)(bend - base < 64 ? bend - base : 64);
+                const float4 *s4 = reinterpret_cast<const float4 *>(sc + (base - pos)), *w4 = reinterpret_cast<const float4 *>(sc + 64 * K + (base - pos));
+                if (cnt == 64) {
+                    float4 xv[16], wv[WX ? 16 : 1];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) { xv[q] = s4[q]; if constexpr (WX) wv[q] = w4[q]; }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        if constexpr (WX) {
+                            acc = __builtin_fmaf(xv[q].x, wv[q].x, acc); acc = __builtin_fmaf(xv[q].y, wv[q].y, acc);
+                            acc = __builtin_fmaf(xv[q].z, wv[q].z, acc); acc = __builtin_fmaf(xv[q].w, wv[q].w, acc);
+                        } else {
+                            acc += xv[q].x; acc += xv[q].y; acc += xv[q].z; acc += xv[q].w;
+                        }
+                    }
+                } else {
+                    for (int q = 0; 4 * q < cnt; q++) {
+                        const float4 x = s4[q];
+                        float4 w = make_float4(0, 0, 0, 0);
+                        if constexpr (WX) w = w4[q];
+                        const float xs[4] = {x.x, x.y, x.z, x.w}, ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (4 * q + e < cnt) {
+                                if constexpr (WX) acc = __builtin_fmaf(xs[e], ws[e], acc);
+                                else acc += xs[e];
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    if (lo < hi) fetch(r0, lo);
+    if (lo + BS < hi) fetch(r1, lo + BS);
+    if (lo + 2 * BS < hi) fetch(r2, lo + 2 * BS);
+    if (lo + 3 * BS < hi) fetch(r3, lo + 3 * BS);
+#define PAMD_KM_STEP(buf, d)                                                              \
+    {                                                                                     \
+        const size_t pos = p0 + (size_t)(d) * BS;                                         \
+        if (pos < hi) {                                                                   \
+            process(buf, pos);                                                            \
+            if (pos + (size_t)D * BS < hi) fetch(buf, pos + (size_t)D * BS);              \
+        }                                                                                 \
+    }
+    for (size_t p0 = lo; p0 < hi; p0 += (size_t)D * BS) {
+        PAMD_KM_STEP(r0, 0) PAMD_KM_STEP(r1, 1) PAMD_KM_STEP(r2, 2) PAMD_KM_STEP(r3, 3)
+    }
+#undef PAMD_KM_STEP
+    return acc;
+}
+
 template <bool W>
 __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ sorted, const unsigned int *__restrict__ rowtot, int k,
                                                   unsigned long long nx, float *cent, float *hassign, float4 *c4,
-                                                  unsigned int *ticket, DevMT *mt) {
+                                                  unsigned int *ticket, DevMT *mt, unsigned long long long_min) {
     __shared__ float4 stage[4][2][64];
+    __shared__ __attribute__((aligned(16))) float replay[4][W ? 2048 : 1024];    // km_chain_long: one block of samples per chain
     __shared__ float res[4];
     __shared__ int s_last;
     const int kidx = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -928,10 +1069,17 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
     pre = __shfl(pre, 0, 64);
     const size_t lo = pre, hi = lo + rowtot[kidx];
     float acc = 0.f;
-    if (wid == 0) acc = km_chain<W, 0>(sorted, lo, hi, stage[0], lane);
-    else if (wid == 1) acc = km_chain<W, 1>(sorted, lo, hi, stage[1], lane);
-    else if (wid == 2) acc = km_chain<W, 2>(sorted, lo, hi, stage[2], lane);
-    else if (W) acc = km_chain<W, 3>(sorted, lo, hi, stage[3], lane);
+    if ((size_t)(hi - lo) >= long_min) {                                  // block-uniform
+        if (wid == 0) acc = km_chain_long<W, 0>(sorted, lo, hi, replay[0], lane);
+        else if (wid == 1) acc = km_chain_long<W, 1>(sorted, lo, hi, replay[1], lane);
+        else if (wid == 2) acc = km_chain_long<W, 2>(sorted, lo, hi, replay[2], lane);
+        else if (W) acc = km_chain_long<W, 3>(sorted, lo, hi, replay[3], lane);
+    } else {
+        if (wid == 0) acc = km_chain<W, 0>(sorted, lo, hi, stage[0], lane);
+        else if (wid == 1) acc = km_chain<W, 1>(sorted, lo, hi, stage[1], lane);
+        else if (wid == 2) acc = km_chain<W, 2>(sorted, lo, hi, stage[2], lane);
+        else if (W) acc = km_chain<W, 3>(sorted, lo, hi, stage[3], lane);
+    }
     if (lane == 0) res[wid] = acc;
     __syncthreads();
     float c0 = res[0], c1 = res[1], c2 = res[2], h = res[3];
@@ -1044,6 +1192,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     static const bool mid_enabled = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
     const bool use_mid = use_lut && G == 64 && mid_enabled && k % 8 == 0;    // four-candidate table in LDS
     if (use_mid) w.mid.reserve(32 * 32 * 32);
+    // clusters of at least this many samples take the block-parallel exact chain (km_chain_long)
+    const unsigned long long long_min = getenv("PAMD_KM_LONG_MIN") ? (unsigned long long)atoll(getenv("PAMD_KM_LONG_MIN")) : 8192ULL;
     for (int it = 0; it < niter; it++) {
         if (use_lut) {
             {
@@ -1082,8 +1232,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         }
         {
             KTIME("k_km_update", s, 16.0 * nx);
-            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 256, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
-            else hipLaunchKernelGGL(k_km_update<false>, k, 256, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 256, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, long_min);
+            else hipLaunchKernelGGL(k_km_update<false>, k, 256, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, long_min);
         }
     }
     HIP_CHECK(hipGetLastError());

@@ -105,6 +105,7 @@ def test_kmeans_bit_exact_vs_reference_faiss_golden(gpu, monkeypatch, pruned):
         monkeypatch.setenv("PAMD_KM_LUT_MIN", "1")
     if pruned == 2:
         monkeypatch.setenv("PAMD_KM_G64_MIN", "1")
+        monkeypatch.setenv("PAMD_KM_LONG_MIN", "1")         # and every centroid through the block-parallel exact chain
     g = golden("kmeans_ref.npz")
     for ci, (n, k, niter, max_samples, weighted, seed, plant) in enumerate(g["cases"]):
         n, k = int(n), int(k)
