@@ -172,6 +172,27 @@ def test_sharded_batch_takes_8bit_images(gpu):
         assert r[0] and np.array_equal(r[1], one[4]) and np.array_equal(r[2], one[2].reshape(-1))
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_kmeans_long_chains_with_ties_and_binade_changes(gpu, ob, weighted):
+    """Clusters of 8192 samples and more sum their members as exact integer sums per 1024-sample block while the f32
+    accumulator keeps its binade; exact ties of the rounding (the parity of the running sum decides) and blocks that could
+    leave the binade are replayed in order.  Samples taken from a handful of dyadic values make ties the rule rather than
+    the exception, mixed signs make the accumulator wander across binades: centroids bit-identical to the oracle's
+    sequential sums."""
+    n, k = 400000, 16
+    rng = np.random.default_rng(17)
+    vals = np.array([0.5, 0.25, 0.75, -0.125, 0.0625, 1.0, -0.5, 0.3125])
+    pts = vals[rng.integers(0, len(vals), size=(n, 3))] + (rng.integers(0, 4, size=(n, 3)) == 0) * rng.standard_normal((n, 3)) * 1e-3
+    flat = np.ascontiguousarray(pts.T).reshape(-1)
+    w = (1.0 + rng.integers(0, 4, size=n) * 0.5) if weighted else None
+    cent = pts[rng.choice(n, size=k, replace=False)].copy()
+    want = ob.kmeans_refine(flat, w, n, cent, 3, n)
+    c = np.ascontiguousarray(cent.T).reshape(-1).copy()
+    assert gpu.patolette_amd_kmeans_refine(_d(flat), _d(w), n, _d(c), k, 3, n) == 0
+    got = c.reshape(3, k).T
+    assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
+
+
 def test_nn_map_bit_exact(gpu, ob):
     for n, k, seed in [(100000, 256, 1), (5000, 7, 2), (333, 1, 3), (70000, 300, 4)]:
         flat = ob.convert("srgb_to_ictcp", ob.image(n, seed))
