@@ -945,111 +945,112 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-template <bool W, int C>
-__device__ __forceinline__ float km_chain_long(const float4 *__restrict__ sorted, size_t lo, size_t hi, float *replay, int lane) {
-    constexpr int K = 16;                                                  // 1024 samples per block
-    constexpr bool WX = W && C < 3;
-    auto comp = [](const float4 v) { return C == 0 ? v.x : (C == 1 ? v.y : (C == 2 ? v.z : v.w)); };
+// All four chains of a centroid run this way at once and share the loads: per super-step of 4096 samples wavefront w fetches
+// block w (1024 records of 16 bytes) and publishes its four components to LDS ([component][sample], 64 KB); every wavefront
+// then runs ITS chain over the four blocks from there -- 4 bytes per sample read per chain instead of 16 from memory, and the
+// in-order replays read the same buffer.  Two barriers per super-step; the next super-step's records are in flight meanwhile.
+template <bool W>
+__device__ __forceinline__ float km_chain_coop(const float4 *__restrict__ sorted, size_t lo, size_t hi, float *coop, int lane, int wid) {
+    constexpr int K = 16;
+    constexpr size_t BS = (size_t)64 * K, SS = 4 * BS;
+    const bool wx = W && wid < 3;                                          // weighted coordinate chain: acc = fma(x, w, acc)
+    const bool chain = W || wid < 3;                                       // unweighted: the count is analytic, wavefront 3 only loads
+    const float *mine = coop + (size_t)wid * SS, *wts = coop + 3 * SS;
     float acc = 0.f;
-    constexpr int D = 4;                                                   // blocks in flight (64 KB per wavefront)
-    constexpr size_t BS = (size_t)64 * K;
-    float4 r0[K], r1[K], r2[K], r3[K];                                     // four separate arrays: stay in registers
-    static_assert(D == 4, "four ring buffers");
-    auto fetch = [&](float4 (&b)[K], const size_t pos) {
+    float4 reg[K];
+    auto fetch = [&](const size_t p0) {                                    // block `wid` of the super-step starting at p0
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            const size_t i = pos + (size_t)j * 64 + lane;
-            b[j] = make_float4(0, 0, 0, 0);
-            if (i < hi) b[j] = sorted[i];
+            const size_t i = p0 + (size_t)wid * BS + (size_t)j * 64 + lane;
+            reg[j] = make_float4(0, 0, 0, 0);
+            if (i < hi) reg[j] = sorted[i];
         }
     };
-    auto process = [&](const float4 (&cur)[K], const size_t pos) {
-        const size_t bend = pos + BS < hi ? pos + BS : hi;
-        bool done = false;
-        const float aa = fabsf(acc);
-        if (aa >= 1e-30f && aa < 1e30f) {                                  // normal, far from the ends of the exponent range
-            int ex;
-            (void)frexpf(aa, &ex);                                         // aa in [2^(ex-1), 2^ex)
-            const double scale = ldexp(acc < 0.f ? -1.0 : 1.0, 24 - ex);   // +-1/u with u = 2^(ex-1-23)
-            const double M0 = (double)aa * fabs(scale);                    // integer in [2^23, 2^24)
-            double tot = 0.0, mag = 0.0, dev = 0.0;                        // sum r, sum |r|, max |t - r|
+    fetch(lo);
+    for (size_t p0 = lo; p0 < hi; p0 += SS) {
 #pragma unroll
-            for (int j = 0; j < K; j++) {
-                const double x = WX ? (double)comp(cur[j]) * (double)cur[j].w : (double)comp(cur[j]);   // samples past hi are zeros
-                const double t = x * scale;                                // exact (power-of-two scaling)
-                const double r = rint(t);
-                dev = fmax(dev, fabs(t - r));                              // 0.5 exactly = a tie somewhere
-                tot += r; mag += fabs(r);
-            }
-            tot = wave_sum_dpp(tot); mag = wave_sum_dpp(mag);              // integers below 2^53: exact in any order
-            const double pp = 0.5 * (tot + mag), nn = 0.5 * (tot - mag);   // sums of the positive / negative integers
-            // (an infinite or NaN addend makes mag non-finite and the comparisons false)
-            if (!__any(dev >= 0.5) && M0 + nn >= 8388609.0 && M0 + pp <= 16777215.0) {
-                acc = (float)(ldexp(M0 + tot, ex - 24) * (acc < 0.f ? -1.0 : 1.0));        // exact: < 2^24 on the same grid
-                done = true;
-            }
+        for (int j = 0; j < K; j++) {
+            const int o = wid * (int)BS + j * 64 + lane;
+            coop[o] = reg[j].x; coop[SS + o] = reg[j].y; coop[2 * SS + o] = reg[j].z; coop[3 * SS + o] = reg[j].w;
         }
-        if (!done) {
-            // replay the block in order: the lane's sixteen values go to LDS (sample order = j * 64 + lane), then every group
-            // of 64 is sixteen 128-bit broadcast reads followed by its 64 dependent adds
-            float *sc = replay;                                             // [64 * K] component, [64 * K] weight
+        if (p0 + SS < hi) fetch(p0 + SS);                                  // in flight while this super-step is processed
+        __syncthreads();
+        if (chain) {
+            for (int d = 0; d < 4; d++) {
+                const size_t pos = p0 + (size_t)d * BS;
+                if (pos >= hi) break;                                      // wave-uniform
+                const size_t bend = pos + BS < hi ? pos + BS : hi;
+                const float *blk = mine + d * (int)BS, *wblk = wts + d * (int)BS;
+                bool done = false;
+                const float aa = fabsf(acc);
+                if (aa >= 1e-30f && aa < 1e30f) {
+                    int ex;
+                    (void)frexpf(aa, &ex);                                 // aa in [2^(ex-1), 2^ex)
+                    const double sgn = acc < 0.f ? -1.0 : 1.0;
+                    const double scale = ldexp(sgn, 24 - ex);              // +-1/u with u = 2^(ex-1-23)
+                    const double M0 = (double)aa * fabs(scale);            // integer in [2^23, 2^24)
+                    double tot = 0.0, mag = 0.0, dev = 0.0;                // sum r, sum |r|, max |t - r|
 #pragma unroll
-            for (int j = 0; j < K; j++) {
-                sc[j * 64 + lane] = comp(cur[j]);
-                if constexpr (WX) sc[64 * K + j * 64 + lane] = cur[j].w;
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (size_t base = pos; base < bend; base += 64) {
-                const int cnt = (int)(bend - base < 64 ? bend - base : 64);
-                const float4 *s4 = reinterpret_cast<const float4 *>(sc + (base - pos)), *w4 = reinterpret_cast<const float4 *>(sc + 64 * K + (base - pos));
-                if (cnt == 64) {
-                    float4 xv[16], wv[WX ? 16 : 1];
-#pragma unroll
-                    for (int q = 0; q < 16; q++) { xv[q] = s4[q]; if constexpr (WX) wv[q] = w4[q]; }
-#pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        if constexpr (WX) {
-                            acc = __builtin_fmaf(xv[q].x, wv[q].x, acc); acc = __builtin_fmaf(xv[q].y, wv[q].y, acc);
-                            acc = __builtin_fmaf(xv[q].z, wv[q].z, acc); acc = __builtin_fmaf(xv[q].w, wv[q].w, acc);
-                        } else {
-                            acc += xv[q].x; acc += xv[q].y; acc += xv[q].z; acc += xv[q].w;
-                        }
-                    }
-                } else {
-                    for (int q = 0; 4 * q < cnt; q++) {
-                        const float4 x = s4[q];
-                        float4 w = make_float4(0, 0, 0, 0);
-                        if constexpr (WX) w = w4[q];
-                        const float xs[4] = {x.x, x.y, x.z, x.w}, ws[4] = {w.x, w.y, w.z, w.w};
+                    for (int q = 0; q < 4; q++) {                          // 16 samples per lane; any split of the block will do
+                        const float4 xv = *reinterpret_cast<const float4 *>(blk + q * 256 + lane * 4);
+                        float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (wx) wv = *reinterpret_cast<const float4 *>(wblk + q * 256 + lane * 4);
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ws[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            if (4 * q + e < cnt) {
-                                if constexpr (WX) acc = __builtin_fmaf(xs[e], ws[e], acc);
-                                else acc += xs[e];
+                            const double x = (double)xs[e] * (double)ws[e];   // exact product (x itself for w = 1)
+                            const double t = x * scale;
+                            const double r = rint(t);
+                            dev = fmax(dev, fabs(t - r));
+                            tot += r; mag += fabs(r);
+                        }
+                    }
+                    tot = wave_sum_dpp(tot); mag = wave_sum_dpp(mag);
+                    const double pp = 0.5 * (tot + mag), nn = 0.5 * (tot - mag);
+                    if (!__any(dev >= 0.5) && M0 + nn >= 8388609.0 && M0 + pp <= 16777215.0) {
+                        acc = (float)(ldexp(M0 + tot, ex - 24) * sgn);
+                        done = true;
+                    }
+                }
+                if (!done) {                                               // in order, straight from the shared buffer
+                    for (size_t base = pos; base < bend; base += 64) {
+                        const int cnt = (int)(bend - base < 64 ? bend - base : 64);
+                        const float4 *s4 = reinterpret_cast<const float4 *>(blk + (base - pos)), *w4 = reinterpret_cast<const float4 *>(wblk + (base - pos));
+                        if (cnt == 64) {
+                            float4 xv[16], wv[16];
+#pragma unroll
+                            for (int q = 0; q < 16; q++) { xv[q] = s4[q]; if (wx) wv[q] = w4[q]; }
+                            if (wx) {
+#pragma unroll
+                                for (int q = 0; q < 16; q++) {
+                                    acc = __builtin_fmaf(xv[q].x, wv[q].x, acc); acc = __builtin_fmaf(xv[q].y, wv[q].y, acc);
+                                    acc = __builtin_fmaf(xv[q].z, wv[q].z, acc); acc = __builtin_fmaf(xv[q].w, wv[q].w, acc);
+                                }
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 16; q++) { acc += xv[q].x; acc += xv[q].y; acc += xv[q].z; acc += xv[q].w; }
+                            }
+                        } else {
+                            for (int q = 0; 4 * q < cnt; q++) {
+                                const float4 x = s4[q];
+                                float4 w = make_float4(0, 0, 0, 0);
+                                if (wx) w = w4[q];
+                                const float xs[4] = {x.x, x.y, x.z, x.w}, ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    if (4 * q + e < cnt) {
+                                        if (wx) acc = __builtin_fmaf(xs[e], ws[e], acc);
+                                        else acc += xs[e];
+                                    }
+                                }
                             }
                         }
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
         }
-    };
-    if (lo < hi) fetch(r0, lo);
-    if (lo + BS < hi) fetch(r1, lo + BS);
-    if (lo + 2 * BS < hi) fetch(r2, lo + 2 * BS);
-    if (lo + 3 * BS < hi) fetch(r3, lo + 3 * BS);
-#define PAMD_KM_STEP(buf, d)                                                              \
-    {                                                                                     \
-        const size_t pos = p0 + (size_t)(d) * BS;                                         \
-        if (pos < hi) {                                                                   \
-            process(buf, pos);                                                            \
-            if (pos + (size_t)D * BS < hi) fetch(buf, pos + (size_t)D * BS);              \
-        }                                                                                 \
+        __syncthreads();                                                   // the buffer is rewritten by the next super-step
     }
-    for (size_t p0 = lo; p0 < hi; p0 += (size_t)D * BS) {
-        PAMD_KM_STEP(r0, 0) PAMD_KM_STEP(r1, 1) PAMD_KM_STEP(r2, 2) PAMD_KM_STEP(r3, 3)
-    }
-#undef PAMD_KM_STEP
     return acc;
 }
 
@@ -1058,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
                                                   unsigned long long nx, float *cent, float *hassign, float4 *c4,
                                                   unsigned int *ticket, DevMT *mt, unsigned long long long_min) {
     __shared__ float4 stage[4][2][64];
-    __shared__ __attribute__((aligned(16))) float replay[4][W ? 2048 : 1024];    // km_chain_long: one block of samples per chain
+    extern __shared__ __attribute__((aligned(16))) float coop[];          // km_chain_coop: [4 components][4096 samples] when launched with it
     __shared__ float res[4];
     __shared__ int s_last;
     const int kidx = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1069,11 +1070,8 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
     pre = __shfl(pre, 0, 64);
     const size_t lo = pre, hi = lo + rowtot[kidx];
     float acc = 0.f;
-    if ((size_t)(hi - lo) >= long_min) {                                  // block-uniform
-        if (wid == 0) acc = km_chain_long<W, 0>(sorted, lo, hi, replay[0], lane);
-        else if (wid == 1) acc = km_chain_long<W, 1>(sorted, lo, hi, replay[1], lane);
-        else if (wid == 2) acc = km_chain_long<W, 2>(sorted, lo, hi, replay[2], lane);
-        else if (W) acc = km_chain_long<W, 3>(sorted, lo, hi, replay[3], lane);
+    if ((size_t)(hi - lo) >= long_min) {                                  // block-uniform (long_min is huge without the LDS buffer)
+        acc = km_chain_coop<W>(sorted, lo, hi, coop, lane, wid);
     } else {
         if (wid == 0) acc = km_chain<W, 0>(sorted, lo, hi, stage[0], lane);
         else if (wid == 1) acc = km_chain<W, 1>(sorted, lo, hi, stage[1], lane);
@@ -1170,6 +1168,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_count, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
     }
     { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (k + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p); }
     // many samples: exact candidate pruning (the grid is rebuilt per iteration, ~0.1 ms, against ~1 ms of full scans per
@@ -1192,7 +1192,7 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     static const bool mid_enabled = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
     const bool use_mid = use_lut && G == 64 && mid_enabled && k % 8 == 0;    // four-candidate table in LDS
     if (use_mid) w.mid.reserve(32 * 32 * 32);
-    // clusters of at least this many samples take the block-parallel exact chain (km_chain_long)
+    // clusters of at least this many samples take the block-parallel exact chain (km_chain_coop)
     const unsigned long long long_min = getenv("PAMD_KM_LONG_MIN") ? (unsigned long long)atoll(getenv("PAMD_KM_LONG_MIN")) : 8192ULL;
     for (int it = 0; it < niter; it++) {
         if (use_lut) {
@@ -1232,8 +1232,12 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         }
         {
             KTIME("k_km_update", s, 16.0 * nx);
-            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 256, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, long_min);
-            else hipLaunchKernelGGL(k_km_update<false>, k, 256, 0, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, long_min);
+            // the shared 64 KB buffer of the block-parallel chain is only asked for when clusters of that length can exist
+            const bool coop_on = nx >= long_min;
+            const size_t lds_up = coop_on ? (size_t)4 * 4096 * sizeof(float) : 0;
+            const unsigned long long lm = coop_on ? long_min : ~0ULL;
+            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm);
+            else hipLaunchKernelGGL(k_km_update<false>, k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm);
         }
     }
     HIP_CHECK(hipGetLastError());
