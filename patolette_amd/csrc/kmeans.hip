@@ -747,22 +747,35 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__re
     const size_t lo = (size_t)chunk * chunk_len;
     const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
     const unsigned long long lt = (1ULL << lane) - 1ULL;
-    for (size_t base = lo; base < hi; base += 64) {
-        const size_t i = base + lane;
-        const bool v = i < hi;
-        const int a = v ? assign[i] : 0;
-        const unsigned long long valid = __ballot(v);
-        const unsigned long long m = match_mask(a, nbits, valid);
-        unsigned run = 0;
-        if (v) run = cnt[a];                                       // read before the leader bumps it
-        const unsigned r = (unsigned)__popcll(m & lt);
-        if (v) {
-            const size_t dst = prebase ? (size_t)run + r : (size_t)rowbase[a] + table[(size_t)a * nchunks + chunk] + run + r;
+    // four groups of 64 samples per trip: their assignments and coordinates are requested together, the ranks (which chain
+    // through the per-centroid counters) are then taken group by group
+    constexpr int U = 4;
+    for (size_t base = lo; base < hi; base += 64 * U) {
+        int a[U]; bool v[U]; float4 rec[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = base + (size_t)u * 64 + lane;
+            v[u] = i < hi;
+            const size_t j = v[u] ? i : lo;
+            a[u] = assign[j];
             float w = 1.0f;
-            if constexpr (W) w = s.w[i];
-            sorted[dst] = make_float4(s.x[i], s.y[i], s.z[i], w);
+            if constexpr (W) w = s.w[j];
+            rec[u] = make_float4(s.x[j], s.y[j], s.z[j], w);
         }
-        if (v && r == 0) cnt[a] = run + (unsigned)__popcll(m);     // leader
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (base + (size_t)u * 64 >= hi) break;                    // wave-uniform
+            const unsigned long long valid = __ballot(v[u]);
+            const unsigned long long m = match_mask(v[u] ? a[u] : 0, nbits, valid);
+            unsigned run = 0;
+            if (v[u]) run = cnt[a[u]];                                 // read before the leader bumps it
+            const unsigned r = (unsigned)__popcll(m & lt);
+            if (v[u]) {
+                const size_t dst = prebase ? (size_t)run + r : (size_t)rowbase[a[u]] + table[(size_t)a[u] * nchunks + chunk] + run + r;
+                sorted[dst] = rec[u];
+            }
+            if (v[u] && r == 0) cnt[a[u]] = run + (unsigned)__popcll(m);   // leader
+        }
     }
 }
 
