@@ -30,6 +30,11 @@ void patolette_amd_free(void *dptr);
 int  patolette_amd_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int  patolette_amd_memcpy_d2h(void *dst, const void *src, size_t bytes);
 int  patolette_amd_synchronize(void);
+/* Every calling thread works on an engine (HIP stream + workspace, ~170 bytes per pixel of the largest image it has
+ * seen) taken from a per-device pool and handed back when the thread exits.  This call frees the calling thread's
+ * engine and every idle pooled one (the reference frees all internals before patolette() returns,
+ * lib/src/patolette.c:338-341; here the workspace is kept between calls for speed and released on request). */
+void patolette_amd_release_workspace(void);
 /* synthetic inputs generated directly in HBM: planar image of n pixels,
  * plane p pixel i = u(1000*seed + p, i); weights = 1 + 3*u(1000*seed + 7, i) */
 int  patolette_amd_fill_image(double *d_planar, size_t n, uint64_t seed);
@@ -125,7 +130,23 @@ void patolette_amd_batch_u8(size_t count, size_t width, size_t height, const uns
                             unsigned char *const *palettes_u8, void *const *palette_maps, int map_elem_bytes,
                             unsigned char *const *quantized, int *exit_codes);
 
+/* Host images in, index maps LEFT IN HBM: the entry behind patolette_amd.dist: each rank quantises its
+ * shard of the batch and the maps go to rank 0 over RCCL straight from device memory -- no widening to size_t, no PCIe
+ * round trip.  images[i]: pixel_format 0 = planar f64 as patolette() takes it, 1 = (N,3) row-major f64, 3 / 4 = interleaved
+ * 8-bit sRGB with that many bytes per pixel.  d_palette_maps (device, may be NULL): count consecutive maps of
+ * width*height elements of map_elem_bytes (1 when palette_size <= 256, else 4).  Everything else as patolette_amd_batch(). */
+void patolette_amd_batch_dmap(size_t count, size_t width, size_t height, const void *const *images, int pixel_format,
+                              const double *const *weights, double tile_size, size_t palette_size,
+                              const patolette__QuantizationOptions *options, double *const *palettes, void *d_palette_maps,
+                              int map_elem_bytes, int *exit_codes);
+
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
+/* patolette__EIGEN_solve (math/eigen.c:83-140: LAPACK dsyev 'V','L', n = 3) as the split loop's host side solves it:
+ * a column-major 3x3 (lower triangle read) -> w ascending, z = eigenvectors as columns; returns LAPACK's info (0 = ok).
+ * patolette_amd_principal_axis: covariance as (xx,xy,xz,yy,yz,zz) -> eigenvector of the largest eigenvalue incl. its
+ * sign (math/pca.c:122-149 takes column 2); 0 ok.  Pure host code (no device needed). */
+int patolette_amd_eigen_sym3(const double a_colmajor[9], double w[3], double z[9]);
+int patolette_amd_principal_axis(const double cov6[6], double axis[3]);
 /* out[i] = pow(x[i], y) as the colour conversions evaluate it on the device (x >= 0; <= 0.51 ulp) */
 int patolette_amd_pow(const double *x, double y, double *out, size_t n);
 
@@ -171,6 +192,11 @@ typedef struct patolette_amd__Stats {
     size_t kmeans_samples;    /* samples clustered per KMeans iteration */
 } patolette_amd__Stats;
 void patolette_amd_last_stats(patolette_amd__Stats *out);
+/* The palette exactly as the mapping stage of the last full-path call on this thread used it: linear Rec2020 when dithering
+ * (patolette.c:268-299), ICtCp for the nearest-neighbour map (:300-324), before the conversion back to sRGB.  Written
+ * column-major with `capacity_rows` rows when they suffice; returns the number of palette rows.  Lets a parity test feed
+ * the oracle's dither / NN map the very inputs the device stage saw. */
+size_t patolette_amd_last_map_palette(double *out, size_t capacity_rows);
 
 /* ---- per-kernel timing with HIP events on the launch stream ------------------------------ */
 void patolette_amd_profile_enable(int on);   /* also resets the accumulated numbers */

@@ -225,8 +225,13 @@ def quantize_batch(width, height, images, palette_size, weights=None, dither=Tru
             raise ValueError(bad_channel_count.format(d.shape[1] if d.ndim == 2 else "?"))
         if d.shape[0] != n:
             raise ValueError(color_mismatch)
+    if weights is not None and len(weights) != count:
+        raise ValueError("weights must hold one entry (array or None) per image")
     ws = [None] * count if weights is None else [None if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
                                                   for w in weights]
+    for w in ws:
+        if w is not None and w.size != n:
+            raise ValueError("weights must hold width*height values")
     opts = _native.QuantizationOptions(bool(dither), bool(palette_only), int(color_space), int(kmeans_niter),
                                        int(kmeans_max_samples), bool(verbose))
     pals = [np.zeros((palette_size, 3), dtype=np.float64, order='F') for _ in range(count)]
@@ -270,6 +275,8 @@ def quantize_u8_batch(images, palette_size, weights=None, dither=True, palette_o
             raise ValueError("images must be (H, W, 3|4) uint8 arrays of one shape")
     height, width, channels = shape
     n = width * height
+    if weights is not None and len(weights) != count:
+        raise ValueError("weights must hold one entry (array or None) per image")
     ws = [None] * count if weights is None else [None if w is None else np.ascontiguousarray(w, dtype=np.float64).reshape(-1) for w in weights]
     for w in ws:
         if w is not None and w.size != n:

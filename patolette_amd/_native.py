@@ -46,6 +46,12 @@ SYMBOLS = {
     "patolette_amd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "patolette_amd_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "patolette_amd_synchronize": (C.c_int, []),
+    "patolette_amd_release_workspace": (None, []),
+    "patolette_amd_batch_dmap": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.POINTER(dp), C.c_double,
+                                        C.c_size_t, C.POINTER(QuantizationOptions), C.POINTER(dp), C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_int)]),
+    "patolette_amd_eigen_sym3": (C.c_int, [dp, dp, dp]),
+    "patolette_amd_principal_axis": (C.c_int, [dp, dp]),
     "patolette_amd_fill_image": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
     "patolette_amd_fill_weights": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
     "patolette_amd_device": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -76,6 +82,7 @@ SYMBOLS = {
     "patolette_amd_nn_map": (C.c_int, [dp, C.c_size_t, dp, C.c_size_t, zp]),
     "patolette_amd_dither": (C.c_int, [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp]),
     "patolette_amd_last_stats": (None, [C.POINTER(Stats)]),
+    "patolette_amd_last_map_palette": (C.c_size_t, [dp, C.c_size_t]),
     "patolette_amd_profile_enable": (None, [C.c_int]),
     "patolette_amd_profile_only": (None, [C.c_char_p]),
     "patolette_amd_profile_count": (C.c_int, []),

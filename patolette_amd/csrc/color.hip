@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ d
     // per-plane min / max of the OUTPUT (bounds for the binned accumulators downstream)
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     double acc[6] = {0, 0, 0, 0, 0, 0};
+    bool bad = false;                                      // (float)value would be NaN or Inf: at or beyond FLT_MAX + half an ulp
     const bool do_sum = stats != nullptr && sumk.M0 != 0.0;
     constexpr bool kLut = std::is_same<SRC, SrcU8>::value && (WHICH == PAMD_SRGB_TO_ICTCP || WHICH == PAMD_SRGB_TO_CIELUV);
     __shared__ double glut[kLut ? 256 : 1];                // companding of the 256 possible 8-bit values (sRGB.c:70-89)
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ d
         }
         dst[i] = c[0]; dst[n + i] = c[1]; dst[2 * n + i] = c[2];
 #pragma unroll
-        for (int p = 0; p < 3; p++) { mn[p] = fmin(mn[p], c[p]); mx[p] = fmax(mx[p], c[p]); }
+        for (int p = 0; p < 3; p++) { mn[p] = fmin(mn[p], c[p]); mx[p] = fmax(mx[p], c[p]); bad |= !(fabs(c[p]) < 0x1.ffffffp127); }
         if (do_sum) {
 #pragma unroll
             for (int p = 0; p < 3; p++) bin_add(c[p], sumk, acc[2 * p], acc[2 * p + 1]);
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ d
         }
     }
     if (stats) {
+        if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&stats->nonfinite_f32, 1u);
         __shared__ double smn[4][3], smx[4][3];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
@@ -95,6 +97,7 @@ __global__ void k_init_stats(ConvertStats *s) {
         for (int p = 0; p < 3; p++) { s->minkey[threadIdx.x][p] = ~0ULL; s->maxkey[threadIdx.x][p] = 0ULL; s->sum[threadIdx.x][p][0] = 0.0; s->sum[threadIdx.x][p][1] = 0.0; }
         s->wmaxkey[threadIdx.x] = f64_key(0.0);
     }
+    if (threadIdx.x == 0) s->nonfinite_f32 = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_fill_uniform(double *out, size_t n, unsigned long long seed) {

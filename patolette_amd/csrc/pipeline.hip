@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup 
 struct Bounds {
     double cmax, range, wmax; int e_lin, e_quad; double lo[3], hi[3];
     bool have_sum = false; double sum[3] = {0, 0, 0};        // column sums of the converted image, when the conversion took them
+    bool nonfinite = false;                                  // a converted value is NaN / Inf as f32 (KMeans then leaves the centres alone)
 };
 
 static int exp_bound(double v) {                 // smallest E with 2^E > v (v > 0)
@@ -182,6 +183,7 @@ struct Engine {
     patolette_amd__Stats stats{};
     double ms_saliency = 0.0;
     std::string last_error;
+    std::vector<double> map_palette;             // the palette as the mapping stage used it (planar (len,3)): Rec2020 / ICtCp / sRGB
 
     void init() {
         if (stream) return;
@@ -193,9 +195,50 @@ struct Engine {
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     }
     void sync() { HIP_CHECK(hipStreamSynchronize(stream)); if (ktimer().enabled) ktimer().collect(); }
+    ~Engine() {                                  // buffers free themselves (DevBuf / PinBuf); only called while the runtime is alive
+        if (stream) { (void)hipSetDevice(device); (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    }
 };
 
-static Engine &engine() { static thread_local Engine *e = new Engine; return *e; }
+// Engines (HIP stream + ~170 bytes of workspace per pixel of the largest image seen) are pooled per device: a thread
+// takes one at its first call and hands it back when it exits (no HIP call at thread or process exit: the runtime may
+// already be shutting down), so short-lived caller threads neither leak a workspace each nor pay for a new one.
+// patolette_amd_release_workspace() gives the memory back.
+namespace {
+std::mutex g_pool_mu;
+std::vector<Engine *> g_pool;
+Engine *pool_acquire(int device) {               // device < 0: any
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (device < 0 || g_pool[i]->device == device || g_pool[i]->device < 0) {
+                Engine *e = g_pool[i];
+                g_pool.erase(g_pool.begin() + i);
+                if (e->device < 0) e->device = device;
+                return e;
+            }
+    }
+    Engine *e = new Engine;
+    e->device = device;
+    return e;
+}
+void pool_release(Engine *e) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool.push_back(e); }
+struct EngineHolder {
+    Engine *e = nullptr;
+    ~EngineHolder() { if (e) pool_release(e); }
+};
+EngineHolder &holder() { static thread_local EngineHolder h; return h; }
+}  // namespace
+
+static Engine &engine() {
+    EngineHolder &h = holder();
+    if (!h.e) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        h.e = pool_acquire(dev);
+    }
+    return *h.e;
+}
 
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -315,7 +358,7 @@ static bool node_axis(const HNode &h, double axis[3]) {
 // returns centres planar (len,3)
 // --------------------------------------------------------------------------------------------
 static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const Bounds &bnd,
-                             std::vector<double> &centers, size_t &len) {
+                             std::vector<double> &centers, size_t &len, bool verbose = false) {
     hipStream_t s = E.stream;
     const size_t planes = weighted ? 4 : 3;
     E.bufA.reserve(planes * N); E.bufB.reserve(planes * N); E.bkt.reserve(N);
@@ -460,6 +503,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     get_nodes(E, base_ids, got);
     for (size_t i = 0; i < base_ids.size(); i++) absorb_moments(hn[base_ids[i]], got[i]);
     E.stats.n_base_clusters = (size_t)kbase;
+    if (verbose) printf("patolette ======== Base cluster count: %zu\n", (size_t)kbase);     // patolette.c:227-229
     E.stats.ms_gq = now_ms() - t0;
     t0 = now_ms();
 
@@ -496,6 +540,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 result[count] = l;                              // local.c:375-376: palette ORDER
                 result[best] = r;
                 count++;
+                if (verbose) { printf("patolette ======== Processed colors: %zu\r", count); fflush(stdout); }   // local.c:386-389
                 continue;
             }
             if (std::max(best >= 0 ? bv : 0.0, max_unknown) < kDelta) break;   // nothing can reach DELTA
@@ -614,7 +659,8 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
 // --------------------------------------------------------------------------------------------
 // KMeans refinement (refine.c:165-221); centres planar (k,3) f64 in/out
 // --------------------------------------------------------------------------------------------
-static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double> &centers, size_t k, int niter, size_t max_samples) {
+static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double> &centers, size_t k, int niter, size_t max_samples,
+                          bool nonfinite) {
     hipStream_t s = E.stream;
     if (k > (size_t)kKMeansMaxK) throw HipError("patolette_amd: KMeans refinement supports at most 4096 palette entries");
     std::vector<float> cent(3 * k);
@@ -622,7 +668,9 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
     const size_t min_samples = 256 * 256;                                          // refine.c:21
     const size_t ms = std::max(max_samples, min_samples);
     const int mppc = (int)(ms / k);                                                // refine.c:87
-    bool ok = N >= k;                                                              // Clustering.cpp:272-278 (throws -> centres unchanged)
+    // Clustering.cpp:272-278 (fewer points than centroids) and :295-304 (a NaN / Inf among the f32 inputs) throw; refine.c:91
+    // swallows the exception and the palette stays the initial centres
+    bool ok = N >= k && !nonfinite;
     size_t nx = N;
     E.stats.kmeans_samples = 0;
     if (ok) {
@@ -695,6 +743,7 @@ static Bounds read_bounds(Engine &E, bool weighted) {
         for (int t = 0; t < kStatSlots; t++) { p0 += cs.sum[t][p][0]; p1 += cs.sum[t][p][1]; }
         b.sum[p] = p0 + p1;
     }
+    b.nonfinite = cs.nonfinite_f32 != 0u;
     return b;
 }
 
@@ -746,14 +795,13 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     if (opt->verbose) printf("patolette ======== Palette generation \n");
     std::vector<double> pal;
     size_t len = 0;
-    if (quantize_clusters(E, N, K, weighted, bnd, pal, len) != 0) throw HipError("internal quantization error");
-    if (opt->verbose) printf("patolette ======== Base cluster count: %zu\n", (size_t)E.stats.n_base_clusters);
+    if (quantize_clusters(E, N, K, weighted, bnd, pal, len, opt->verbose) != 0) throw HipError("internal quantization error");
 
     // S4: optional KMeans refinement
     t0 = now_ms();
     if (opt->kmeans_niter > 0) {
         if (opt->verbose) printf("patolette ======== KMeans refinement\n");                // patolette.c:249-251
-        kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples);
+        kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples, bnd.nonfinite);
     }
     E.stats.ms_kmeans = now_ms() - t0;
 
@@ -768,6 +816,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
             if (opt->color_space == patolette__CIELuv) { pix = PAMD_CIELUV_TO_REC2020; pf = hm::color::cieluv_to_rec2020; }
             else if (opt->color_space == patolette__ICtCp) { pix = PAMD_ICTCP_TO_REC2020; pf = hm::color::ictcp_to_rec2020; }
             palette_rows(pal, len, pf);
+            E.map_palette = pal;
             if (d_map) {
                 E.aux.reserve(3 * N);
                 launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);          // plane stride of cvt is N for x,y,z
@@ -792,6 +841,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
                 palette_rows(pal, len, hm::color::rec2020_to_srgb);
                 palette_rows(pal, len, hm::color::srgb_to_ictcp);
             }
+            E.map_palette = pal;
             if (d_map) {
                 HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipStreamSynchronize(s));
@@ -901,7 +951,9 @@ static void download_map_widened(Engine &E, const void *d_map, int me, size_t N,
 
 // host-buffer entry: upload, run, download + widen
 static void run_host(Engine &E, size_t width, size_t height, const double *data, const double *weights, double tile_size,
-                     size_t K, const patolette__QuantizationOptions *opt, double *palette, size_t *palette_map, bool rows = false) {
+                     size_t K, const patolette__QuantizationOptions *opt, double *palette, size_t *palette_map, bool rows = false,
+                     void *d_map_out = nullptr) {
+    // d_map_out: leave the narrow index map (u8 for K <= 256, else u32) in HBM there instead of widening it into palette_map
     const size_t N = width * height;
     double t0 = now_ms();
     E.src.reserve(3 * N);
@@ -916,13 +968,13 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     E.ms_saliency = 0.0;
     if (!weights && tile_size > 0.0) d_w = derive_weights(E, E.src.p, nullptr, rows ? -3 : 3, width, height, tile_size);
     const int me = map_elem_for(K);
-    if (!opt->palette_only) E.dmap.reserve(N * (size_t)me);
+    if (!opt->palette_only && !d_map_out) E.dmap.reserve(N * (size_t)me);
     std::vector<double> pal(3 * K);
-    run_device(E, width, height, Pixels{E.src.p, nullptr, 3, rows}, d_w, K, opt, pal.data(), E.dmap.p, me);
+    run_device(E, width, height, Pixels{E.src.p, nullptr, 3, rows}, d_w, K, opt, pal.data(), d_map_out ? d_map_out : (void *)E.dmap.p, me);
     E.stats.ms_saliency = E.ms_saliency;
     E.stats.ms_total += E.ms_saliency;
     t0 = now_ms();
-    if (!opt->palette_only) {
+    if (!opt->palette_only && !d_map_out) {
         const bool touched = !(opt->dither && std::max(width, height) <= 1);   // 1x1 dither visits nothing (riemersma.c:452-456)
         if (touched) {
             download_map_widened(E, E.dmap.p, me, N, palette_map);
@@ -948,7 +1000,7 @@ static void palette_to_u8(const double *palette, size_t K, unsigned char *out) {
 // reconstructed u8 image out.  `pixels`, `d_map_out`, `d_quant_out` are device pointers when `on_device`.
 static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *pixels, int channels, const double *weights,
                    double tile_size, size_t K, const patolette__QuantizationOptions *opt, double *palette, unsigned char *palette_u8,
-                   void *map_out, int map_elem_out, unsigned char *quant_out, bool on_device) {
+                   void *map_out, int map_elem_out, unsigned char *quant_out, bool on_device, bool map_on_device = false) {
     const size_t N = width * height;
     hipStream_t s = E.stream;
     double t0 = now_ms();
@@ -972,7 +1024,7 @@ static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *
     const bool want_map = !opt->palette_only && (map_out || quant_out);
     void *d_map = nullptr;                  // stays null when no map-derived output is wanted: the map kernels are skipped
     if (want_map) {
-        if (on_device && map_out && map_elem_out == me) d_map = map_out;
+        if ((on_device || map_on_device) && map_out && map_elem_out == me) d_map = map_out;
         else { E.dmap.reserve(N * (size_t)me); d_map = E.dmap.p; }
     }
     std::vector<double> pal(3 * K);
@@ -996,7 +1048,7 @@ static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *
             HIP_CHECK(hipStreamSynchronize(s));
         }
         if (map_out && d_map != map_out) {
-            if (on_device) throw HipError("patolette_amd: device map_elem_bytes must be 1 for K <= 256, else 4");
+            if (on_device || map_on_device) throw HipError("patolette_amd: device map_elem_bytes must be 1 for K <= 256, else 4");
             if (map_elem_out == me) HIP_CHECK(hipMemcpy(map_out, d_map, N * (size_t)me, hipMemcpyDeviceToHost));
             else {
                 std::vector<unsigned char> tmp(N * (size_t)me);
@@ -1156,10 +1208,21 @@ int patolette_amd_device_count(void) {
     return c;
 }
 int patolette_amd_set_device(int ordinal) {
-    Engine &E = engine();
-    if (E.stream && E.device != ordinal) return -1;      // one engine (stream, buffers) per thread, bound at first use
-    E.device = ordinal;
-    return hipSetDevice(ordinal) == hipSuccess ? 0 : -1;
+    if (hipSetDevice(ordinal) != hipSuccess) return -1;
+    EngineHolder &h = holder();
+    if (h.e && h.e->stream && h.e->device != ordinal) { pool_release(h.e); h.e = nullptr; }   // bound to another GPU: swap engines
+    if (!h.e) h.e = pool_acquire(ordinal);
+    h.e->device = ordinal;
+    return 0;
+}
+void patolette_amd_release_workspace(void) {
+    // this thread's engine and every idle pooled one: streams destroyed, device and pinned buffers freed; the next call
+    // allocates afresh.  Engines in use by other threads (a batch in flight) are not touched.
+    EngineHolder &h = holder();
+    std::vector<Engine *> victims;
+    if (h.e) { victims.push_back(h.e); h.e = nullptr; }
+    { std::lock_guard<std::mutex> lk(g_pool_mu); victims.insert(victims.end(), g_pool.begin(), g_pool.end()); g_pool.clear(); }
+    for (Engine *e : victims) delete e;
 }
 const char *patolette_amd_last_error(void) { return engine().last_error.c_str(); }
 void *patolette_amd_malloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; return p; }
@@ -1238,21 +1301,6 @@ void patolette_amd_u8_device(size_t width, size_t height, const unsigned char *d
 // Independent images: up to three are in flight at once, each on its own engine (HIP stream + workspace) driven by
 // its own host thread, so the upload / host-side split-loop work of one image overlaps the kernels of another.
 // Engines are pooled per device and reused across calls.
-namespace {
-std::mutex g_pool_mu;
-std::vector<Engine *> g_pool;
-Engine *pool_acquire(int device) {
-    {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        for (size_t i = 0; i < g_pool.size(); i++)
-            if (g_pool[i]->device == device) { Engine *e = g_pool[i]; g_pool.erase(g_pool.begin() + i); return e; }
-    }
-    Engine *e = new Engine;
-    e->device = device;
-    return e;
-}
-void pool_release(Engine *e) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool.push_back(e); }
-}  // namespace
 
 // run item(E, i) for i in [0, count) on pooled engines, `workers` of them in flight
 static void batch_run(size_t count, size_t width, size_t height, const patolette__QuantizationOptions *options, int *exit_codes,
@@ -1333,6 +1381,38 @@ void patolette_amd_batch_u8(size_t count, size_t width, size_t height, const uns
     });
 }
 
+void patolette_amd_batch_dmap(size_t count, size_t width, size_t height, const void *const *images, int pixel_format,
+                              const double *const *weights, double tile_size, size_t palette_size,
+                              const patolette__QuantizationOptions *options, double *const *palettes, void *d_palette_maps,
+                              int map_elem_bytes, int *exit_codes) {
+    int v = validate(width, height, palette_size);
+    if (v == 0 && pixel_format != 0 && pixel_format != 1 && pixel_format != 3 && pixel_format != 4) v = -1;
+    if (v == 0 && d_palette_maps && map_elem_bytes != map_elem_for(palette_size)) {
+        fprintf(stderr, "patolette_amd: device map_elem_bytes must be 1 for K <= 256, else 4\n");
+        v = -1;
+    }
+    if (v != 0) { for (size_t i = 0; i < count; i++) exit_codes[i] = v; return; }
+    const size_t N = width * height;
+    batch_run(count, width, height, options, exit_codes, [&](Engine &E, size_t i) {
+        void *d_map = d_palette_maps ? (void *)((unsigned char *)d_palette_maps + i * N * (size_t)map_elem_bytes) : nullptr;
+        const double *w = weights ? weights[i] : nullptr;
+        if (pixel_format <= 1)
+            run_host(E, width, height, (const double *)images[i], w, tile_size, palette_size, options, palettes[i], nullptr,
+                     pixel_format == 1, d_map);
+        else
+            run_u8(E, width, height, (const unsigned char *)images[i], pixel_format, w, tile_size, palette_size, options, palettes[i],
+                   nullptr, d_map, map_elem_bytes, nullptr, false, true);
+    });
+}
+
+int patolette_amd_principal_axis(const double cov6[6], double axis[3]) {
+    return hm::principal_axis(cov6, axis) ? 0 : -1;
+}
+int patolette_amd_eigen_sym3(const double a_colmajor[9], double w[3], double z[9]) {
+    std::memcpy(z, a_colmajor, 9 * sizeof(double));
+    return hm::eigen_sym3(z, w);                                           // LAPACK info: 0 = converged
+}
+
 void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data, const double *const *weights,
                          double tile_size, size_t palette_size, const patolette__QuantizationOptions *options, double *const *palettes,
                          size_t *const *palette_maps, int *exit_codes) {
@@ -1400,7 +1480,9 @@ int patolette_amd_kmeans_refine(const double *colors, const double *weights, siz
     HIP_CHECK(hipMemcpy(E.cvt.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
     if (weighted) HIP_CHECK(hipMemcpy(E.cvt.p + 3 * n, weights, n * sizeof(double), hipMemcpyHostToDevice));
     std::vector<double> pal(centers_io, centers_io + 3 * k);
-    kmeans_refine(E, n, weighted, pal, k, niter, max_samples);
+    bool nonfinite = false;                                     // Clustering.cpp:295-304 over every colour value as f32
+    for (size_t i = 0; i < 3 * n && !nonfinite; i++) nonfinite = !(std::fabs(colors[i]) < 0x1.ffffffp127);
+    kmeans_refine(E, n, weighted, pal, k, niter, max_samples, nonfinite);
     std::memcpy(centers_io, pal.data(), 3 * k * sizeof(double));
     return 0;
     PAMD_GUARD_END(-1)
@@ -1440,6 +1522,13 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
 }
 
 void patolette_amd_last_stats(patolette_amd__Stats *out) { *out = engine().stats; }
+size_t patolette_amd_last_map_palette(double *out, size_t capacity_rows) {
+    const std::vector<double> &mp = engine().map_palette;
+    const size_t len = mp.size() / 3;
+    if (out && capacity_rows >= len)
+        for (int j = 0; j < 3; j++) for (size_t i = 0; i < len; i++) out[(size_t)j * capacity_rows + i] = mp[(size_t)j * len + i];
+    return len;
+}
 
 void patolette_amd_profile_enable(int on) {
     KernelTimer &t = ktimer();

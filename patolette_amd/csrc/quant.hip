@@ -117,10 +117,10 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
     constexpr int NQS = GQ ? kNQ_GQ : kNQ_LQ;            // slot stride in quantities
     extern __shared__ double lds[];
     double *h = lds;                                       // [NQ][2][512]
-    unsigned int *cnt = (unsigned int *)(h + NQ * 2 * kBuckets);
-    unsigned int *siz = cnt + kBuckets;
+    unsigned long long *siz = (unsigned long long *)(h + NQ * 2 * kBuckets);     // 64-bit: weights may be large (local.c:133 sums in size_t)
+    unsigned int *cnt = (unsigned int *)(siz + kBuckets);
     for (int i = threadIdx.x; i < NQ * 2 * kBuckets; i += blockDim.x) h[i] = 0.0;
-    for (int i = threadIdx.x; i < 2 * kBuckets; i += blockDim.x) cnt[i] = 0u;
+    for (int i = threadIdx.x; i < kBuckets; i += blockDim.x) { cnt[i] = 0u; siz[i] = 0ULL; }
     __syncthreads();
 
     // a block walks consecutive tiles (the tiles of one node are consecutive) and flushes its LDS histogram to HBM
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
                 HADD(0, x * w, klin); HADD(1, y * w, klin); HADD(2, z * w, klin);
                 if constexpr (W) {
                     HADD(3, w, klin);
-                    atomicAdd(&siz[b], (unsigned)(unsigned long long)w);      // size_t += double truncates (local.c:133)
+                    atomicAdd(&siz[b], (unsigned long long)w);               // size_t += double truncates (local.c:133)
                 }
             } else {
                 HADD(0, x, klin); HADD(1, y, klin); HADD(2, z, klin);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
         for (int b = threadIdx.x; b < kBuckets; b += blockDim.x) {
             unsigned c = cnt[b];
             if (c) { atomicAdd(&hcount[slot * kBuckets + b], c); cnt[b] = 0u; }
-            if constexpr (W && !GQ) { unsigned s = siz[b]; if (s) { atomicAdd(&hsize[slot * kBuckets + b], (unsigned long long)s); siz[b] = 0u; } }
+            if constexpr (W && !GQ) { const unsigned long long s = siz[b]; if (s) { atomicAdd(&hsize[slot * kBuckets + b], s); siz[b] = 0ULL; } }
         }
         __syncthreads();
     }
@@ -615,7 +615,7 @@ template <bool W, bool GQ>
 static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, double *d_hist,
                           unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s) {
     constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
-    size_t lds = (size_t)NQ * 2 * kBuckets * sizeof(double) + 2 * kBuckets * sizeof(unsigned int);
+    size_t lds = (size_t)NQ * 2 * kBuckets * sizeof(double) + kBuckets * (sizeof(unsigned int) + sizeof(unsigned long long));
     static PerDeviceOnce attr_set;
     if (attr_set.first()) HIP_CHECK(hipFuncSetAttribute((const void *)k_hist<W, GQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KTIME(GQ ? "k_hist_gq" : "k_hist_lq", s, (W ? 34.0 : 26.0) * px);

@@ -2,12 +2,24 @@
 
 Images are independent (the reference itself is one-image-per-call), so every rank runs the
 full single-GPU pipeline on a contiguous block of the batch and there is NO collective on the
-data path.  torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" in CPU tests) is
-used only for the final gather of results to rank 0: palettes (K*3 f64 = 6 KB/image) and index
-maps as u8 when K <= 256 (1 B/px; never size_t over the fabric).  A direct gather to one root
-uses the 7 distinct inbound xGMI links of that GPU, which a ring all-gather would not.
+data path.  torch.distributed is used only for the final gather of results to rank 0: exit
+codes, palettes (K*3 f64 = 6 KB/image) and index maps as u8 when K <= 256 (1 B/px; never
+size_t over the fabric).  A direct gather to one root uses the 7 distinct inbound xGMI links
+of that GPU, which a ring all-gather would not.
+
+backend "nccl" (= RCCL over xGMI on ROCm): every rank binds its engine to GPU LOCAL_RANK, the
+library leaves each image's index map in HBM (`patolette_amd_batch_dmap`) inside one torch
+tensor per rank, and RCCL gathers exit codes, palettes and maps from device memory.
+backend "gloo" (CPU tests, or GPUs without RCCL): the same protocol on host tensors.
+Import torch (and initialise the process group) BEFORE the first patolette_amd call in such a
+process: torch and libpatolette_amd.so link HIP runtimes of the same SONAME.
 """
+import ctypes as C
+import os
+
 import numpy as np
+
+MESSAGES = {0: "Quantization successful.", -1: "Internal quantization error."}
 
 
 def shard(count, rank, world):
@@ -17,14 +29,25 @@ def shard(count, rank, world):
     return start, base + (1 if rank < rem else 0)
 
 
+def collective_device(dist):
+    """torch.device the collectives of this process group need their tensors on (None = host)."""
+    import torch
+    if dist.get_backend() != "nccl":
+        return None
+    local_rank = int(os.environ.get("LOCAL_RANK", dist.get_rank() % max(1, torch.cuda.device_count())))
+    return torch.device("cuda", local_rank)
+
+
 def gather_to_root(local, dist, root=0, device=None):
-    """Gather equally-shaped per-rank numpy arrays (first axis = local batch, padded to the
-    largest shard) to `root`; returns the list of per-rank arrays on root, None elsewhere."""
+    """Gather per-rank arrays or tensors (first axis = local batch, padded to the largest shard)
+    to `root`; returns the list of per-rank numpy arrays on root, None elsewhere.  `device`:
+    where the collective runs (collective_device(dist)); a tensor already there is gathered
+    in place (the RCCL path hands in the device-resident maps)."""
     import torch
     world = dist.get_world_size()
     rank = dist.get_rank()
-    t = torch.from_numpy(np.ascontiguousarray(local))
-    if device is not None:
+    t = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local))
+    if device is not None and t.device != device:
         t = t.to(device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device))
@@ -34,67 +57,172 @@ def gather_to_root(local, dist, root=0, device=None):
         pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         t = torch.cat([t, pad], dim=0)
     out = [torch.empty_like(t) for _ in range(world)] if rank == root else None
-    dist.gather(t, out, dst=root)
+    dist.gather(t.contiguous(), out, dst=root)
     if rank != root:
         return None
     return [o[:n].cpu().numpy() for o, n in zip(out, sizes)]
 
 
-def quantize_batch_sharded(width, height, images, palette_size, dist=None, quantize_fn=None, weights=None, **kwargs):
-    """Quantise `images` (a list, identical on every rank, or a callable i -> (N,3) float64 array or (H,W,3|4) uint8 image) with
-    the batch sharded over the ranks of `dist`; rank 0 returns [(success, palette, map, message)]
-    for the whole batch in order, the other ranks return None.  With dist=None it is a plain
-    loop.  `quantize_fn` defaults to patolette_amd.quantize (tests inject the CPU oracle to
-    exercise the sharding and gather logic without a GPU)."""
-    batch_fn = None
-    if quantize_fn is None:
-        from . import quantize as quantize_fn
-        from . import quantize_batch as batch_fn          # three images in flight per GPU
+def _check_weights(weights, count, npx):
+    if weights is None:
+        return None
+    if len(weights) != count:
+        raise ValueError("weights must hold one entry (array or None) per image")
+    out = []
+    for w in weights:
+        if w is None:
+            out.append(None)
+            continue
+        w = np.ascontiguousarray(w, dtype=np.float64).reshape(-1)
+        if w.size != npx:
+            raise ValueError("weights must hold width*height values")
+        out.append(w)
+    return out
+
+
+def _quantize_block_to_device(width, height, get, idx, palette_size, weights, device, opts_kw):
+    """This rank's block through patolette_amd_batch_dmap: host images in, maps left in HBM in one torch tensor.
+    Returns (codes int64 (n,1), palettes (n,K,3) f64, maps tensor (n, N) on `device`)."""
+    import torch
+    from . import _native, bad_channel_count, color_mismatch
+    L = _native.lib()
+    npx = width * height
+    n = len(idx)
+    me = 1 if palette_size <= 256 else 4
+    palette_only = bool(opts_kw.get("palette_only", False))
+    maps_t = torch.zeros((n, 0 if palette_only else npx), dtype=torch.uint8 if me == 1 else torch.int32, device=device)
+    codes = np.full((n, 1), -1, dtype=np.int64)
+    pals = np.full((n, palette_size, 3), np.nan)
+    opts = _native.QuantizationOptions(bool(opts_kw.get("dither", True)), palette_only, int(opts_kw.get("color_space", 2)),
+                                       int(opts_kw.get("kmeans_niter", 32)), int(opts_kw.get("kmeans_max_samples", 512 ** 2)), False)
+    tile_size = float(opts_kw.get("tile_size", 512))
+    torch.cuda.current_stream(device).synchronize()               # the library runs on its own streams
+    for g0 in range(0, n, 6):                                     # groups of six bound the host memory held at once
+        grp = list(range(g0, min(g0 + 6, n)))
+        imgs = [np.asarray(get(idx[j])) for j in grp]
+        if all(im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] in (3, 4) for im in imgs):
+            fmt = int(imgs[0].shape[2])
+            if any(im.shape != (height, width, fmt) for im in imgs):
+                raise ValueError("images must be (height, width, 3|4) uint8 arrays of one shape")
+            datas = [np.ascontiguousarray(im) for im in imgs]
+        else:
+            planar = all(im.ndim == 2 and im.dtype == np.float64 and im.flags.f_contiguous and not im.flags.c_contiguous for im in imgs)
+            fmt = 0 if planar else 1
+            datas = imgs if planar else [np.ascontiguousarray(im, dtype=np.float64) for im in imgs]
+            for d in datas:
+                if d.ndim != 2 or d.shape[1] != 3:
+                    raise ValueError(bad_channel_count.format(d.shape[1] if d.ndim == 2 else "?"))
+                if d.shape[0] != npx:
+                    raise ValueError(color_mismatch)
+        cnt = len(grp)
+        ws = None if weights is None else [weights[idx[j]] for j in grp]
+        gp = [np.zeros((palette_size, 3), dtype=np.float64, order="F") for _ in grp]
+        gc = (C.c_int * cnt)()
+        PV, PD = C.c_void_p * cnt, _native.dp * cnt
+        L.patolette_amd_batch_dmap(cnt, width, height, PV(*[d.ctypes.data_as(C.c_void_p) for d in datas]), fmt,
+                                   None if ws is None else PD(*[w.ctypes.data_as(_native.dp) if w is not None else _native.dp() for w in ws]),
+                                   tile_size, palette_size, C.byref(opts), PD(*[p.ctypes.data_as(_native.dp) for p in gp]),
+                                   None if palette_only else C.c_void_p(maps_t[g0].data_ptr()), me, gc)
+        for j, p, c in zip(grp, gp, gc):
+            codes[j, 0] = c
+            if c == 0:
+                pals[j] = p
+    return codes, pals, maps_t
+
+
+def quantize_batch_sharded(width, height, images, palette_size, dist=None, quantize_fn=None, weights=None, narrow_maps=False,
+                           **kwargs):
+    """Quantise `images` (a list, identical on every rank, or a callable i -> (N,3) float64 array or (H,W,3|4) uint8 image,
+    then with count=) with the batch sharded over the ranks of `dist`; rank 0 returns [(success, palette, map, message)]
+    for the whole batch in order, the other ranks return None.  With dist=None it is a plain loop on the current GPU.
+    Keyword arguments and their defaults are those of `patolette_amd.quantize` (tile_size=512 derives saliency weights
+    for images without explicit `weights`, as there).  `narrow_maps` keeps the maps in their device width (uint8 for
+    palette_size <= 256, else int32) instead of widening them to uintp on the root (256 maps of 16 MP are 4 GB narrow,
+    34 GB wide).  A failing image does not raise: its tuple carries success=False and the exit-code message, so every
+    rank reaches the collective.  `quantize_fn` replaces the per-image call (tests inject the CPU oracle to exercise
+    the sharding and gather logic without a GPU)."""
     count = len(images) if not callable(images) else kwargs.pop("count")
     get = images if callable(images) else (lambda i: images[i])
-    kwargs.setdefault("tile_size", 0)
+    npx = width * height
+    weights = _check_weights(weights, count, npx)
     rank, world = (0, 1) if dist is None else (dist.get_rank(), dist.get_world_size())
     start, n = shard(count, rank, world)
-    local = []
-    if batch_fn is not None:
-        for g0 in range(start, start + n, 6):                 # groups of six bound the host memory held at once
-            idx = list(range(g0, min(g0 + 6, start + n)))
-            ws = None if weights is None else [weights[i] for i in idx]
-            group = [get(i) for i in idx]
-            if all(getattr(im, "dtype", None) == np.uint8 and getattr(im, "ndim", 0) == 3 for im in group):
-                # 8-bit images as decoded, (H, W, 3|4): 3 bytes per pixel over PCIe instead of 24
-                from . import quantize_u8_batch
-                kw = {k: v for k, v in kwargs.items() if k != "verbose"}
-                for r in quantize_u8_batch(group, palette_size, weights=ws, want_quantized=False, **kw):
-                    local.append((r[0], r[4], None if r[2] is None else r[2].reshape(-1), r[5]))
-            else:
-                local.extend(batch_fn(width, height, group, palette_size, weights=ws, **kwargs))
-    else:
-        for i in range(start, start + n):
-            w = None if weights is None else weights[i]
-            local.append(quantize_fn(width, height, get(i), palette_size, weights=w, **kwargs))
-    if dist is None:
-        return local
-    npx = width * height
-    ok = np.array([1 if r[0] else 0 for r in local], dtype=np.int64).reshape(-1, 1)
-    pals = np.stack([np.asarray(r[1], dtype=np.float64) if r[1] is not None else np.full((palette_size, 3), np.nan) for r in local]) \
-        if local else np.zeros((0, palette_size, 3))
+    idx = list(range(start, start + n))
     mdt = np.uint8 if palette_size <= 256 else np.int32
     have_map = not kwargs.get("palette_only", False)
-    maps = np.stack([np.asarray(r[2]).astype(mdt) if r[2] is not None else np.zeros(npx, dtype=mdt) for r in local]) \
-        if local else np.zeros((0, npx), dtype=mdt)
-    g_ok = gather_to_root(ok, dist)
-    g_pal = gather_to_root(pals, dist)
-    g_map = gather_to_root(maps, dist) if have_map else None
-    if rank != 0:
-        return None
+    device = collective_device(dist) if dist is not None else None
+
+    messages = dict(MESSAGES)
+    if quantize_fn is None:
+        from . import _native
+        L = _native.lib()
+        for c in range(-6, 1):
+            m = L.get_patolette_exit_code_info_message(c)
+            if m:
+                messages[c] = m.decode("UTF-8")
+
+    if quantize_fn is None and device is not None:
+        # RCCL: bind this rank's engine to its GPU, leave the maps in HBM, gather from there
+        if L.patolette_amd_set_device(device.index) != 0:
+            raise RuntimeError("patolette_amd.dist: cannot bind to GPU %d" % device.index)
+        codes, pals, maps = _quantize_block_to_device(width, height, get, idx, palette_size, weights, device, kwargs)
+    else:
+        codes = np.full((n, 1), -1, dtype=np.int64)
+        pals = np.full((n, palette_size, 3), np.nan)
+        maps = np.zeros((n, npx if have_map else 0), dtype=mdt)
+
+        def put(j, r, code=None):
+            codes[j, 0] = (0 if r[0] else -1) if code is None else code
+            if r[0]:
+                pals[j] = np.asarray(r[1], dtype=np.float64)
+                if have_map and r[2] is not None:
+                    maps[j] = np.asarray(r[2]).reshape(-1).astype(mdt)
+
+        if quantize_fn is None:
+            from . import quantize_batch, quantize_u8_batch
+            for g0 in range(0, n, 6):                             # groups of six bound the host memory held at once
+                grp = list(range(g0, min(g0 + 6, n)))
+                group = [get(idx[j]) for j in grp]
+                ws = None if weights is None else [weights[idx[j]] for j in grp]
+                try:
+                    if all(getattr(im, "dtype", None) == np.uint8 and getattr(im, "ndim", 0) == 3 for im in group):
+                        # 8-bit images as decoded, (H, W, 3|4): 3 bytes per pixel over PCIe instead of 24
+                        kw = {k: v for k, v in kwargs.items() if k != "verbose"}
+                        res = [(r[0], r[4], r[2], r[5]) for r in quantize_u8_batch(group, palette_size, weights=ws, want_quantized=False, **kw)]
+                    else:
+                        res = quantize_batch(width, height, group, palette_size, weights=ws, **kwargs)
+                except (ValueError, np.linalg.LinAlgError) as e:  # saliency stage: shape (-5) / singular covariance (-6)
+                    code = -6 if isinstance(e, np.linalg.LinAlgError) else -5
+                    messages[code] = str(e)
+                    res = [(False, None, None, str(e))] * len(grp)
+                    for j in grp:
+                        put(j, res[0], code)
+                    continue
+                for j, r in zip(grp, res):
+                    put(j, r)
+        else:
+            for j, i in enumerate(idx):
+                w = None if weights is None else weights[i]
+                put(j, quantize_fn(width, height, get(i), palette_size, weights=w, **kwargs))
+
+    if dist is None:
+        g_code, g_pal, g_map = [codes], [pals], [maps.cpu().numpy() if hasattr(maps, "cpu") else maps]
+    else:
+        g_code = gather_to_root(codes, dist, device=device)
+        g_pal = gather_to_root(pals, dist, device=device)
+        g_map = gather_to_root(maps, dist, device=device) if have_map else None
+        if rank != 0:
+            return None
     out = []
-    for r in range(world):
-        for j in range(g_ok[r].shape[0]):
-            success = bool(g_ok[r][j, 0])
-            msg = "Quantization successful." if success else "Internal quantization error."
-            if not success:
+    for r in range(len(g_code)):
+        for j in range(g_code[r].shape[0]):
+            code = int(g_code[r][j, 0])
+            msg = messages.get(code, MESSAGES[-1])
+            if code != 0:
                 out.append((False, None, None, msg))
             else:
-                out.append((True, np.asfortranarray(g_pal[r][j]), g_map[r][j].astype(np.uintp) if have_map else None, msg))
+                m = None
+                if have_map:
+                    m = g_map[r][j] if narrow_maps else g_map[r][j].astype(np.uintp)
+                out.append((True, np.asfortranarray(g_pal[r][j]), m, msg))
     return out

@@ -213,3 +213,35 @@ def test_host_entry_map_equals_device_entry_map(gpu, native, K):
     finally:
         L.patolette_amd_free(img)
         L.patolette_amd_free(dmap)
+
+
+def test_c4_full_size_cieluv_weighted_dither(gpu, native, ob):
+    """BASELINE configs[3] as stated: 8192x8192, 256 colours, CIELuv + weights + Riemersma dither, through the
+    device-resident entry.  The chain is causal, so the first 300 000 steps of the map must equal, bit for bit, the
+    oracle's chain run on the inputs the device stage saw (the device's own Rec2020 pixels -- the same two conversion
+    kernels applied to a host copy -- and the palette as the mapping stage used it); over the whole image every index
+    is a palette row, every row is used, and error diffusion keeps the mean colour."""
+    w = h = 8192
+    n, K, steps = w * h, 256, 300000
+    d = Dev(gpu, n, 7, weighted=True)
+    try:
+        pal, pmap, st = run(native, d, w, h, K, color_space=1, dither=True)
+        L = native.lib()
+        assert st["n_clusters"] == K and np.all(pal >= 0) and np.all(pal <= 1)
+        mp = np.zeros((K, 3), dtype=np.float64, order="F")
+        assert L.patolette_amd_last_map_palette(mp.ctypes.data_as(dp), K) == K
+        rec = d.host_image()
+        assert L.patolette_amd_convert(1, rec.ctypes.data_as(dp), n) == 0      # sRGB -> CIELuv (patolette.c:201-207)
+        assert L.patolette_amd_convert(3, rec.ctypes.data_as(dp), n) == 0      # CIELuv -> linear Rec2020 (patolette.c:276-281)
+        want = ob.dither_prefix(rec, w, h, mp, steps)
+        visited = want != 0xFFFF
+        assert int(visited.sum()) == steps
+        assert np.array_equal(pmap[visited].astype(np.uintp), want[visited])
+        assert pmap.max() < K and len(np.unique(pmap)) == K
+        # error diffusion: the dithered image keeps the mean colour of the original (in the space it is diffused in)
+        mean_img = rec.reshape(3, n).mean(axis=1)
+        counts = np.bincount(pmap, minlength=K).astype(np.float64)
+        mean_map = (counts[:, None] * mp).sum(axis=0) / n
+        assert np.max(np.abs(mean_img - mean_map)) < 2e-3, (mean_img, mean_map)
+    finally:
+        d.free()
