@@ -248,7 +248,9 @@ __device__ __forceinline__ KmBox km_box(const KmGridDev &g, int G, const int idx
     KmBox b; b.cellnorm2 = 0;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const double r = (double)g.hi[a] - (double)g.lo[a], cw = r / G, m = 1e-9 * r + 1e-30;
+        // every box is widened by 1e-5 of the range: k_km_assign_mid finds its cell in f32 (two roundings of 2^-24 and
+        // a scale factor 1 - 2^-18, together < 3e-4 of a 32^3 cell = 1e-5 of the range); km_cell (f64) needs 1e-9
+        const double r = (double)g.hi[a] - (double)g.lo[a], cw = r / G, m = 1e-5 * r + 1e-30;
         b.cl[a] = (double)g.lo[a] + idx[a] * cw - m;
         b.ch[a] = (double)g.lo[a] + (idx[a] + span) * cw + m;
         const double f = fmax(fabs(b.cl[a]), fabs(b.ch[a]));
@@ -323,8 +325,9 @@ __global__ __launch_bounds__(64) void k_km_lut_coarse(const float4 *__restrict__
 // cells with more than four survivors are parked (coordinates + index, 16 bytes) in a per-wavefront LDS queue and go
 // through the 16-byte records of the G^3 table with full wavefronts.
 // --------------------------------------------------------------------------------------------
-constexpr unsigned kKmMidOverflow = 0x00010000u;               // bytes {0, 0, 1, 0}: impossible for a padded list
-__device__ __forceinline__ bool km_mid_is_overflow(unsigned e) { return (e & 0xffu) == ((e >> 8) & 0xffu) && ((e >> 8) & 0xffu) != ((e >> 16) & 0xffu); }
+constexpr int kKmMidSurv = 48;                                 // survivors of the first rule listed per cell of the 32^3 table
+constexpr unsigned kKmMidOverflow = 0x00000001u;               // bytes {1, 0, 0, 0}: SIMD lane 1 before lane 0, impossible for a list
+__device__ __forceinline__ bool km_mid_is_overflow(unsigned e) { return e == kKmMidOverflow; }
 
 // One wavefront fills the eight cells of the 32^3 table inside one coarse block: lane = (cell << 3) | slice, the eight lanes
 // of a cell share the list (slice s takes positions s, s + 8, ...); list order is kept through the ballots.
@@ -354,27 +357,54 @@ __device__ __forceinline__ void km_mid_entries(const float4 *__restrict__ c4, co
     const double thr = km_threshold(b, U, cn2);
     const double margin = thr - U;                              // the absolute rounding margin of the rule (plus 1e-12 U)
     const float4 yq = c4[qs];
-    const double q[3] = {(double)yq.x, (double)yq.y, (double)yq.z};
-    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-    unsigned e = 0; int cnt = 0;
-    for (int t0 = 0; t0 < ntest; t0 += 8) {
+    // `far(p, o)`: the computed distance of entry p exceeds that of entry o on the whole box, beyond rounding: |x-p|^2 - |x-o|^2 is
+    // linear in x, its minimum over the box is taken term by term
+    auto far = [&](const float4 yp, const float4 yo) -> bool {
+        const double p[3] = {(double)yp.x, (double)yp.y, (double)yp.z}, o[3] = {(double)yo.x, (double)yo.y, (double)yo.z};
+        const double o2 = (o[0] * o[0] + o[1] * o[1]) + o[2] * o[2];
+        double f = -o2, scale = o2;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double w = o[a] - p[a];
+            f += 2.0 * fmin(b.cl[a] * w, b.ch[a] * w) + p[a] * p[a];
+            const double big = fmax(fmax(fabs(b.cl[a]), fabs(b.ch[a])), fabs(p[a]));
+            scale += 4.0 * big * big;
+        }
+        return f > margin + 1e-12 * scale;
+    };
+    // first rule + the bisector test against q*; the survivors of the cell are listed in LDS (list order kept)
+    __shared__ unsigned char sv[8][kKmMidSurv];
+    int ns = 0;                                                  // uniform over the eight lanes of a cell
+    for (int t0 = 0; t0 < ntest; t0 += 8) {                      // wave-uniform trip count (ntest is)
         const int t = t0 + sl;
         bool keep = false; int j = 0;
         if (t < ntest) {
             j = entry(t);
             const float4 y = c4[j];
-            if (km_mind2(b, y) <= thr) {
-                const double p[3] = {(double)y.x, (double)y.y, (double)y.z};
-                double f = -q2, scale = q2;
+            keep = km_mind2(b, y) <= thr && !far(y, yq);
+        }
+        const unsigned bits = (unsigned)((__ballot(keep) >> (8 * m)) & 0xffULL);
+        const int pos = ns + __popc(bits & ((1u << sl) - 1u));
+        if (keep && pos < kKmMidSurv) sv[m][pos] = (unsigned char)j;
+        ns += __popc(bits);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // second rule, pairwise: a survivor that is `far` from ANOTHER survivor everywhere in the cell can neither win nor tie there
+    // (being farther is a strict partial order: whatever is dropped is beaten by something that stays), and whatever it would
+    // displace inside its SIMD lane was no winner either.  Cells near a Voronoi vertex keep five or more; most keep <= 4.
+    unsigned e = 0; int cnt = 0;
+    const int nsv = ns <= kKmMidSurv ? ns : 0;
+    int nmax = nsv;                                              // wave-uniform trip count
 #pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    const double w = q[a] - p[a];
-                    f += 2.0 * fmin(b.cl[a] * w, b.ch[a] * w) + p[a] * p[a];
-                    const double big = fmax(fmax(fabs(b.cl[a]), fabs(b.ch[a])), fabs(p[a]));
-                    scale += 4.0 * big * big;
-                }
-                keep = !(f > margin + 1e-12 * scale);            // else: strictly farther than q* on the whole box, beyond rounding
-            }
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    for (int u0 = 0; u0 < nmax; u0 += 8) {
+        const int u = u0 + sl;
+        bool keep = false; int j = 0;
+        if (u < nsv) {
+            j = (int)sv[m][u];
+            const float4 y = c4[j];
+            keep = true;
+            for (int v = 0; v < nsv; v++) { if (v != u && far(y, c4[sv[m][v]])) { keep = false; break; } }
         }
         const unsigned bits = (unsigned)((__ballot(keep) >> (8 * m)) & 0xffULL);
         const int pos = cnt + __popc(bits & ((1u << sl) - 1u));
@@ -383,7 +413,7 @@ __device__ __forceinline__ void km_mid_entries(const float4 *__restrict__ c4, co
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) e |= (unsigned)__shfl_xor((int)e, o, 64);
-    if (cnt > 4) e = kKmMidOverflow;
+    if (cnt > 4 || ns > kKmMidSurv) e = kKmMidOverflow;
     else {
         const unsigned last = (e >> (8 * (cnt - 1))) & 0xffu;
         for (int t = cnt; t < 4; t++) e |= last << (8 * t);
@@ -578,141 +608,235 @@ __device__ __forceinline__ int km_assign_rec4(const float x0, const float x1, co
 }
 
 constexpr int kKmQueue = 48;                                   // parked samples per wavefront (16 B each)
+
+// minimum of two non-negative-or-not doubles given as bit patterns, no canonicalisation (the operands are never NaN here)
+__device__ __forceinline__ double km_min_key(const double a, const double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Four candidates given by their LDS addresses (index << 4 into the centroid records at `lb`), branch-free.  The reference
+// keeps one strict-'<' tracker per SIMD lane (j & 7) over the raw form dp = fma(-2 x2, y2, fma(-2 x1, y1, (-2 x0) y0)) + |y|^2
+// and merges the lane minima by (max(0, dp + |x|^2), index).  With s_t = dp_t + |x|^2 >= 0 for every candidate, the winner of
+// that procedure is the candidate with the smallest (s, index) over ALL candidates, unless two candidates of one lane share
+// the smallest s with different dp (the tracker then prefers the smaller dp, not the smaller index): s is monotone in dp, so
+// a lane's tracker holds a smallest-s member, and among equal s the merge takes the smallest index.  {s bits : address} is
+// one 64-bit key (s >= 0: bit patterns order like values; read as a positive double, v_min_f64 is its 64-bit minimum).
+// Returns the winner's address; `doubt` is set when some OTHER index reaches the smallest s or the smallest s is negative
+// (the reference clamps: ties at 0) -- then the caller runs the exact procedure; on real data a handful per million.
+// The order of the four and repeated entries (padding) do not matter.
+__device__ __forceinline__ double km_eval4(const float x0, const float x1, const float x2, const char *lb, const unsigned (&ad)[4], bool &doubt) {
+    const float m0 = -2 * x0, m1 = -2 * x1, m2 = -2 * x2;
+    const float xn = __builtin_fmaf(x2, x2, __builtin_fmaf(x0, x0, x1 * x1));
+    int sb[4];
+    double key[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float4 y = *reinterpret_cast<const float4 *>(lb + ad[t]);
+        float d = m0 * y.x;
+        d = __builtin_fmaf(m1, y.y, d);
+        d = __builtin_fmaf(m2, y.z, d);
+        d = d + y.w;
+        sb[t] = __float_as_int(d + xn);
+        key[t] = __hiloint2double(sb[t], (int)ad[t]);
+    }
+    const double kmin = km_min_key(km_min_key(key[0], key[1]), km_min_key(key[2], key[3]));
+    const int smin = __double2hiint(kmin);
+    const unsigned amin = (unsigned)__double2loint(kmin);
+    unsigned flag = (unsigned)(smin < 0);                                       // no short circuits: no branches
+#pragma unroll
+    for (int t = 0; t < 4; t++) flag |= (unsigned)(sb[t] == smin) & (unsigned)(ad[t] != amin);
+    doubt = flag != 0u;
+    return kmin;                                                                // {s bits : address} of the winner
+}
+
+// Parked samples of k_km_assign_mid, a (nearly) full wavefront at a time: the 64^3 records hold up to fifteen candidates, but
+// the cell of a sample is an eighth of the crowded one and four suffice for most -- the evaluation above on the first four
+// entries (records are padded with their last); longer lists and doubtful samples take the exact procedure.  Called from ONE
+// place (the code is long; several inlined copies cost more in instruction fetch than the drains themselves).
+struct KmDrainGrid { float lo[3], inv64[3]; int sane; };
+__device__ __forceinline__ void km_mid_drain(const int n, const uint4 *q, const float4 *lc4, unsigned int *cnt, unsigned char *assign_chunk,
+                                          const unsigned char *__restrict__ lut, const int k, const KmDrainGrid dg) {
+    const int lane = threadIdx.x & 63;
+    int a = 0;
+    uint4 it = make_uint4(0u, 0u, 0u, 0u), rec = it;
+    bool exact = false;
+    if (lane < n) {
+        it = q[lane];
+        const float a0 = __uint_as_float(it.x), a1 = __uint_as_float(it.y), a2 = __uint_as_float(it.z);
+        const unsigned ix = __float2uint_rz((a0 - dg.lo[0]) * dg.inv64[0]), iy = __float2uint_rz((a1 - dg.lo[1]) * dg.inv64[1]),
+                       iz = __float2uint_rz((a2 - dg.lo[2]) * dg.inv64[2]);
+        rec = reinterpret_cast<const uint4 *>(lut)[dg.sane ? ((iz << 12) | (iy << 6) | ix) : 0u];
+        const unsigned ad[4] = {(rec.x >> 4) & 0xff0u, (rec.x >> 12) & 0xff0u, (rec.x >> 20) & 0xff0u, (rec.y << 4) & 0xff0u};
+        bool doubt;
+        double kw = km_eval4(a0, a1, a2, (const char *)lc4, ad, doubt);
+        const unsigned cnt = rec.x & 0xffu;
+        if (__any(cnt > 4u && cnt <= 8u)) {
+            // entries five to eight the same way; the two groups combine like two candidates: the smaller key wins, equal s
+            // at different addresses is a doubt (a record's padding repeats its LAST entry, so for cnt <= 4 group B is all
+            // one entry of group A and changes nothing)
+            if (cnt > 4u) {
+                const unsigned ad2[4] = {(rec.y >> 4) & 0xff0u, (rec.y >> 12) & 0xff0u, (rec.y >> 20) & 0xff0u, (rec.z << 4) & 0xff0u};
+                bool doubt2;
+                const double k2 = km_eval4(a0, a1, a2, (const char *)lc4, ad2, doubt2);
+                doubt = doubt || doubt2 || (__double2hiint(k2) == __double2hiint(kw) && __double2loint(k2) != __double2loint(kw));
+                kw = km_min_key(kw, k2);
+            }
+        }
+        a = (int)((unsigned)__double2loint(kw) >> 4);
+        exact = doubt || cnt > 8u || !dg.sane;
+    }
+    if (__any(exact)) {
+        if (exact) {
+            if (!dg.sane) rec.x = 255u;                                           // full scan
+            a = km_assign_rec4(__uint_as_float(it.x), __uint_as_float(it.y), __uint_as_float(it.z), lc4, k, rec);
+        }
+    }
+    if (lane < n) {
+        assign_chunk[it.w] = (unsigned char)a;                                    // after (program order) the packed store that left a 0 here
+        atomicAdd(&cnt[a], 1u);
+    }
+}
+
+// LDS (uints): centroid records [0, 1024) | per-wavefront counters [1024, 5120) | 32^3 table [5120, 37888) | parked samples
+template <int ABL, int PG>
 __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k,
-                                                        int chunk_len, int nchunks, int *__restrict__ assign, unsigned int *table,
+                                                        int chunk_len, int nchunks, unsigned char *__restrict__ assign, unsigned int *table,
                                                         const KmGridDev *__restrict__ gp, const unsigned int *__restrict__ mid,
                                                         const unsigned char *__restrict__ lut) {
+    // assign: ONE BYTE per sample (k <= 256 here): 13 bytes of traffic per sample instead of 16, and k_km_scatter reads a
+    // quarter.  Per trip a lane takes PG groups of four CONSECUTIVE samples (group g = samples 256 g + 4 lane ...): three 16-byte
+    // loads in and one packed 4-byte store out per group.
     extern __shared__ unsigned int lds_u[];
-    constexpr int G = 64, Gm = 32, ncell = Gm * Gm * Gm, P = 4;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    unsigned int *T = lds_u;                                                      // [ncell]
-    float4 *lc4 = (float4 *)(lds_u + ncell);                                      // [256]
-    unsigned int *cnt = lds_u + ncell + 4 * 256 + (size_t)wid * 256;              // this wavefront's counters
-    uint4 *q = (uint4 *)(lds_u + ncell + 4 * 256 + 16 * 256) + wid * kKmQueue;    // this wavefront's parked samples
+    constexpr int Gm = 32, ncell = Gm * Gm * Gm, P = 4 * PG;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: chunk bounds and bases live in SGPRs
+    float4 *lc4 = (float4 *)lds_u;                                                // [256] at byte 0: a candidate's address is its index << 4
+    unsigned int *cnt = lds_u + 4 * 256 + (size_t)wid * 256;                      // this wavefront's counters
+    unsigned int *T = lds_u + 4 * 256 + 16 * 256;                                 // [ncell]
+    uint4 *q = (uint4 *)(T + ncell) + wid * kKmQueue;                             // this wavefront's parked samples
     for (int i = threadIdx.x; i < ncell / 4; i += 1024) ((uint4 *)T)[i] = ((const uint4 *)mid)[i];
     for (int j = threadIdx.x; j < 256; j += 1024) lc4[j] = j < k ? c4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = lane; j < 256; j += 64) cnt[j] = 0u;
     __syncthreads();
     const KmGridDev g = *gp;
-    double glo[3], ginv[3];
+    // Grid cells in f32: t = (x - lo) * inv with inv = G' (1 - 2^-18) / range rounded to f32 (G' = 32 for the table in LDS, 64 for
+    // the records).  x - lo >= 0 (lo is the exact minimum), three roundings of 2^-24 and the factor 1 - 2^-18 keep t in
+    // [0, G') and within 3e-4 of a cell of the exact position: the boxes both tables were built from are wider than that
+    // (km_box).  Ranges f32 cannot handle without overflow or underflow send every sample through the exact full scan.
+    float flo[3], finv[3], finv64[3];
+    bool sane = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const double r = (double)g.hi[a] - (double)g.lo[a];
-        glo[a] = (double)g.lo[a];
-        ginv[a] = r > 0 ? (double)G / r : 0.0;                                    // km_cell's arithmetic
+        flo[a] = g.lo[a];
+        finv[a] = r > 0 ? (float)(32.0 * (1.0 - 0x1.0p-18) / r) : 0.f;
+        finv64[a] = r > 0 ? (float)(64.0 * (1.0 - 0x1.0p-18) / r) : 0.f;
+        sane = sane && fabsf(g.lo[a]) < 1e18f && fabsf(g.hi[a]) < 1e18f && (r == 0 || r > 1e-30);
     }
-    auto cell3 = [&](const float a0, const float a1, const float a2, int &ix, int &iy, int &iz) {
-        ix = (int)(((double)a0 - glo[0]) * ginv[0]); iy = (int)(((double)a1 - glo[1]) * ginv[1]); iz = (int)(((double)a2 - glo[2]) * ginv[2]);
-        ix = max(0, min(ix, G - 1)); iy = max(0, min(iy, G - 1)); iz = max(0, min(iz, G - 1));
-    };
+    KmDrainGrid dg;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { dg.lo[a] = flo[a]; dg.inv64[a] = finv64[a]; }
+    dg.sane = sane ? 1 : 0;
     const unsigned long long ltmask = (1ULL << lane) - 1ULL;
+    const char *lb = (const char *)lc4;
     for (int chunk = blockIdx.x * 16 + wid; chunk < nchunks; chunk += gridDim.x * 16) {
         const size_t lo = (size_t)chunk * chunk_len;
         const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
         int qn = 0;                                                               // wave-uniform
-        auto count = [&](const unsigned a) { atomicAdd(&cnt[a], 1u); };
-        auto drain = [&](const int first, const int n) {                          // parked samples through the G^3 records
-            if (lane < n) {
-                const uint4 it = q[first + lane];
-                const float a0 = __uint_as_float(it.x), a1 = __uint_as_float(it.y), a2 = __uint_as_float(it.z);
-                int ix, iy, iz;
-                cell3(a0, a1, a2, ix, iy, iz);
-                const uint4 rec = reinterpret_cast<const uint4 *>(lut)[(iz * G + iy) * G + ix];
-                const int a = km_assign_rec4(a0, a1, a2, lc4, k, rec);
-                assign[lo + it.w] = a;
-                count((unsigned)a);
+        auto drain = [&](const int n) { km_mid_drain(n, q, lc4, cnt, assign + lo, lut, k, dg); };
+        // the samples of trip n+1 are requested before trip n is evaluated (a wavefront owns its chunk: nothing else hides
+        // the memory latency at four wavefronts per SIMD)
+        float n0[P], n1[P], n2[P];
+        auto fetch = [&](const size_t base) {
+            const unsigned left = (unsigned)min((size_t)(64 * P), hi - base);    // wave-uniform base + 32-bit lane offsets
+            const float *bx = s.x + base, *by = s.y + base, *bz = s.z + base;
+            if (left == 64u * P) {                                               // chunks start at multiples of 64 samples: 16-byte aligned
+#pragma unroll
+                for (int gq = 0; gq < PG; gq++) {
+                    const float4 v0 = reinterpret_cast<const float4 *>(bx)[64 * gq + lane], v1 = reinterpret_cast<const float4 *>(by)[64 * gq + lane],
+                                 v2 = reinterpret_cast<const float4 *>(bz)[64 * gq + lane];
+                    n0[4 * gq] = v0.x; n0[4 * gq + 1] = v0.y; n0[4 * gq + 2] = v0.z; n0[4 * gq + 3] = v0.w;
+                    n1[4 * gq] = v1.x; n1[4 * gq + 1] = v1.y; n1[4 * gq + 2] = v1.z; n1[4 * gq + 3] = v1.w;
+                    n2[4 * gq] = v2.x; n2[4 * gq + 1] = v2.y; n2[4 * gq + 2] = v2.z; n2[4 * gq + 3] = v2.w;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const unsigned j = min(256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3), left - 1u);
+                    n0[p] = bx[j]; n1[p] = by[j]; n2[p] = bz[j];
+                }
             }
         };
+        if (lo < hi) fetch(lo);
         for (size_t base = lo; base < hi; base += 64 * P) {
             float x0[P], x1[P], x2[P];
             bool v[P];
-            const unsigned left = (unsigned)min((size_t)(64 * P), hi - base);    // wave-uniform base + 32-bit lane offsets
-            const float *bx = s.x + base, *by = s.y + base, *bz = s.z + base;
-            int *ba = assign + base;
+            const unsigned left = (unsigned)min((size_t)(64 * P), hi - base);
+            unsigned char *ba = assign + base;
 #pragma unroll
-            for (int p = 0; p < P; p++) {
-                const unsigned t = (unsigned)p * 64u + (unsigned)lane;
-                v[p] = t < left;
-                const unsigned j = min(t, left - 1u);
-                x0[p] = bx[j]; x1[p] = by[j]; x2[p] = bz[j];
-            }
+            for (int p = 0; p < P; p++) { x0[p] = n0[p]; x1[p] = n1[p]; x2[p] = n2[p]; v[p] = 256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3) < left; }
+            unsigned packed[PG];
+#pragma unroll
+            for (int gq = 0; gq < PG; gq++) packed[gq] = 0u;
+            if (base + 64 * P < hi) fetch(base + 64 * P);
             unsigned e[P];
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                int ix, iy, iz;
-                cell3(x0[p], x1[p], x2[p], ix, iy, iz);
-                e[p] = T[((iz >> 1) * Gm + (iy >> 1)) * Gm + (ix >> 1)];
+                const unsigned ix = __float2uint_rz((x0[p] - flo[0]) * finv[0]), iy = __float2uint_rz((x1[p] - flo[1]) * finv[1]),
+                               iz = __float2uint_rz((x2[p] - flo[2]) * finv[2]);
+                e[p] = *reinterpret_cast<const unsigned int *>(reinterpret_cast<const char *>(T) + (sane ? ((iz << 12) | (iy << 7) | (ix << 2)) : 0u));
             }
             unsigned ovbits = 0;
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                const bool ov = v[p] && km_mid_is_overflow(e[p]);
-                ovbits |= ov ? (1u << p) : 0u;
-                // The four candidates (k % 8 == 0: no scalar leftovers), branch-free.  The reference keeps one strict-'<'
-                // tracker per SIMD lane (j & 7) over the raw dot-product form, then merges the lane minima by
-                // (clamped distance, index).  The entry is sorted by lane, so the members of a lane are adjacent: a running
-                // tracker is merged whenever the lane changes.  (distance >= 0, so its bit pattern orders like the value
-                // and {distance bits : index} compares as one 64-bit key.)
-                const float m0 = -2 * x0[p], m1 = -2 * x1[p], m2 = -2 * x2[p];
-                const float xn = __builtin_fmaf(x2[p], x2[p], __builtin_fmaf(x0[p], x0[p], x1[p] * x1[p]));
-                unsigned jj[4]; float dp[4];
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    jj[t] = (e[p] >> (8 * t)) & 0xffu;
-                    const float4 y = lc4[jj[t]];
-                    float d = m0 * y.x;
-                    d = __builtin_fmaf(m1, y.y, d);
-                    d = __builtin_fmaf(m2, y.z, d);
-                    dp[t] = d + y.w;
-                }
-                unsigned long long key = ~0ULL;                                   // {cur_d = FLT_MAX.., cur_i = 0xFFFFFFFF}
-                float trd = dp[0]; unsigned tri = jj[0];
-                auto merge = [&](const bool doit) {
-                    float cand = trd + xn;
-                    cand = cand < 0 ? 0.f : cand;
-                    const unsigned long long kk = ((unsigned long long)__float_as_uint(cand) << 32) | tri;
-                    key = (doit && kk < key) ? kk : key;
-                };
-#pragma unroll
-                for (int t = 1; t < 4; t++) {
-                    const bool newlane = ((jj[t] ^ jj[t - 1]) & 7u) != 0u;
-                    merge(newlane);
-                    const bool better = newlane || dp[t] < trd;
-                    trd = better ? dp[t] : trd; tri = better ? jj[t] : tri;
-                }
-                merge(true);
-                const unsigned cur_i = (unsigned)key;
-                if (v[p] && !ov) { ba[(unsigned)p * 64u + (unsigned)lane] = (int)cur_i; count(cur_i); }
+                // the (up to) four candidates of the cell (k % 8 == 0: no scalar leftovers in the reference's procedure)
+                const unsigned ad[4] = {(e[p] << 4) & 0xff0u, (e[p] >> 4) & 0xff0u, (e[p] >> 12) & 0xff0u, (e[p] >> 20) & 0xff0u};
+                bool doubt;
+                const unsigned cur_i = (unsigned)__double2loint(km_eval4(x0[p], x1[p], x2[p], lb, ad, doubt)) >> 4;
+                const bool park = (doubt || e[p] == kKmMidOverflow || !sane) && v[p] && !(ABL & 2);
+                ovbits |= park ? (1u << p) : 0u;
+                if (v[p] && !park) { packed[p >> 2] |= cur_i << (8 * (p & 3)); atomicAdd(&cnt[cur_i], 1u); }
             }
-            if (__ballot(ovbits != 0u)) {                                         // rare enough per slot; one copy of the slow code
+            if (left == 64u * P) {                                                // parked samples: 0 for now, the drain writes theirs
 #pragma unroll
-                for (int p = 0; p < P; p++) {
-                    const bool ov = (ovbits >> p) & 1u;
-                    const unsigned long long m = __ballot(ov);
-                    if (!m) continue;
-                    const float a0 = p == 0 ? x0[0] : p == 1 ? x0[1] : p == 2 ? x0[2] : x0[3];
-                    const float a1 = p == 0 ? x1[0] : p == 1 ? x1[1] : p == 2 ? x1[2] : x1[3];
-                    const float a2 = p == 0 ? x2[0] : p == 1 ? x2[1] : p == 2 ? x2[2] : x2[3];
-                    const unsigned rel = (unsigned)(base - lo) + (unsigned)p * 64u + (unsigned)lane;
-                    const int rank = (int)__popcll(m & ltmask), b = (int)__popcll(m);
-                    int done = 0;
-                    while (done < b) {                                            // wave-uniform
-                        const int take = min(kKmQueue - qn, b - done);
-                        if (ov && rank >= done && rank < done + take) q[qn + rank - done] = make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(a2), rel);
-                        qn += take; done += take;
-                        if (qn == kKmQueue) { drain(0, qn); qn = 0; }
+                for (int gq = 0; gq < PG; gq++) reinterpret_cast<unsigned int *>(ba)[64 * gq + lane] = packed[gq];
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; p++) if (v[p]) ba[256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3)] = (unsigned char)(packed[p >> 2] >> (8 * (p & 3)));
+            }
+            const bool lasttrip = base + 64 * P >= hi;
+            if (__ballot(ovbits != 0u) || lasttrip) {
+                // park: the samples of this trip are numbered slot-major (all of slot 0, then slot 1, ...); as many as fit go
+                // into the queue, a full queue is drained, and so on -- one loop around ONE drain site
+                unsigned long long m[P];
+                int off[P + 1];
+                off[0] = 0;
+#pragma unroll
+                for (int p = 0; p < P; p++) { m[p] = __ballot((ovbits >> p) & 1u); off[p + 1] = off[p] + (int)__popcll(m[p]); }
+                const int btot = off[P];
+                int done = 0;
+                do {                                                              // wave-uniform
+                    const int take = min(kKmQueue - qn, btot - done);
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const int gr = off[p] + (int)__popcll(m[p] & ltmask) - done;
+                        if (((ovbits >> p) & 1u) && gr >= 0 && gr < take)
+                            q[qn + gr] = make_uint4(__float_as_uint(x0[p]), __float_as_uint(x1[p]), __float_as_uint(x2[p]),
+                                                    (unsigned)(base - lo) + 256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3));
                     }
-                }
+                    qn += take; done += take;
+                    if (qn == kKmQueue || (lasttrip && done == btot)) { drain(qn); qn = 0; }
+                } while (done < btot);
             }
         }
-        drain(0, qn);
         for (int j = lane; j < k; j += 64) { table[(size_t)j * nchunks + chunk] = cnt[j]; cnt[j] = 0u; }
     }
 }
 
 // second half of the sort: samples -> (x,y,z,w) records grouped by centroid, sample order kept
-template <bool W>
-__global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__restrict__ assign, size_t nx, int k, int nbits,
+template <bool W, typename AT>
+__global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const AT *__restrict__ assign, size_t nx, int k, int nbits,
                                                     int chunk_len, int nchunks, const unsigned int *__restrict__ table,
                                                     const unsigned int *__restrict__ rowtot, float4 *sorted) {
     extern __shared__ unsigned int lds_u[];
@@ -757,7 +881,7 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const int *__re
             const size_t i = base + (size_t)u * 64 + lane;
             v[u] = i < hi;
             const size_t j = v[u] ? i : lo;
-            a[u] = assign[j];
+            a[u] = (int)assign[j];
             float w = 1.0f;
             if constexpr (W) w = s.w[j];
             rec[u] = make_float4(s.x[j], s.y[j], s.z[j], w);
@@ -1179,8 +1303,10 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     static PerDeviceOnce attr;
     if (attr.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_count, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true, int>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false, int>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true, unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false, unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
     }
@@ -1222,12 +1348,23 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
                 const size_t lds_mid = ((size_t)nmid + 4 * 256 + 16 * 256) * 4 + (size_t)16 * kKmQueue * 16;
                 static PerDeviceOnce attr3;
                 if (attr3.first()) {
-                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
                 }
                 const int mblocks = std::min(num_cus(), (nchunks + 15) / 16);
+                static const int abl = getenv("PAMD_KM_ABL") ? atoi(getenv("PAMD_KM_ABL")) : 0;      // TEMPORARY ablation switch
                 KTIME("k_km_assign", s, 16.0 * nx);
-                hipLaunchKernelGGL(k_km_assign_mid, mblocks, 1024, lds_mid, s, ks, nx, w.c4.p, k, chunk_len, nchunks, w.assign.p, w.table.p,
-                                   (const KmGridDev *)w.grid.p, (const unsigned int *)w.mid.p, (const unsigned char *)w.lut.p);
+                static const int pg = getenv("PAMD_KM_PG") ? atoi(getenv("PAMD_KM_PG")) : 1;          // TEMPORARY
+#define PAMD_MID(A) hipLaunchKernelGGL((k_km_assign_mid<A, 1>), mblocks, 1024, lds_mid, s, ks, nx, w.c4.p, k, chunk_len, nchunks, (unsigned char *)w.assign.p, w.table.p, \
+                                   (const KmGridDev *)w.grid.p, (const unsigned int *)w.mid.p, (const unsigned char *)w.lut.p)
+#define PAMD_MID2(A) hipLaunchKernelGGL((k_km_assign_mid<A, 2>), mblocks, 1024, lds_mid, s, ks, nx, w.c4.p, k, chunk_len, nchunks, (unsigned char *)w.assign.p, w.table.p, \
+                                   (const KmGridDev *)w.grid.p, (const unsigned int *)w.mid.p, (const unsigned char *)w.lut.p)
+                if (pg == 2) { if (abl == 2) PAMD_MID2(2); else PAMD_MID2(0); }
+                else { if (abl == 2) PAMD_MID(2); else PAMD_MID(0); }
+#undef PAMD_MID2
+#undef PAMD_MID
             } else {
             KTIME("k_km_assign", s, 16.0 * nx);
             hipLaunchKernelGGL(k_km_assign_lut, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p,
@@ -1239,9 +1376,15 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         }
         { KTIME("k_km_rowscan", s, 8.0 * k * nchunks); hipLaunchKernelGGL(k_km_rowscan, k, 256, 0, s, w.table.p, nchunks, w.rowtot.p); }
         {
-            KTIME("k_km_scatter", s, (weighted ? 36.0 : 32.0) * nx);
-            if (weighted) hipLaunchKernelGGL(k_km_scatter<true>, cblocks, 256, lds_sct, s, ks, w.assign.p, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
-            else hipLaunchKernelGGL(k_km_scatter<false>, cblocks, 256, lds_sct, s, ks, w.assign.p, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+            KTIME("k_km_scatter", s, (weighted ? 36.0 : 32.0) * nx - (use_mid ? 3.0 : 0.0) * nx);
+            const unsigned char *a8 = (const unsigned char *)w.assign.p;               // k_km_assign_mid leaves one byte per sample
+            if (use_mid) {
+                if (weighted) hipLaunchKernelGGL((k_km_scatter<true, unsigned char>), cblocks, 256, lds_sct, s, ks, a8, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+                else hipLaunchKernelGGL((k_km_scatter<false, unsigned char>), cblocks, 256, lds_sct, s, ks, a8, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+            } else {
+                if (weighted) hipLaunchKernelGGL((k_km_scatter<true, int>), cblocks, 256, lds_sct, s, ks, (const int *)w.assign.p, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+                else hipLaunchKernelGGL((k_km_scatter<false, int>), cblocks, 256, lds_sct, s, ks, (const int *)w.assign.p, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+            }
         }
         {
             KTIME("k_km_update", s, 16.0 * nx);

@@ -66,3 +66,21 @@ def test_python_surface_validation_messages():
                                                                     "tile_size parameter expected to be in the range [0, inf]")
     assert (p.ColorSpace_sRGB, p.ColorSpace_CIELuv, p.ColorSpace_ICtCp) == (0, 1, 2)
     assert {"quantize", "ColorSpace_sRGB", "ColorSpace_CIELuv", "ColorSpace_ICtCp"} <= set(p.__all__)
+
+
+def test_batch_entry_rejects_malformed_weights(native):
+    """quantize_batch validates the weights before anything reaches the C ABI (a short array would be read out of bounds)."""
+    import numpy as np
+    import pytest
+    import patolette_amd as p
+    imgs = [np.zeros((12, 3)), np.zeros((12, 3))]
+    with pytest.raises(ValueError):
+        p.quantize_batch(4, 3, imgs, 2, weights=[np.ones(12)])              # one entry per image
+    with pytest.raises(ValueError):
+        p.quantize_batch(4, 3, imgs, 2, weights=[np.ones(12), np.ones(5)])  # width*height values each
+    u8 = [np.zeros((3, 4, 3), dtype=np.uint8)] * 2
+    with pytest.raises(ValueError):
+        p.quantize_u8_batch(u8, 2, weights=[np.ones(12)])
+    from patolette_amd import dist as pdist
+    with pytest.raises(ValueError):
+        pdist.quantize_batch_sharded(4, 3, imgs, 2, weights=[np.ones(12), np.ones(11)], quantize_fn=lambda *a, **k: None)

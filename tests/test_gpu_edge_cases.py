@@ -138,3 +138,90 @@ def test_kmeans_beyond_supported_palette_size_fails_loudly(gpu, native, ob):
     code = C.c_int(0)
     L.patolette(w, h, _d(flat), None, K, C.byref(opts), pal.ctypes.data_as(dp), pmap.ctypes.data_as(zp), C.byref(code))
     assert code.value == -1 and "4096" in native.last_error()
+
+
+def test_kmeans_skipped_when_a_value_is_not_finite_as_float(gpu, native, ob):
+    """faiss scans the f32 training set for NaN / Inf and throws (Clustering.cpp:295-304); refine.c:91 swallows the
+    exception, so the palette stays the (float-rounded) initial centres.  A pixel of 1e39 is finite in f64 and Inf once
+    cast to float.  (Such an outlier spans more than the ~80 bits of dynamic range the order-independent sums of the HIP
+    split loop keep below the largest value -- DESIGN.md section 2 -- so the palettes themselves are not compared with the
+    oracle here: the point is that KMeans leaves them alone.)"""
+    w, h, K = 64, 48, 12
+    n = w * h
+    flat = ob.image(n, 3)
+    flat[n + 17] = 1e39
+    L = native.lib()
+
+    def hip(niter):
+        opts = native.QuantizationOptions(False, True, 0, niter, 65536, False)
+        pal = np.zeros((K, 3), dtype=np.float64, order="F")
+        code = C.c_int(99)
+        L.patolette(w, h, _d(flat), None, K, C.byref(opts), pal.ctypes.data_as(dp), None, C.byref(code))
+        assert code.value == 0
+        return pal
+    pal0, pal4 = hip(0), hip(4)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(pal4, np.where(pal0 == -1, -1.0, pal0.astype(np.float32).astype(np.float64)))
+    flat[n + 17] = 0.5                                          # the same image without the outlier: KMeans does move the palette
+    assert not np.array_equal(hip(4), hip(0))
+    # the stage on its own: centres come back float-rounded and otherwise untouched
+    cent = ob.image(K, 4).reshape(3, K).T.copy()
+    cio = np.ascontiguousarray(cent.T).reshape(-1).copy()
+    flat[5] = np.nan
+    assert native.lib().patolette_amd_kmeans_refine(_d(flat), None, n, _d(cio), K, 3, 65536) == 0
+    assert np.array_equal(cio.reshape(3, K).T, cent.astype(np.float32).astype(np.float64))
+
+
+def test_product_eigen_solver_vs_lapack_golden_and_oracle(gpu, native, ob):
+    """The split loop's host-side 3x3 eigen-solve (host_math.h, what pipeline.hip calls) against the LAPACK the reference
+    calls (eigen.c:83-140 -> dsyev; golden from OpenBLAS 0.3.28) incl. the eigenvector SIGN, and bit for bit against the
+    oracle's restatement on 20 000 random covariance-like matrices."""
+    from tests.util import bits, golden
+    L = native.lib()
+
+    def solve(a):
+        buf = np.asfortranarray(np.array(a, dtype=np.float64)).reshape(-1, order="F").copy()
+        wv, z = np.zeros(3), np.zeros(9)
+        info = L.patolette_amd_eigen_sym3(_d(buf), _d(wv), _d(z))
+        return info, wv, z.reshape(3, 3, order="F")
+    g = golden("eigen_lapack.npz")
+    exact = 0
+    for a, wv, v in zip(g["A"], g["W"], g["V"]):
+        info, w2, v2 = solve(a)
+        assert info == 0
+        scale = max(1e-300, np.max(np.abs(wv)))
+        assert np.max(np.abs(wv - w2)) <= 1e-13 * scale
+        assert np.max(np.abs(v[:, 2] - v2[:, 2])) < 1e-9
+        if np.all(np.diff(wv) > 1e-6 * scale):
+            assert np.max(np.abs(v - v2)) < 1e-8
+        exact += np.array_equal(bits(v), bits(v2))
+        ax = np.zeros(3)
+        c6 = np.array([a[0, 0], a[1, 0], a[2, 0], a[1, 1], a[2, 1], a[2, 2]])
+        assert L.patolette_amd_principal_axis(_d(c6), _d(ax)) == 0 and np.array_equal(bits(ax), bits(v2[:, 2]))
+    assert exact > 0.4 * len(g["A"])
+    rng = np.random.default_rng(0)
+    for _ in range(20000):
+        m = rng.normal(size=(3, 3)) * 10.0 ** rng.integers(-6, 3)
+        a = m @ m.T
+        i1, w1, v1 = solve(a)
+        i2, w2, v2 = ob.eigen_sym3(a)
+        assert i1 == i2 and np.array_equal(bits(w1), bits(w2)) and np.array_equal(bits(v1), bits(v2))
+
+
+def test_release_workspace_and_thread_engines(gpu, native, ob):
+    """Engines are pooled: a short-lived thread hands its engine back at exit, release_workspace frees the idle ones, and
+    the next call works (and gives the same answer) on a fresh workspace."""
+    import threading
+    import patolette_amd as p
+    w, h, K = 80, 60, 10
+    colors = ob.image(w * h, 21).reshape(3, -1).T.copy()
+    first = p.quantize(w, h, colors, K, dither=False, tile_size=0, kmeans_niter=2)
+    box = []
+    for _ in range(3):
+        t = threading.Thread(target=lambda: box.append(p.quantize(w, h, colors, K, dither=False, tile_size=0, kmeans_niter=2)))
+        t.start()
+        t.join()
+    native.lib().patolette_amd_release_workspace()
+    box.append(p.quantize(w, h, colors, K, dither=False, tile_size=0, kmeans_niter=2))
+    for r in box:
+        assert r[0] and np.array_equal(r[1], first[1]) and np.array_equal(r[2], first[2])
