@@ -700,7 +700,6 @@ __device__ __forceinline__ void km_mid_drain(const int n, const uint4 *q, const 
 }
 
 // LDS (uints): centroid records [0, 1024) | per-wavefront counters [1024, 5120) | 32^3 table [5120, 37888) | parked samples
-template <int ABL, int PG>
 __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k,
                                                         int chunk_len, int nchunks, unsigned char *__restrict__ assign, unsigned int *table,
                                                         const KmGridDev *__restrict__ gp, const unsigned int *__restrict__ mid,
@@ -709,7 +708,7 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
     // quarter.  Per trip a lane takes PG groups of four CONSECUTIVE samples (group g = samples 256 g + 4 lane ...): three 16-byte
     // loads in and one packed 4-byte store out per group.
     extern __shared__ unsigned int lds_u[];
-    constexpr int Gm = 32, ncell = Gm * Gm * Gm, P = 4 * PG;
+    constexpr int Gm = 32, ncell = Gm * Gm * Gm, PG = 1, P = 4 * PG;       // PG = 2 needs more than 128 VGPRs: slower
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: chunk bounds and bases live in SGPRs
     float4 *lc4 = (float4 *)lds_u;                                                // [256] at byte 0: a candidate's address is its index << 4
     unsigned int *cnt = lds_u + 4 * 256 + (size_t)wid * 256;                      // this wavefront's counters
@@ -794,7 +793,7 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
                 const unsigned ad[4] = {(e[p] << 4) & 0xff0u, (e[p] >> 4) & 0xff0u, (e[p] >> 12) & 0xff0u, (e[p] >> 20) & 0xff0u};
                 bool doubt;
                 const unsigned cur_i = (unsigned)__double2loint(km_eval4(x0[p], x1[p], x2[p], lb, ad, doubt)) >> 4;
-                const bool park = (doubt || e[p] == kKmMidOverflow || !sane) && v[p] && !(ABL & 2);
+                const bool park = (doubt || e[p] == kKmMidOverflow || !sane) && v[p];
                 ovbits |= park ? (1u << p) : 0u;
                 if (v[p] && !park) { packed[p >> 2] |= cur_i << (8 * (p & 3)); atomicAdd(&cnt[cur_i], 1u); }
             }
@@ -1348,23 +1347,12 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
                 const size_t lds_mid = ((size_t)nmid + 4 * 256 + 16 * 256) * 4 + (size_t)16 * kKmQueue * 16;
                 static PerDeviceOnce attr3;
                 if (attr3.first()) {
-                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
-                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
-                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
-                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
                 }
                 const int mblocks = std::min(num_cus(), (nchunks + 15) / 16);
-                static const int abl = getenv("PAMD_KM_ABL") ? atoi(getenv("PAMD_KM_ABL")) : 0;      // TEMPORARY ablation switch
                 KTIME("k_km_assign", s, 16.0 * nx);
-                static const int pg = getenv("PAMD_KM_PG") ? atoi(getenv("PAMD_KM_PG")) : 1;          // TEMPORARY
-#define PAMD_MID(A) hipLaunchKernelGGL((k_km_assign_mid<A, 1>), mblocks, 1024, lds_mid, s, ks, nx, w.c4.p, k, chunk_len, nchunks, (unsigned char *)w.assign.p, w.table.p, \
-                                   (const KmGridDev *)w.grid.p, (const unsigned int *)w.mid.p, (const unsigned char *)w.lut.p)
-#define PAMD_MID2(A) hipLaunchKernelGGL((k_km_assign_mid<A, 2>), mblocks, 1024, lds_mid, s, ks, nx, w.c4.p, k, chunk_len, nchunks, (unsigned char *)w.assign.p, w.table.p, \
-                                   (const KmGridDev *)w.grid.p, (const unsigned int *)w.mid.p, (const unsigned char *)w.lut.p)
-                if (pg == 2) { if (abl == 2) PAMD_MID2(2); else PAMD_MID2(0); }
-                else { if (abl == 2) PAMD_MID(2); else PAMD_MID(0); }
-#undef PAMD_MID2
-#undef PAMD_MID
+                hipLaunchKernelGGL(k_km_assign_mid, mblocks, 1024, lds_mid, s, ks, nx, w.c4.p, k, chunk_len, nchunks, (unsigned char *)w.assign.p, w.table.p,
+                                   (const KmGridDev *)w.grid.p, (const unsigned int *)w.mid.p, (const unsigned char *)w.lut.p);
             } else {
             KTIME("k_km_assign", s, 16.0 * nx);
             hipLaunchKernelGGL(k_km_assign_lut, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p,

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64) void k_nn_lut_coarse(const double *__restrict__
 // (byte 0 > byte 1, impossible for an ascending list); their pixels are queued per wavefront in LDS and taken 64 at a
 // time through the G^3 records, so that path runs with full wavefronts too.
 // --------------------------------------------------------------------------------------------
+constexpr int kMidSurv = 48;                                   // survivors of the first rule listed per cell of the (G/2)^3 table
 constexpr unsigned kMidOverflow = 0x00000001u;                 // bytes {1, 0, 0, 0}
 
 // One wavefront fills the eight cells of the (G/2)^3 table that lie in one coarse block: lane = (cell << 3) | slice, the
@@ -154,26 +155,55 @@ __device__ __forceinline__ void nn_mid_entries(const double *__restrict__ pal, c
         if (u2 < U || (u2 == U && q2i < qs)) { U = u2; qs = q2i; }
     }
     const double thr = U * (1.0 + 1e-12) + 1e-300;
-    const double q[3] = {px[qs], py[qs], pz[qs]};
-    const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-    unsigned entry = 0; int cnt = 0;                             // cnt: uniform over the eight lanes of a cell
+    // `far(p, o)`: |x-p|^2 - |x-o|^2 > 0 on the whole (widened) box, with a 1e-12 relative margin: linear in x, so the minimum over the
+    // box is taken term by term; p is then strictly farther than o everywhere in the cell and can neither win nor tie
+    auto far = [&](const int jp, const int jo) -> bool {
+        const double p[3] = {px[jp], py[jp], pz[jp]}, o[3] = {px[jo], py[jo], pz[jo]};
+        const double o2 = (o[0] * o[0] + o[1] * o[1]) + o[2] * o[2];
+        double f = -o2, scale = o2;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double w = o[a] - p[a];
+            f += 2.0 * fmin(cl[a] * w, ch[a] * w) + p[a] * p[a];
+            const double big = fmax(fmax(fabs(cl[a]), fabs(ch[a])), fabs(p[a]));
+            scale += 4.0 * big * big;
+        }
+        return f > 1e-12 * scale + 1e-300;
+    };
+    // first rule + the bisector test against q*; the survivors of the cell are listed in LDS (ascending index)
+    __shared__ unsigned char sv[8][kMidSurv];
+    int ns = 0;                                                  // uniform over the eight lanes of a cell
     for (int t0 = 0; t0 < ntest; t0 += 8) {                      // wave-uniform trip count (ntest is)
         const int t = t0 + sl;
         bool keep = false; int j = 0;
         if (t < ntest) {
             j = all ? t : (int)cand[1 + t];
             const double p[3] = {px[j], py[j], pz[j]};
-            double mn = 0, f = -q2, scale = q2;
+            double mn = 0;
 #pragma unroll
-            for (int a = 0; a < 3; a++) {
-                const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0);
-                mn += d * d;
-                const double w = q[a] - p[a];
-                f += 2.0 * fmin(cl[a] * w, ch[a] * w) + p[a] * p[a];      // min over the box of |x-p|^2 - |x-q|^2, term by term
-                const double big = fmax(fmax(fabs(cl[a]), fabs(ch[a])), fabs(p[a]));
-                scale += 4.0 * big * big;
-            }
-            keep = mn <= thr && !(f > 1e-12 * scale + 1e-300);
+            for (int a = 0; a < 3; a++) { const double d = fmax(fmax(cl[a] - p[a], p[a] - ch[a]), 0.0); mn += d * d; }
+            keep = mn <= thr && !far(j, qs);
+        }
+        const unsigned bits = (unsigned)((__ballot(keep) >> (8 * m)) & 0xffULL);
+        const int pos = ns + __popc(bits & ((1u << sl) - 1u));
+        if (keep && pos < kMidSurv) sv[m][pos] = (unsigned char)j;
+        ns += __popc(bits);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // second rule, pairwise among the survivors (being strictly farther is a strict partial order: whatever is dropped is beaten by
+    // something that stays).  Cells near a Voronoi vertex keep five or more; most keep <= 4.
+    unsigned entry = 0; int cnt = 0;
+    const int nsv = ns <= kMidSurv ? ns : 0;
+    int nmax = nsv;                                              // wave-uniform trip count
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    for (int u0 = 0; u0 < nmax; u0 += 8) {
+        const int u = u0 + sl;
+        bool keep = false; int j = 0;
+        if (u < nsv) {
+            j = (int)sv[m][u];
+            keep = true;
+            for (int v = 0; v < nsv; v++) { if (v != u && far(j, (int)sv[m][v])) { keep = false; break; } }
         }
         const unsigned bits = (unsigned)((__ballot(keep) >> (8 * m)) & 0xffULL);
         const int pos = cnt + __popc(bits & ((1u << sl) - 1u));
@@ -182,7 +212,7 @@ __device__ __forceinline__ void nn_mid_entries(const double *__restrict__ pal, c
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) entry |= (unsigned)__shfl_xor((int)entry, o, 64);
-    if (cnt > 4) entry = kMidOverflow;
+    if (cnt > 4 || ns > kMidSurv) entry = kMidOverflow;
     else {
         const unsigned last = (entry >> (8 * (cnt - 1))) & 0xffu;
         for (int t = cnt; t < 4; t++) entry |= last << (8 * t);
@@ -367,64 +397,82 @@ __global__ __launch_bounds__(256) void k_nn_map_lut(const double *__restrict__ c
 // palette as three f64 arrays in LDS (6 KB): leaves room for the overflow queues next to the 128 KB table
 struct PalSoA { const double *x, *y, *z; };
 
-__device__ __forceinline__ int nn_eval_rec(const double x, const double y, const double z, LutRec<unsigned char> rec, const size_t cell,
-                                           const unsigned char *__restrict__ lut2, const PalSoA sp, const int k) {
-    const int cnt = rec.next();
+constexpr int kMidQueue = 56;                                  // overflow pixels parked per wavefront (28 B each)
+constexpr size_t kMidLds = 131072 + 3 * 256 * 8 + 16 * kMidQueue * 28;
+
+// One parked pixel through its record of the G^3 table: the first eight entries unconditionally in two groups of four (a record is
+// padded with its last entry, and re-evaluating an entry cannot change a strict-'<' arg-min), the second group only when some lane
+// of the wavefront holds more than four; longer lists and overflowed cells (rare) take the general loop.
+__device__ __forceinline__ int nn_drain_one(const double x, const double y, const double z, const size_t cell, const unsigned char *__restrict__ lut,
+                                            const unsigned char *__restrict__ lut2, const PalSoA sp, const int k) {
+    const uint4 r = *reinterpret_cast<const uint4 *>(lut + cell * 16);
+    const int cnt = (int)(r.x & 0xffu);
     double bd = INFINITY; int best = 0;
     auto test = [&](const int j) {
         const double d0 = x - sp.x[j], d1 = y - sp.y[j], d2 = z - sp.z[j];
         const double d = (d0 * d0 + d1 * d1) + d2 * d2;
         if (d < bd) { bd = d; best = j; }                       // ascending j + strict '<' = lowest index on ties
     };
-    if (cnt != 255) {
-        // the first four unconditionally (records are padded with their last entry; 99 % of them hold no more), the rest
-        // only if some lane of the wavefront has more
-        test(rec.next()); test(rec.next()); test(rec.next()); test(rec.next());
-        if (!__any(cnt > 4)) return best;
-        const int n1 = cnt < 15 ? cnt : 15;
-        for (int t = 4; t < n1; t++) test(rec.next());
-        if (cnt > 15) {
-            LutRec<unsigned char> r2;
-            r2.load(lut2 + cell * 16);
-            for (int t = 15; t < cnt; t++) test(r2.next());
+    test((int)((r.x >> 8) & 0xffu)); test((int)((r.x >> 16) & 0xffu)); test((int)(r.x >> 24)); test((int)(r.y & 0xffu));
+    if (__any(cnt > 4)) {
+        test((int)((r.y >> 8) & 0xffu)); test((int)((r.y >> 16) & 0xffu)); test((int)(r.y >> 24)); test((int)(r.z & 0xffu));
+        if (__any(cnt > 8)) {
+            if (cnt == 255) { bd = INFINITY; best = 0; for (int j = 0; j < k; j++) test(j); }
+            else if (cnt > 8) {
+                LutRec<unsigned char> rec;
+                rec.load(lut + cell * 16);
+                bd = INFINITY; best = 0;
+                (void)rec.next();
+                const int n1 = cnt < 15 ? cnt : 15;
+                for (int t = 0; t < n1; t++) test(rec.next());
+                if (cnt > 15) {
+                    LutRec<unsigned char> r2;
+                    r2.load(lut2 + cell * 16);
+                    for (int t = 15; t < cnt; t++) test(r2.next());
+                }
+            }
         }
-    } else {
-        for (int j = 0; j < k; j++) test(j);
     }
     return best;
 }
 
-constexpr int kMidQueue = 56;                                  // overflow pixels parked per wavefront (28 B each)
-constexpr size_t kMidLds = 131072 + 3 * 256 * 8 + 16 * kMidQueue * 28;
-
+// 1024 threads = 16 wavefronts per CU around the 128 KB table.  A wavefront streams its own tiles of 64 * P pixels: a lane takes
+// P / 2 pairs of CONSECUTIVE pixels (pair g = pixels 128 g + 2 lane, + 1): one 16-byte load per plane and pair, the next tile's
+// loads in flight while this one is evaluated, one packed store per pair.
 template <typename OutT, int P>
 __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ c, size_t N, size_t n, const double *__restrict__ pal, int k,
                                                      NNGrid g, const unsigned int *__restrict__ mid, const unsigned char *__restrict__ lut,
                                                      const unsigned char *__restrict__ lut2, OutT *__restrict__ out) {
     extern __shared__ unsigned char smem_mid[];
     constexpr int Gm = 32, ncell = Gm * Gm * Gm;                                  // g.G == 64
+    static_assert(P % 2 == 0, "pairs of pixels");
     unsigned int *T = (unsigned int *)smem_mid;                                  // [ncell]
     double *spx = (double *)(smem_mid + (size_t)ncell * 4), *spy = spx + 256, *spz = spy + 256;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // this wavefront's overflow queue: coordinates and pixel index of up to kMidQueue pixels
     double *qx = spz + 256 + wid * 3 * kMidQueue, *qy = qx + kMidQueue, *qz = qy + kMidQueue;
     unsigned int *qi = (unsigned int *)(spz + 256 + 16 * 3 * kMidQueue) + wid * kMidQueue;
     const PalSoA sp{spx, spy, spz};
 
-    const size_t tile = (size_t)1024 * P, step = (size_t)gridDim.x * tile;
+    constexpr size_t tile = (size_t)64 * P;
+    const size_t step = (size_t)gridDim.x * 16 * tile;
     double nx[P], ny[P], nz[P];
-    auto fetch = [&](size_t base) {
-        const double *cb = c + base;                                              // wave-uniform base + 32-bit lane offset
-        if (base + tile <= n) {
+    auto fetch = [&](const size_t base) {                                         // wave-uniform base
+        const double *cb = c + base;
+        if (base + tile <= n && ((N | base) & 1) == 0) {                          // 16-byte aligned pairs in every plane
 #pragma unroll
-            for (int p = 0; p < P; p++) { const unsigned t = p * 1024u + threadIdx.x; nx[p] = cb[t]; ny[p] = cb[N + t]; nz[p] = cb[2 * N + t]; }
+            for (int gq = 0; gq < P / 2; gq++) {
+                const double2 vx = reinterpret_cast<const double2 *>(cb)[64 * gq + lane], vy = reinterpret_cast<const double2 *>(cb + N)[64 * gq + lane],
+                              vz = reinterpret_cast<const double2 *>(cb + 2 * N)[64 * gq + lane];
+                nx[2 * gq] = vx.x; nx[2 * gq + 1] = vx.y; ny[2 * gq] = vy.x; ny[2 * gq + 1] = vy.y; nz[2 * gq] = vz.x; nz[2 * gq + 1] = vz.y;
+            }
         } else {
             const unsigned last = (unsigned)(n - base - 1);
 #pragma unroll
-            for (int p = 0; p < P; p++) { const unsigned t = min(p * 1024u + threadIdx.x, last); nx[p] = cb[t]; ny[p] = cb[N + t]; nz[p] = cb[2 * N + t]; }
+            for (int p = 0; p < P; p++) { const unsigned t = min(128u * (unsigned)(p >> 1) + 2u * (unsigned)lane + (unsigned)(p & 1), last); nx[p] = cb[t]; ny[p] = cb[N + t]; nz[p] = cb[2 * N + t]; }
         }
     };
-    size_t base = (size_t)blockIdx.x * tile;
+    size_t base = ((size_t)blockIdx.x * 16 + wid) * tile;
     if (base < n) fetch(base);                                                    // in flight while the table is copied in
     for (int i = threadIdx.x; i < ncell / 4; i += 1024) ((uint4 *)T)[i] = ((const uint4 *)mid)[i];
     for (int j = threadIdx.x; j < 256; j += 1024) {
@@ -435,18 +483,13 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
     const int G = g.G;
     const double lo0 = g.lo[0], lo1 = g.lo[1], lo2 = g.lo[2], in0 = g.inv[0], in1 = g.inv[1], in2 = g.inv[2];
     const unsigned long long ltmask = (1ULL << lane) - 1ULL;
-    auto slow = [&](const double x, const double y, const double z, const size_t i) {      // through the G^3 records
-        const size_t cell = nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2);
-        LutRec<unsigned char> r;
-        r.load(lut + cell * 16);
-        out[i] = (OutT)nn_eval_rec(x, y, z, r, cell, lut2, sp, k);
-    };
     int qn = 0;                                                                   // wave-uniform
     for (; base < n; base += step) {
         double x[P], y[P], z[P];
 #pragma unroll
         for (int p = 0; p < P; p++) { x[p] = nx[p]; y[p] = ny[p]; z[p] = nz[p]; }
-        if (base + step < n) fetch(base + step);                                  // the next tile's pixels are in flight during this one
+        const bool lasttile = base + step >= n;
+        if (!lasttile) fetch(base + step);                                        // the next tile's pixels are in flight during this one
         const unsigned left = (unsigned)min((size_t)tile, n - base);
         OutT *ob = out + base;
         unsigned e[P];
@@ -458,10 +501,10 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
             iz = max(0, min(iz, G - 1));
             e[p] = T[((iz >> 1) * Gm + (iy >> 1)) * Gm + (ix >> 1)];
         }
+        unsigned ovbits = 0, bests[P];
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            const unsigned t = p * 1024u + threadIdx.x;
-            const size_t i = base + t;
+            const unsigned t = 128u * (unsigned)(p >> 1) + 2u * (unsigned)lane + (unsigned)(p & 1);
             const bool ok = t < left;
             const int j0 = (int)(e[p] & 0xffu), j1 = (int)((e[p] >> 8) & 0xffu), j2 = (int)((e[p] >> 16) & 0xffu), j3 = (int)(e[p] >> 24);
             const bool ov = ok && j0 > j1;
@@ -479,26 +522,53 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
                 d = (d0 * d0 + d1 * d1) + d2 * d2;
                 if (d < bd) { bd = d; best = j3; }
             }
-            if (ok && !ov) ob[t] = (OutT)best;
-            const unsigned long long m = __ballot(ov);
-            if (m) {                                                              // wave-uniform
-                const int b = (int)__popcll(m);
-                if (qn + b > kMidQueue) {                                         // make room: the parked pixels go now
-                    if (lane < qn) slow(qx[lane], qy[lane], qz[lane], qi[lane]);
-                    qn = 0;
-                }
-                if (b > kMidQueue) { if (ov) slow(x[p], y[p], z[p], i); }        // a crowded palette: nothing to gain from parking
-                else {
-                    if (ov) {
-                        const int s = qn + (int)__popcll(m & ltmask);
-                        qx[s] = x[p]; qy[s] = y[p]; qz[s] = z[p]; qi[s] = (unsigned int)i;
-                    }
-                    qn += b;
-                }
+            bests[p] = (unsigned)best;
+            ovbits |= ov ? (1u << p) : 0u;
+        }
+        // results: parked pixels get a 0 for now, the drain writes theirs later (same wavefront, program order)
+        if (left == (unsigned)tile && sizeof(OutT) == 1) {
+#pragma unroll
+            for (int gq = 0; gq < P / 2; gq++)
+                reinterpret_cast<unsigned short *>(ob)[64 * gq + lane] = (unsigned short)((bests[2 * gq] & 0xffu) | (bests[2 * gq + 1] << 8));
+        } else {
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const unsigned t = 128u * (unsigned)(p >> 1) + 2u * (unsigned)lane + (unsigned)(p & 1);
+                if (t < left) ob[t] = (OutT)bests[p];
             }
         }
+        if (__ballot(ovbits != 0u) || lasttile) {
+            // park: the overflow pixels of this tile are numbered slot-major; as many as fit go into the queue, a full queue is
+            // drained, and so on -- one loop around ONE drain site
+            unsigned long long m[P];
+            int off[P + 1];
+            off[0] = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) { m[p] = __ballot((ovbits >> p) & 1u); off[p + 1] = off[p] + (int)__popcll(m[p]); }
+            const int btot = off[P];
+            int done = 0;
+            do {                                                                  // wave-uniform
+                const int take = min(kMidQueue - qn, btot - done);
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const int gr = off[p] + (int)__popcll(m[p] & ltmask) - done;
+                    if (((ovbits >> p) & 1u) && gr >= 0 && gr < take) {
+                        qx[qn + gr] = x[p]; qy[qn + gr] = y[p]; qz[qn + gr] = z[p];
+                        qi[qn + gr] = (unsigned int)base + 128u * (unsigned)(p >> 1) + 2u * (unsigned)lane + (unsigned)(p & 1);
+                    }
+                }
+                qn += take; done += take;
+                if (qn == kMidQueue || (lasttile && done == btot)) {
+                    if (lane < qn) {
+                        const double px = qx[lane], py = qy[lane], pz = qz[lane];
+                        const size_t cell = nn_cell(px, py, pz, G, lo0, lo1, lo2, in0, in1, in2);
+                        out[qi[lane]] = (OutT)nn_drain_one(px, py, pz, cell, lut, lut2, sp, k);
+                    }
+                    qn = 0;
+                }
+            } while (done < btot);
+        }
     }
-    if (lane < qn) slow(qx[lane], qy[lane], qz[lane], qi[lane]);
 }
 
 __global__ __launch_bounds__(256) void k_minmax3(const double *__restrict__ c, size_t N, size_t n, unsigned long long *keys /* min[3], max[3] */) {
@@ -549,12 +619,13 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
             hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, l1, l2, (const unsigned char *)w.clist.p, use_mid ? w.mid.p : nullptr);
         }
         if (use_mid) {
-            constexpr int P = 2;
+            constexpr int P = 4;
             const size_t lds_mid = kMidLds;
             static PerDeviceOnce attr_mid;
             if (attr_mid.first()) {
                 HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_mid<OutT, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
             }
+            if (n >> 32) throw HipError("patolette_amd: the LDS-table map kernel indexes pixels with 32 bits");
             const int blocks = (int)std::min<size_t>((size_t)num_cus(), ceil_div(n, (size_t)1024 * P));
             KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
             hipLaunchKernelGGL((k_nn_map_mid<OutT, P>), blocks, 1024, lds_mid, s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned int *)w.mid.p,

@@ -193,6 +193,32 @@ def test_kmeans_long_chains_with_ties_and_binade_changes(gpu, ob, weighted):
     assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
 
 
+@pytest.mark.parametrize("k,weighted", [(64, False), (256, True)])
+def test_kmeans_lds_table_path_with_exact_distance_ties(gpu, ob, monkeypatch, k, weighted):
+    """The LDS-table assignment evaluates a cell's four candidates as 64-bit {distance : index} keys and hands every doubtful
+    sample (another index at the same smallest distance, a negative rounded distance) to the reference's exact procedure.
+    Samples on a coarse dyadic lattice around the origin, centroids started ON lattice points: coincident samples
+    (distance 0), equidistant centroids in different and in equal SIMD lanes, and sums with no cancellation at all are the
+    rule here; centroids bit-identical to the oracle's full scans."""
+    monkeypatch.setenv("PAMD_KM_LUT_MIN", "1")
+    monkeypatch.setenv("PAMD_KM_G64_MIN", "1")
+    n = 600000
+    rng = np.random.default_rng(100 + k)
+    lattice = rng.integers(-8, 9, size=(n, 3)) / 16.0
+    jitter = (rng.integers(0, 3, size=(n, 1)) == 0) * rng.standard_normal((n, 3)) * 2e-3
+    pts = (lattice + jitter).astype(np.float32).astype(np.float64)
+    flat = np.ascontiguousarray(pts.T).reshape(-1)
+    w = (1.0 + rng.integers(0, 3, size=n) * 0.25) if weighted else None
+    cent = (rng.integers(-8, 9, size=(k, 3)) / 16.0 + (rng.integers(0, 2, size=(k, 1)) * rng.standard_normal((k, 3)) * 1e-2))
+    cent[3] = cent[11]                                      # equal centroids in one SIMD lane (3 = 11 mod 8) ...
+    cent[4] = cent[13]                                      # ... and in different lanes
+    want = ob.kmeans_refine(flat, w, n, cent, 3, n)
+    c = np.ascontiguousarray(cent.T).reshape(-1).copy()
+    assert gpu.patolette_amd_kmeans_refine(_d(flat), _d(w), n, _d(c), k, 3, n) == 0
+    got = c.reshape(3, k).T
+    assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
+
+
 def test_nn_map_bit_exact(gpu, ob):
     for n, k, seed in [(100000, 256, 1), (5000, 7, 2), (333, 1, 3), (70000, 300, 4)]:
         flat = ob.convert("srgb_to_ictcp", ob.image(n, seed))
