@@ -104,6 +104,99 @@ class Runner:
             q.put(None)
 
 
+def north_star_kernels(L, native):
+    """The two kernels BASELINE.json's north_star sets a target for (>= 60 % of the HBM roofline on KMeans-assign and
+    palette-map, 67 MP, 256 colours), measured here in the driver's own run: two untimed steps of the `c4km` configuration
+    (8192x8192, ICtCp, KMeans over all 67 M pixels, NN map) with every kernel under HIP events.  avg_us = mean launch
+    duration; frac = algorithmic bytes (16 B/sample assign, 25 B/px map: DESIGN.md section 4) / avg / 8 TB/s; traffic = HBM
+    bytes per launch from the PMC passes kept in profiles/traffic_c4km.json (None if that file is absent)."""
+    import numpy as np
+    width, height, K, cs, niter, max_samples, dither, weighted, _ = CONFIGS["c4km"]
+    n = width * height
+    img = L.patolette_amd_malloc(3 * n * 8)
+    dmap = L.patolette_amd_malloc(n)
+    if not img or not dmap:
+        return None
+    try:
+        assert L.patolette_amd_fill_image(img, n, 77) == 0
+        opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+        pal = np.zeros((K, 3), dtype=np.float64, order="F")
+        code = C.c_int(0)
+
+        def one():
+            L.patolette_amd_device(width, height, img, None, K, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+            if code.value != 0:
+                raise RuntimeError("bench.py: c4km step failed: %s" % native.last_error())
+        one()                                           # warm-up: workspace allocation, subsample-free path, clocks
+        native.profile(True)
+        steps = 2
+        for _ in range(steps):
+            one()
+        L.patolette_amd_synchronize()
+        prof = native.profile_results()
+        native.profile(False)
+    finally:
+        L.patolette_amd_free(img)
+        L.patolette_amd_free(dmap)
+        L.patolette_amd_release_workspace()             # ~11 GB of workspace for the 67 MP image: give it back
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic_c4km.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("kernels", {})
+    out = {"config": CONFIGS["c4km"][8], "steps": steps, "peak_GBps": HBM_PEAK_GBS}
+    for name in ("k_km_assign", "k_nn_map"):
+        r = prof.get(name)
+        if not r or not r["launches"]:
+            continue
+        avg_ms = r["total_ms"] / r["launches"]
+        gbs = r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9
+        out[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": r["launches"], "achieved_GBps": round(gbs, 1),
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"], 1),
+                     "traffic": traffic.get(name, {}).get("hbm_bytes_per_launch")}
+    return out
+
+
+def host_to_host(L, native, cfg, reps=3):
+    """SURVEY.md 8(d) metric (ii): the same workload through the reference's own entry point `patolette()` -- host f64
+    image in (pageable numpy memory), size_t map and f64 palette out, PCIe copies included.  Reported next to, never as,
+    `value`."""
+    import numpy as np
+    width, height, K, cs, niter, max_samples, dither, weighted, _ = cfg
+    n = width * height
+    d = L.patolette_amd_malloc(3 * n * 8)
+    if not d:
+        return None
+    host = np.empty(3 * n)
+    try:
+        assert L.patolette_amd_fill_image(d, n, 55) == 0
+        assert L.patolette_amd_memcpy_d2h(host.ctypes.data_as(C.c_void_p), d, host.nbytes) == 0
+    finally:
+        L.patolette_amd_free(d)
+    wts = None
+    if weighted is True:
+        from oracle import binding as ob            # the synthetic weights generator only (inputs, not results)
+        wts = ob.weights(n, 55)
+    opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+    pal = np.zeros((K, 3), dtype=np.float64, order="F")
+    pmap = np.zeros(n, dtype=np.uintp)
+    code = C.c_int(0)
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        L.patolette(width, height, host.ctypes.data_as(native.dp), wts.ctypes.data_as(native.dp) if wts is not None else None, K,
+                    C.byref(opts), pal.ctypes.data_as(native.dp), pmap.ctypes.data_as(native.zp), C.byref(code))
+        dt = time.perf_counter() - t0
+        if code.value != 0:
+            return None
+        if i > 0:
+            times.append(dt)
+    st = native.last_stats()
+    best = sorted(times)[len(times) // 2]
+    return {"value": round(n / best / 1e6, 2), "unit": "Mpx/s", "ms_per_image": round(best * 1e3, 3), "reps": reps,
+            "entry": "patolette() (include/patolette.h), pageable host buffers, f64 planar in, size_t map out",
+            "ms_upload": round(st["ms_upload"], 3), "ms_download": round(st["ms_download"], 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +204,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras of the default run: north_star_kernels, host_to_host")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even with one rank")
     ap.add_argument("--streams", type=int, default=1, help="images quantised concurrently per GPU and step in the timed region")
@@ -295,26 +389,47 @@ def main():
                     "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"], 1),
                     "time_share": round(r["total_ms"] / args.steps / max(1e-9, sum(v["ms_per_step"] for v in kernels.values())), 3)}
 
-    # ---- CPU baseline: the oracle (plain-C port of the reference algorithm), one core, bounded sample ----
+    # ---- extras of the default run, all outside the timed region ----
+    ns_kernels = h2h = None
+    if not args.no_extras and world == 1 and args.config == "c3":
+        h2h = host_to_host(L, _native, cfg)
+        ns_kernels = north_star_kernels(L, _native)
+
+    # ---- CPU baseline: the oracle (plain-C restatement of the reference path) on this host, same workload ----
+    # all-core = the loops the reference's dependencies thread (faiss search / compute_centroids, FLANN's NN search) on every
+    # core of the box, the rest single-threaded as in the reference; single_thread = everything on one core.
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         from oracle import binding as ob
-        sw, sh = (4096, 2048) if n > 4096 * 2048 else (width, height)      # ~10 s of single-core work for the C3 workload
+        ncores = os.cpu_count() or 1
+        sw, sh = width, height                                # the full workload for the default config (~10 + ~17 s)
+        if n > 4096 * 4096:
+            sw, sh = 4096, 4096
         if dither and n > 1024 * 1024:
             sw, sh = 1024, 1024
         sn = sw * sh
         flat = ob.image(sn, 0)
-        wt = ob.weights(sn, 0) if weighted else None
-        t1 = time.perf_counter()
-        if weighted == "saliency":               # the reference derives these on the CPU inside quantize(): part of the job
-            from oracle import saliency
-            wt = saliency.get_weights(np.ascontiguousarray(flat.reshape(3, sn).T).reshape(sh, sw, 3), 512.0)
-        ec, _, _ = ob.patolette(sw, sh, flat, wt, K, dither=dither, color_space=cs, kmeans_niter=niter,
-                                kmeans_max_samples=min(max_samples, sn) if max_samples > 512 ** 2 else max_samples)
-        dt = time.perf_counter() - t1
-        cpu = {"value": round(sn / dt / 1e6, 4), "unit": "Mpx/s", "cores": 1, "kind": "port",
-               "sample": "oracle (plain-C restatement of the reference path, single thread) on %dx%d of the same workload, %.1f s; stages %s"
-                         % (sw, sh, dt, {k: round(v, 2) for k, v in ob.last_timings().items()})}
+        wt = ob.weights(sn, 0) if weighted is True else None
+        kms = min(max_samples, sn) if max_samples > 512 ** 2 else max_samples
+
+        def cpu_run(threads):
+            ob.set_threads(threads)
+            t1 = time.perf_counter()
+            w_ = wt
+            if weighted == "saliency":               # the reference derives these on the CPU inside quantize(): part of the job
+                from oracle import saliency
+                w_ = saliency.get_weights(np.ascontiguousarray(flat.reshape(3, sn).T).reshape(sh, sw, 3), 512.0)
+            ec, _, _ = ob.patolette(sw, sh, flat, w_, K, dither=dither, color_space=cs, kmeans_niter=niter, kmeans_max_samples=kms)
+            dt_ = time.perf_counter() - t1
+            ob.set_threads(1)
+            return dt_, {k: round(v, 2) for k, v in ob.last_timings().items()}
+        dt_all, st_all = cpu_run(ncores)
+        dt_one, st_one = cpu_run(1)
+        scale = "the full %dx%d workload" % (sw, sh) if sn == n else "%dx%d of the same workload (the %dx%d image would take %.0fx as long)" % (sw, sh, width, height, n / sn)
+        cpu = {"value": round(sn / dt_all / 1e6, 4), "unit": "Mpx/s", "cores": ncores, "kind": "port",
+               "sample": "oracle (plain-C restatement of the reference path; KMeans assign/update and the NN map on %d threads as faiss / FLANN "
+                         "thread them, everything else single-threaded as in the reference) on %s, %.1f s; stages %s" % (ncores, scale, dt_all, st_all),
+               "single_thread": {"value": round(sn / dt_one / 1e6, 4), "cores": 1, "seconds": round(dt_one, 1), "stages": st_one}}
 
     out = {
         "metric": "Mpixels/sec quantized (256-color ICtCp + KMeans) at 1 GPU" if args.config.startswith("c3") else "Mpixels/sec quantized",
@@ -323,11 +438,14 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "width": width, "height": height, "palette_size": K, "images_per_step_per_gpu": S,
                    "input": "uniform random sRGB (splitmix64), planar f64, resident in HBM; index map left in HBM as u8",
+                   "cached_between_steps": "the KMeans subsample index list (faiss rand_perm(N, seed 1234): a pure function of N and the sample count, "
+                                           "262 144 mt19937 draws + 1 MB upload, ~2 ms) is built in the first warm-up step and reused; a pool of <= 3 "
+                                           "distinct images rotates through the steps",
                    "kernel_events_in_timed_region": ("none" if args.no_profile else
                                                      ("dominant kernel only (%s); per-kernel table from one extra untimed step" % dom_name
                                                       if dom_name else "all kernels")),
                    "final_gather": ("RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region" if dist is not None else "none (1 GPU)")},
-        "roofline": roofline, "cpu_baseline": cpu, "throughput_concurrent": conc,
+        "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -85,6 +85,9 @@ def lib():
         L.orc_exit_message.restype = C.c_char_p
         L.orc_last_timings.argtypes = [dp]
         L.orc_last_timings.restype = None
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = None
+        L.orc_get_threads.restype = C.c_int
         _lib = L
     return _lib
 
@@ -203,6 +206,11 @@ def patolette(width, height, flat, w, K, dither=True, palette_only=False, color_
                         pal.ctypes.data_as(dp) if K > 0 else None,
                         pmap.ctypes.data_as(zp) if pmap is not None and n > 0 else None, C.byref(code))
     return code.value, pal, pmap
+
+
+def set_threads(n):
+    """Threads for the loops the reference's dependencies thread (faiss assign / update, FLANN search); results do not depend on it."""
+    lib().orc_set_threads(int(n))
 
 
 def last_timings():

@@ -1048,11 +1048,21 @@ void orc_kmeans_subsample_indices(size_t n, size_t take, int64_t seed, int32_t *
  * fma(v2,v2, fma(v0,v0, v1*v1)) */
 static float l2sqr3(const float *v) { return fmaf(v[2], v[2], fmaf(v[0], v[0], v[1] * v[1])); }
 
+/* Threads for the three loops the reference's dependencies run on several cores: faiss' search and compute_centroids
+ * (OpenMP, distances.cpp:807-823 / Clustering.cpp:152-201) and FLANN's nearest-neighbour search (cores = 0,
+ * nearest.c:189-199).  Everything else in the reference is single-threaded (LQ, GQ, the conversions, the dither).  Every
+ * item of these loops is independent (compute_centroids splits the CENTROIDS over threads and each thread scans all
+ * samples in order), so the results do not depend on the thread count.  Default 1; bench.py's cpu_baseline sets it. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return g_threads; }
+
 /* IndexFlatL2::search k=1 -> exhaustive_L2sqr_fused_cmax<3,6,1> (simdlib_based.cpp:59-277) */
 void orc_kmeans_assign(const float *x, size_t nx, const float *cent, size_t k, int64_t *assign, float *dis) {
     float *yn = (float *)malloc(sizeof(float) * (k ? k : 1));
     for (size_t j = 0; j < k; j++) yn[j] = l2sqr3(cent + 3 * j);
     size_t ny_p = (k / 8) * 8;
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t i = 0; i < nx; i++) {
         const float *xi = x + 3 * i;
         float m2x0 = -2 * xi[0], m2x1 = -2 * xi[1], m2x2 = -2 * xi[2];
@@ -1093,17 +1103,25 @@ void orc_kmeans_update(const float *x, const float *w, size_t nx, const int64_t 
                        float *cent, size_t k, float *hassign) {
     memset(cent, 0, sizeof(float) * 3 * k);
     memset(hassign, 0, sizeof(float) * k);
-    for (size_t i = 0; i < nx; i++) {
-        int64_t ci = assign[i];
-        float *c = cent + 3 * ci;
-        const float *xi = x + 3 * i;
-        if (w) {
-            float wi = w[i];
-            hassign[ci] += wi;
-            for (int j = 0; j < 3; j++) c[j] = fmaf(xi[j], wi, c[j]);
-        } else {
-            hassign[ci] += 1.0f;
-            for (int j = 0; j < 3; j++) c[j] += xi[j];
+    /* Clustering.cpp:152-201: thread r of nt owns centroids [k r / nt, k (r + 1) / nt) and scans ALL samples in order */
+    /* (every extra thread re-scans all samples: beyond 16 the scan costs more than the sums it shares out) */
+    const int nt = g_threads > 16 ? 16 : (g_threads > 1 ? g_threads : 1);
+#pragma omp parallel for schedule(static, 1) num_threads(nt) if (nt > 1)
+    for (int r = 0; r < nt; r++) {
+        const int64_t c0 = (int64_t)((k * (size_t)r) / (size_t)nt), c1 = (int64_t)((k * (size_t)(r + 1)) / (size_t)nt);
+        for (size_t i = 0; i < nx; i++) {
+            int64_t ci = assign[i];
+            if (ci < c0 || ci >= c1) continue;
+            float *c = cent + 3 * ci;
+            const float *xi = x + 3 * i;
+            if (w) {
+                float wi = w[i];
+                hassign[ci] += wi;
+                for (int j = 0; j < 3; j++) c[j] = fmaf(xi[j], wi, c[j]);
+            } else {
+                hassign[ci] += 1.0f;
+                for (int j = 0; j < 3; j++) c[j] += xi[j];
+            }
         }
     }
     for (size_t ci = 0; ci < k; ci++) {
@@ -1194,6 +1212,7 @@ void orc_kmeans_refine(const double *colors, const double *weights, size_t n,
  * Exact NN palette map -- palette/nearest.c:150-209 (FLANN L2, eps = 0: dist = ((d0^2)+d1^2)+d2^2)
  * ==================================================================================== */
 void orc_nn_map(const double *colors, size_t n, const double *palette, size_t k, size_t *map) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t i = 0; i < n; i++) {
         double x = colors[i], y = colors[n + i], z = colors[2 * n + i];
         size_t best = 0; double bd = INFINITY;

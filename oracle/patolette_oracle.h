@@ -106,6 +106,10 @@ const char *orc_exit_message(int exit_code);
 
 /* per-stage wall seconds of the last orc_patolette call: convert, gq, lq, kmeans, map/dither, total */
 void orc_last_timings(double out[6]);
+/* threads for the loops the reference's dependencies run on several cores (faiss search / compute_centroids, FLANN's
+ * nearest-neighbour search); results are independent of it.  Default 1. */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 
 #ifdef __cplusplus
 }

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
 #pragma unroll
                 for (int gq = 0; gq < PG; gq++) {
                     const float4 v0 = reinterpret_cast<const float4 *>(bx)[64 * gq + lane], v1 = reinterpret_cast<const float4 *>(by)[64 * gq + lane],
-                                 v2 = reinterpret_cast<const float4 *>(bz)[64 * gq + lane];
+                                 v2 = reinterpret_cast<const float4 *>(bz)[64 * gq + lane];   // (non-temporal loads measured the same)
                     n0[4 * gq] = v0.x; n0[4 * gq + 1] = v0.y; n0[4 * gq + 2] = v0.z; n0[4 * gq + 3] = v0.w;
                     n1[4 * gq] = v1.x; n1[4 * gq + 1] = v1.y; n1[4 * gq + 2] = v1.z; n1[4 * gq + 3] = v1.w;
                     n2[4 * gq] = v2.x; n2[4 * gq + 1] = v2.y; n2[4 * gq + 2] = v2.z; n2[4 * gq + 3] = v2.w;
