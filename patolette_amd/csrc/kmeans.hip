@@ -956,26 +956,27 @@ __device__ void km_split_clusters(float *cent, float *hassign, int k, unsigned l
 // wavefront to finish handles empty clusters and writes (y, |y|^2) for the next assignment ----
 // One wavefront per coordinate: the x, y, z (and weight) sums of a centroid are independent sequential chains, so a
 // block of four wavefronts runs them side by side -- per sample one LDS broadcast read and one add on each chain.
-template <bool W, int C>
-__device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, size_t lo, size_t hi, float4 (*stage)[64], int lane) {
+// `load(i)`: record i of the centroid's members in sample order, as (x, y, z, w) -- only component C and w are looked at
+template <bool W, int C, class Loader>
+__device__ __forceinline__ float km_chain_over(const Loader load, const size_t count, float4 (*stage)[64], const int lane, const float acc0) {
     // A dependent f32 add issues every ~8 cycles (3.3 ns) on a lone wavefront; an LDS read takes ~130.  So the 64 samples
     // of block n+1 are staged and their sixteen 128-bit broadcast reads issued BEFORE the 64 adds of block n: two register
     // sets, nothing but the chain itself on the critical path.
     constexpr int D = 8;                                                   // 1-KiB global loads kept in flight
     constexpr bool WX = W && C < 3;                                        // weighted coordinate chain: acc = fma(x, w, acc)
     constexpr int NR = WX ? 32 : 16;
-    float acc = 0.f;
-    const size_t nfull = (hi - lo) / 64;
-    const int tail = (int)((hi - lo) - nfull * 64);
+    float acc = acc0;
+    const size_t nfull = count / 64;
+    const int tail = (int)(count - nfull * 64);
     auto comp = [](const float4 v) { return C == 0 ? v.x : (C == 1 ? v.y : (C == 2 ? v.z : v.w)); };
     float4 ring[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         ring[d] = make_float4(0, 0, 0, 0);
-        if ((size_t)d < nfull) ring[d] = sorted[lo + (size_t)d * 64 + lane];
+        if ((size_t)d < nfull) ring[d] = load((size_t)d * 64 + lane);
     }
     float4 tv = make_float4(0, 0, 0, 0);                                   // the partial last block, fetched up front
-    if (lane < tail) tv = sorted[lo + nfull * 64 + lane];
+    if (lane < tail) tv = load(nfull * 64 + lane);
     auto put = [&](const int buf, const float4 v) {                        // this wavefront's coordinate (and weight) of 64 samples
         float *sc = reinterpret_cast<float *>(&stage[buf][0]);
         sc[lane] = comp(v);
@@ -1001,7 +1002,7 @@ __device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, siz
     if (nfull > 0) {
         put(0, ring[0]);
         ring[0] = make_float4(0, 0, 0, 0);
-        if ((size_t)D < nfull) ring[0] = sorted[lo + (size_t)D * 64 + lane];
+        if ((size_t)D < nfull) ring[0] = load((size_t)D * 64 + lane);
         __builtin_amdgcn_wave_barrier();
         issue(0, xa);
     }
@@ -1016,7 +1017,7 @@ __device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, siz
                 const int rd = (d + 1) % D;
                 put((d + 1) & 1, ring[rd]);
                 ring[rd] = make_float4(0, 0, 0, 0);
-                if (n + 1 + D < nfull) ring[rd] = sorted[lo + (n + 1 + D) * 64 + lane];
+                if (n + 1 + D < nfull) ring[rd] = load((n + 1 + D) * 64 + lane);
                 __builtin_amdgcn_wave_barrier();
                 if ((d & 1) == 0) issue(1, xb); else issue(0, xa);
             }
@@ -1047,6 +1048,11 @@ __device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, siz
         }
     }
     return acc;
+}
+
+template <bool W, int C>
+__device__ __forceinline__ float km_chain(const float4 *__restrict__ sorted, size_t lo, size_t hi, float4 (*stage)[64], int lane) {
+    return km_chain_over<W, C>([=](const size_t i) { return sorted[lo + i]; }, hi - lo, stage, lane, 0.f);
 }
 
 // Long chains (many samples per centroid) without waiting a dependent-add latency per sample -- and still bit-exact.
@@ -1190,6 +1196,54 @@ __device__ __forceinline__ float km_chain_coop(const float4 *__restrict__ sorted
     return acc;
 }
 
+// Tail of a centroid's update block: res[0..3] = the four chain results; scales the centroid, publishes it, and the LAST block
+// to arrive handles empty clusters and writes (y, |y|^2) for the next assignment.  All 256 threads of the block call it.
+template <bool W>
+__device__ __forceinline__ void km_update_finish(const int kidx, const int k, const unsigned long long nx, const size_t cnt, const float *res,
+                                                 int *s_last, float *cent, float *hassign, float4 *c4, unsigned int *ticket, DevMT *mt) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float c0 = res[0], c1 = res[1], c2 = res[2], h = res[3];
+    if constexpr (!W) {
+        // the reference's h += 1.0f per sample is exact below 2^24 and sticks there (16777216 + 1 rounds back)
+        h = cnt < (size_t)16777216 ? (float)cnt : 16777216.0f;
+    }
+    if (threadIdx.x == 0) {
+        if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
+        // publish with write-through (sc1) stores + drained counter: no per-wave L2 write-back fence
+        // (256 release fences, each flushing the XCD's dirty lines, cost more than the chains themselves)
+        __hip_atomic_store(&cent[3 * kidx], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cent[3 * kidx + 1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cent[3 * kidx + 2], c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hassign[kidx], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = (tk == (unsigned)k - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!*s_last || wid != 0) return;                                     // terminated wavefronts do not count at later barriers
+    // last block: every centroid was published with sc1 stores; read them back with sc1 (L1-bypassing) loads
+    bool mine_empty = false;
+    for (int ci = lane; ci < k; ci += 64)
+        if (__hip_atomic_load(&hassign[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.f) mine_empty = true;
+    const bool any = __ballot(mine_empty) != 0ULL;
+    if (lane == 0) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next iteration's launch
+        if (any) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // the split code uses plain accesses
+            km_split_clusters(cent, hassign, k, nx, *mt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    for (int j = lane; j < k; j += 64) {
+        const float v0 = __hip_atomic_load(&cent[3 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v1 = __hip_atomic_load(&cent[3 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v2 = __hip_atomic_load(&cent[3 * j + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c4[j] = make_c4(v0, v1, v2);
+    }
+}
+
 template <bool W>
 __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ sorted, const unsigned int *__restrict__ rowtot, int k,
                                                   unsigned long long nx, float *cent, float *hassign, float4 *c4,
@@ -1216,47 +1270,122 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
     }
     if (lane == 0) res[wid] = acc;
     __syncthreads();
-    float c0 = res[0], c1 = res[1], c2 = res[2], h = res[3];
-    if constexpr (!W) {
-        // the reference's h += 1.0f per sample is exact below 2^24 and sticks there (16777216 + 1 rounds back)
-        const size_t cnt = hi - lo;
-        h = cnt < (size_t)16777216 ? (float)cnt : 16777216.0f;
-    }
-    if (threadIdx.x == 0) {
-        if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
-        // publish with write-through (sc1) stores + drained counter: no per-wave L2 write-back fence
-        // (256 release fences, each flushing the XCD's dirty lines, cost more than the chains themselves)
-        __hip_atomic_store(&cent[3 * kidx], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&cent[3 * kidx + 1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&cent[3 * kidx + 2], c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&hassign[kidx], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (tk == (unsigned)k - 1u) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last || wid != 0) return;                                      // terminated wavefronts do not count at later barriers
-    // last block: every centroid was published with sc1 stores; read them back with sc1 (L1-bypassing) loads
-    bool mine_empty = false;
-    for (int ci = lane; ci < k; ci += 64)
-        if (__hip_atomic_load(&hassign[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.f) mine_empty = true;
-    const bool any = __ballot(mine_empty) != 0ULL;
-    if (lane == 0) {
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next iteration's launch
-        if (any) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // the split code uses plain accesses
-            km_split_clusters(cent, hassign, k, nx, *mt);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    km_update_finish<W>(kidx, k, nx, hi - lo, res, &s_last, cent, hassign, c4, ticket, mt);
+}
+
+// --------------------------------------------------------------------------------------------
+// Few samples (the default: 512^2 of them, ~1000 per centroid): the stable counting sort costs more than the sums it feeds
+// (three launches and a k x chunks table per iteration).  Here ONE block per centroid finds its members itself: it scans
+// the one-byte assignments of all samples (nx bytes from L2 per block: 64 KB at a time, four SWAR compares per sixteen
+// samples), lists the matching sample numbers in LDS in sample order, and replays the centroid's sequential f32 chains
+// from there -- each wavefront gathers just its own coordinate.  Same sums in the same order as k_km_update.
+// --------------------------------------------------------------------------------------------
+// inclusive prefix sum over the 64 lanes through DPP row shifts and row broadcasts (a __shfl_up loop is six LDS round trips)
+__device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8  -> inclusive within each row of 16
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+constexpr int kKmDirectCap = 16384;                                    // listed members between two chain replays (64 KB of LDS)
+
+__global__ __launch_bounds__(256) void k_km_assign_plain(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, unsigned char *__restrict__ assign) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride)
+        assign[i] = (unsigned char)km_assign_one(s.x[i], s.y[i], s.z[i], (scalar_c4_t)(unsigned long long)c4, k);
+}
+
+template <bool W>
+__global__ __launch_bounds__(256) void k_km_update_direct(KmSamples s, const unsigned char *__restrict__ assign, unsigned long long nx, int k,
+                                                         float *cent, float *hassign, float4 *c4, unsigned int *ticket, DevMT *mt) {
+    __shared__ float4 stage[4][2][64];
+    extern __shared__ unsigned int members[];                              // [kKmDirectCap] sample numbers, in sample order
+    __shared__ float res[4];
+    __shared__ int s_last;
+    __shared__ unsigned int wtot[4];
+    static_assert(kKmDirectCap >= 4 * 64 * 16 * 4, "one round of assignments must fit the member list");
+    const int kidx = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned pat = (unsigned)kidx * 0x01010101u;
+    float acc = 0.f;
+    size_t total = 0;
+    unsigned fill = 0;                                                    // block-uniform
+    auto replay = [&]() {                                                 // the chains over members[0, fill), continuing `acc`
+        const unsigned n = fill;
+        if (wid == 0) acc = km_chain_over<W, 0>([&](const size_t i) { return make_float4(s.x[members[i]], 0.f, 0.f, W ? s.w[members[i]] : 0.f); }, n, stage[0], lane, acc);
+        else if (wid == 1) acc = km_chain_over<W, 1>([&](const size_t i) { return make_float4(0.f, s.y[members[i]], 0.f, W ? s.w[members[i]] : 0.f); }, n, stage[1], lane, acc);
+        else if (wid == 2) acc = km_chain_over<W, 2>([&](const size_t i) { return make_float4(0.f, 0.f, s.z[members[i]], W ? s.w[members[i]] : 0.f); }, n, stage[2], lane, acc);
+        else if (W) acc = km_chain_over<W, 3>([&](const size_t i) { return make_float4(0.f, 0.f, 0.f, s.w[members[i]]); }, n, stage[3], lane, acc);
+    };
+    // Rounds of 16384 samples: a lane holds 64 CONSECUTIVE one-byte assignments (four 16-byte loads), a wavefront 4096, so the
+    // members come out in sample order lane by lane; the next round's bytes are requested before this round's are looked at.
+    constexpr int R = 4;
+    constexpr unsigned kRound = 4u * 64u * 16u * R;
+    uint4 cur[R], nxt[R];
+    auto fetch = [&](const unsigned long long s0, uint4 (&v)[R]) {
+        const unsigned long long first = s0 + (unsigned)(wid * 64 + lane) * (16u * R);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned long long at = first + 16u * (unsigned)r;
+            if (at + 16 <= nx) v[r] = *reinterpret_cast<const uint4 *>(assign + at);
+            else {                                                        // the ragged end: bytes past nx read as "not mine"
+                unsigned wv[4] = {~pat, ~pat, ~pat, ~pat};
+                for (unsigned bq = 0; bq < 16u && at + bq < nx; bq++)
+                    wv[bq >> 2] = (wv[bq >> 2] & ~(0xffu << (8 * (bq & 3)))) | ((unsigned)assign[at + bq] << (8 * (bq & 3)));
+                v[r] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
         }
+    };
+    fetch(0, nxt);
+    for (unsigned long long s0 = 0; s0 < nx; s0 += kRound) {
+#pragma unroll
+        for (int r = 0; r < R; r++) cur[r] = nxt[r];
+        if (s0 + kRound < nx) fetch(s0 + kRound, nxt);
+        unsigned long long mine = 0;                                      // bit b set <=> byte b of the lane's 64 is this centroid's
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned wv[4] = {cur[r].x, cur[r].y, cur[r].z, cur[r].w};
+            unsigned nib16 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned x = wv[q] ^ pat;                           // zero bytes = matches
+                const unsigned y = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;       // bit 7 of a byte stays clear <=> its low seven bits were zero (no carries between bytes)
+                const unsigned z = ~(y | x | 0x7f7f7f7fu);                // bit 7 of byte b set <=> byte b matched
+                // the four flags (bits 7, 15, 23, 31) as a nibble, byte order kept: flag i moves from bit 8 i to bit 21 + i, no two
+                // partial products meet
+                nib16 |= (((((z >> 7) & 0x01010101u) * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+            }
+            mine |= (unsigned long long)nib16 << (16 * r);
+        }
+        const unsigned c = (unsigned)__popcll(mine);
+        const unsigned inc = wave_scan_incl_u32(c);                       // DPP: no LDS round trips
+        if (lane == 63) wtot[wid] = inc;
+        __syncthreads();
+        const unsigned round_total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        if (fill + round_total > (unsigned)kKmDirectCap) {                // block-uniform: make room first (a round holds <= 16384)
+            replay();
+            fill = 0;
+            __syncthreads();
+        }
+        unsigned at = fill + inc - c;
+        for (int w = 0; w < wid; w++) at += wtot[w];
+        const unsigned first = (unsigned)s0 + (unsigned)(wid * 64 + lane) * (16u * R);
+        while (mine) {                                                    // a lane holds a member every fourth round on average (1 / k of its 64)
+            const int bit = __builtin_ctzll(mine);
+            mine &= mine - 1ULL;
+            members[at++] = first + (unsigned)bit;
+        }
+        fill += round_total;
+        total += round_total;
+        __syncthreads();
     }
+    replay();
+    if (lane == 0) res[wid] = acc;
     __syncthreads();
-    for (int j = lane; j < k; j += 64) {
-        const float v0 = __hip_atomic_load(&cent[3 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float v1 = __hip_atomic_load(&cent[3 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float v2 = __hip_atomic_load(&cent[3 * j + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c4[j] = make_c4(v0, v1, v2);
-    }
+    km_update_finish<W>(kidx, k, nx, total, res, &s_last, cent, hassign, c4, ticket, mt);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1327,12 +1456,37 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         { KTIME("k_km_bounds", s, 12.0 * nx); hipLaunchKernelGGL(k_km_bounds, (int)std::min<size_t>(ceil_div(nx, 256), 2048), 256, 0, s, ks, nx, w.bkeys.p); }
         hipLaunchKernelGGL(k_km_bounds_fold, 1, 64, 0, s, w.bkeys.p, (KmGridDev *)w.grid.p);
     }
+    // few samples: no sort at all -- one block per centroid finds its members in the one-byte assignments (k_km_update_direct)
+    const size_t direct_max = getenv("PAMD_KM_DIRECT_MAX") ? (size_t)atoll(getenv("PAMD_KM_DIRECT_MAX")) : ((size_t)1 << 19);
+    const bool use_direct = !use_lut && k <= 256 && nx <= direct_max && nx < ((size_t)1 << 32);
+    if (use_direct) {
+        static PerDeviceOnce attr4;
+        if (attr4.first()) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_direct<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 4));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_direct<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 4));
+        }
+    }
     static const bool mid_enabled = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
     const bool use_mid = use_lut && G == 64 && mid_enabled && k % 8 == 0;    // four-candidate table in LDS
     if (use_mid) w.mid.reserve(32 * 32 * 32);
     // clusters of at least this many samples take the block-parallel exact chain (km_chain_coop)
     const unsigned long long long_min = getenv("PAMD_KM_LONG_MIN") ? (unsigned long long)atoll(getenv("PAMD_KM_LONG_MIN")) : 8192ULL;
     for (int it = 0; it < niter; it++) {
+        if (use_direct) {
+            unsigned char *a8 = (unsigned char *)w.assign.p;
+            {
+                KTIME("k_km_assign", s, 13.0 * nx);
+                hipLaunchKernelGGL(k_km_assign_plain, (int)std::min<size_t>(ceil_div(nx, 256), 8192), 256, 0, s, ks, nx, w.c4.p, k, a8);
+            }
+            {
+                KTIME("k_km_update", s, (weighted ? 17.0 : 13.0) * nx);
+                if (weighted) hipLaunchKernelGGL(k_km_update_direct<true>, k, 256, kKmDirectCap * 4, s, ks, (const unsigned char *)a8, (unsigned long long)nx, k,
+                                                 w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+                else hipLaunchKernelGGL(k_km_update_direct<false>, k, 256, kKmDirectCap * 4, s, ks, (const unsigned char *)a8, (unsigned long long)nx, k,
+                                        w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+            }
+            continue;
+        }
         if (use_lut) {
             {
                 KTIME("k_km_lut_build", s, 16.0 * G * G * G);
