@@ -44,9 +44,17 @@ __device__ __forceinline__ float4 make_c4(float v0, float v1, float v2) {
     return make_float4(v0, v1, v2, __builtin_fmaf(v2, v2, __builtin_fmaf(v0, v0, v1 * v1)));
 }
 
+// The centroid table the assignment kernels read: c4[j] = (y0, y1, y2, |y|^2), and behind it (c4 + k) the same numbers pair by
+// pair -- entry p = {y0 of 2p, y0 of 2p+1, y1.., y1.., y2.., y2.., |y|^2.., |y|^2..} -- for the packed-f32 full scan.
+__device__ __forceinline__ void km_store_c4(float4 *c4, const int k, const int j, const float v0, const float v1, const float v2) {
+    const float4 r = make_c4(v0, v1, v2);
+    c4[j] = r;
+    float *pp = reinterpret_cast<float *>(c4 + k) + 8 * (j >> 1) + (j & 1);
+    pp[0] = r.x; pp[2] = r.y; pp[4] = r.z; pp[6] = r.w;
+}
 __global__ void k_km_prep(const float *__restrict__ cent, int k, float4 *c4) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < k) c4[j] = make_c4(cent[3 * j], cent[3 * j + 1], cent[3 * j + 2]);
+    if (j < k) km_store_c4(c4, k, j, cent[3 * j], cent[3 * j + 1], cent[3 * j + 2]);
 }
 
 // top-1 of one sample against all centroids, exactly as the AVX2 fused kernel orders it
@@ -1240,7 +1248,7 @@ __device__ __forceinline__ void km_update_finish(const int kidx, const int k, co
         const float v0 = __hip_atomic_load(&cent[3 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float v1 = __hip_atomic_load(&cent[3 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float v2 = __hip_atomic_load(&cent[3 * j + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c4[j] = make_c4(v0, v1, v2);
+        km_store_c4(c4, k, j, v0, v1, v2);
     }
 }
 
@@ -1293,10 +1301,57 @@ __device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
 
 constexpr int kKmDirectCap = 16384;                                    // listed members between two chain replays (64 KB of LDS)
 
+// km_assign_one with two centroids per instruction: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 round each half like the scalar
+// instruction, so centroids 2p and 2p+1 (SIMD lanes l, l+1 of the reference's kernel) take four packed instructions instead of
+// eight; the pairwise table comes through the scalar cache like the plain one.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef float f8_t __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) f8_t *scalar_c8_t;
+__device__ __forceinline__ int km_assign_one_pk(const float x0, const float x1, const float x2, const scalar_c4_t c4, const scalar_c8_t c8, const int k) {
+    const f2_t m0 = {-2 * x0, -2 * x0}, m1 = {-2 * x1, -2 * x1}, m2 = {-2 * x2, -2 * x2};
+    const float xn = __builtin_fmaf(x2, x2, __builtin_fmaf(x0, x0, x1 * x1));
+    float ld[8]; int lb[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) { ld[l] = 3.402823466e+38F - xn; lb[l] = -l; }
+    const int ny_p = (k / 8) * 8;
+    for (int j = 0; j < ny_p; j += 8) {
+#pragma unroll
+        for (int l = 0; l < 8; l += 2) {
+            const f8_t y = c8[(j + l) >> 1];                    // wave-uniform address: scalar load
+            const f2_t y0 = {y[0], y[1]}, y1 = {y[2], y[3]}, y2 = {y[4], y[5]}, yw = {y[6], y[7]};
+            f2_t dp = m0 * y0;
+            dp = __builtin_elementwise_fma(m1, y1, dp);
+            dp = __builtin_elementwise_fma(m2, y2, dp);
+            dp = dp + yw;
+            if (dp[0] < ld[l]) { ld[l] = dp[0]; lb[l] = j; }
+            if (dp[1] < ld[l + 1]) { ld[l + 1] = dp[1]; lb[l + 1] = j; }
+        }
+    }
+    float cur_d = 3.402823466e+38F; unsigned cur_i = 0xFFFFFFFFu;
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        const unsigned li = (unsigned)(lb[l] + l);
+        float cand = ld[l] + xn;
+        if (cand < 0) cand = 0;
+        if (cur_d > cand) { cur_d = cand; cur_i = li; }
+        else if (cur_d == cand && cur_i > li) cur_i = li;
+    }
+    for (int j0 = ny_p; j0 < k; j0++) {                     // simdlib_based.cpp:201-216
+        const auto y = c4[j0];
+        float dp = __builtin_fmaf(x2, y.z, __builtin_fmaf(x1, y.y, x0 * y.x));
+        float d = xn + y.w - 2 * dp;
+        if (d < 0) d = 0;
+        if (cur_d > d) { cur_d = d; cur_i = (unsigned)j0; }
+    }
+    return (int)cur_i;
+}
+
 __global__ __launch_bounds__(256) void k_km_assign_plain(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, unsigned char *__restrict__ assign) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const scalar_c4_t t4 = (scalar_c4_t)(unsigned long long)c4;
+    const scalar_c8_t t8 = (scalar_c8_t)(unsigned long long)(c4 + k);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride)
-        assign[i] = (unsigned char)km_assign_one(s.x[i], s.y[i], s.z[i], (scalar_c4_t)(unsigned long long)c4, k);
+        assign[i] = (unsigned char)km_assign_one_pk(s.x[i], s.y[i], s.z[i], t4, t8, k);
 }
 
 template <bool W>
@@ -1402,7 +1457,7 @@ void KMeansWork::reserve(size_t nx, int k) {
     const int nchunks = (int)ceil_div(nx, (size_t)chunk_len_for(nx));
     table.reserve((size_t)k * (size_t)(nchunks > 0 ? nchunks : 1));
     rowtot.reserve(k);
-    cent.reserve(3 * (size_t)k); hassign.reserve(k); c4.reserve(k);
+    cent.reserve(3 * (size_t)k); hassign.reserve(k); c4.reserve(2 * (size_t)k + 2);        // + the pairwise copy (km_store_c4)
     perm.reserve(nx);
     if (!mt.p) mt.reserve(1);
     if (!ticket.p) { ticket.reserve(1); HIP_CHECK(hipMemset(ticket.p, 0, sizeof(unsigned int))); }

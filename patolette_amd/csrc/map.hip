@@ -747,10 +747,13 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-    v = min(v, dpp_u32<0xB1>(v));
-    v = min(v, dpp_u32<0x4E>(v));
-    v = min(v, dpp_u32<0x124>(v));
-    v = min(v, dpp_u32<0x128>(v));
+    // the minimum taken BY the DPP instruction (v_min_u32 with a permuted first operand): one instruction per step instead of
+    // move + minimum; s_nop 1 = the two wait states a DPP read of a just-written VGPR needs (the assembler does not add them)
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0" : "+v"(v));                                   // -> every lane holds its 16-lane row minimum
     const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
                    r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
     return min(min(r0, r1), min(r2, r3));
@@ -768,18 +771,32 @@ __device__ __forceinline__ int wave_argmin_nonneg_f64(double v) {
     return (int)__builtin_ctzll(c);
 }
 
-// One wavefront walks one image.  Lanes 0..2 carry the R,G,B error queues (the 16-term weighted sum is a
-// 16-deep chain per channel, evaluated for the three channels at once); all 64 lanes share the palette for
-// the nearest-colour search: lane L owns the contiguous entries [L*PER, (L+1)*PER), so on equal distance the
-// lowest palette index is simply the lowest lane (first set bit of a ballot).
+// One wavefront walks one image; every instruction of the chain is issued by that one wavefront (~2.5 ns each), so the count of
+// instructions per pixel is what matters.
+//
+// Error sums, systolic: the reference forms, for every pixel, e = q[0] w[0] + ... + q[15] w[15] in that order over the last sixteen
+// error vectors (riemersma.c:286-296) -- thirty dependent instructions per channel if one lane does it.  Here lane (c, d) = 16 c + d
+// owns channel c of the pixels whose step number is d mod 16: its sum starts when step d - 16 has produced its error vector
+// (term 0, weight w[0]) and takes one term per step, as each later error vector appears, so that after step d - 1 all sixteen
+// terms are in, added in the reference's order.  Every step is then ONE multiply and ONE add in all lanes at once (each lane
+// with the weight of its own phase), and the finished sum of the current pixel is read from the lane whose turn it is.
+// Sixteen steps are unrolled so that phases and lanes are compile-time constants.
+//
+// Pixels: blocks of 64 curve positions are decoded and loaded by the 64 lanes in parallel; the in-image ones are appended, in
+// order, to a ring in LDS and consumed sixteen at a time (the last group may be short), so edges need no second code path.
+//
+// Nearest colour: all 64 lanes share the palette (lane L owns entries [L PER, (L + 1) PER), in registers when PER <= 4), per-lane
+// best in ascending index with strict '<', then the lowest lane among the wave-wide minima = lowest index on ties.
 template <typename OutT, int PER>
 __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, size_t plane_stride, unsigned width, unsigned height,
                                                const double *__restrict__ pal /* planar (k,3), linear Rec2020 */, int k,
                                                OutT *__restrict__ out, DitherWeights wts) {
     extern __shared__ double lds[];
+    constexpr int kRing = 128;                                       // >= 64 + 15 pending pixels
     double *praw = lds;                                              // [3][k] raw palette
     double *pwt = lds + 3 * k;                                       // [3][k] palette scaled by (float)-cast weights (riemersma.c:419-425)
-    double *spx = lds + 6 * k;                                       // [3][64] channels of the current block of pixels
+    double *rpx = lds + 6 * k;                                       // [3][kRing] channels of the pending pixels
+    unsigned int *rpos = reinterpret_cast<unsigned int *>(rpx + 3 * kRing);   // [kRing] their linear pixel numbers
     const int lane = threadIdx.x;
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
     for (int j = lane; j < k; j += 64)
@@ -799,20 +816,82 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
     int L = 0;
     while ((1u << L) < mxd) L++;
     if (L == 0) return;                                              // riemersma.c:452-456
-    double qw[16];
+    const int ch = lane < 48 ? lane >> 4 : 2, dph = lane & 15;       // lanes 48..63 shadow channel 2 (never read)
+    const double Wc = ch == 0 ? kRw : (ch == 1 ? kGw : kBw);         // query weights are the DOUBLE constants (riemersma.c:305-311)
+    double wl[16];                                                   // weight this lane applies at step j (mod 16): w[15 - ((d - j - 1) mod 16)]
 #pragma unroll
-    for (int i = 0; i < 16; i++) qw[i] = wts.w[i];                    // w_i = m^i/16 (host libm, riemersma.c:360-373)
-    double q[16];
+    for (int j = 0; j < 16; j++) {
+        double v = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) q[i] = 0;
-    const double Wc = lane == 0 ? kRw : (lane == 1 ? kGw : kBw);     // query weights are the DOUBLE constants (riemersma.c:305-311)
-    const int ch = lane < 3 ? lane : 0;
+        for (int i = 0; i < 16; i++) v = (15 - ((dph - j - 1) & 15)) == i ? wts.w[i] : v;     // w_i = m^i / 16 (host libm, riemersma.c:360-373)
+        wl[j] = v;
+    }
+    double acc = 0.0;                                                // this lane's partial sum (the queue starts as zeros: 0 + x = x)
+    const double *prw = praw + ch * k;
+
+    // nearest palette entry of the query (qx, qy, qz)
+    auto nearest = [&](const double qx, const double qy, const double qz) -> int {
+        double bd = INFINITY; int bj = 0;
+        if constexpr (PER > 0) {
+            // the lane's smallest distance first (v_min_f64), the entry that attains it afterwards: the FIRST of the lane's
+            // entries equal to the minimum = ascending index with strict '<' (distances are never NaN here)
+            double dd[PER];
+#pragma unroll
+            for (int m = 0; m < PER; m++) {
+                const double e0 = qx - ex[m], e1 = qy - ey[m], e2 = qz - ez[m];
+                dd[m] = (e0 * e0 + e1 * e1) + e2 * e2;
+            }
+            bd = dd[0];
+#pragma unroll
+            for (int m = 1; m < PER; m++) bd = fmin(bd, dd[m]);
+            bj = PER - 1;
+#pragma unroll
+            for (int m = PER - 2; m >= 0; m--) bj = dd[m] == bd ? m : bj;
+            bj += lane * PER;
+        } else {
+            for (int m = 0; m < per; m++) {
+                const int j = lane * per + m;
+                if (j < k) {
+                    const double e0 = qx - pwt[j], e1 = qy - pwt[k + j], e2 = qz - pwt[2 * k + j];
+                    const double dd = (e0 * e0 + e1 * e1) + e2 * e2;
+                    if (dd < bd) { bd = dd; bj = j; }
+                }
+            }
+        }
+        return __builtin_amdgcn_readlane(bj, wave_argmin_nonneg_f64(bd));
+    };
+
+    unsigned head = 0, count = 0;                                    // ring positions (absolute); head is a multiple of 16
+    // up to sixteen pending pixels, in order; `limit` < 16 only for the very last group
+    auto group = [&](const int limit) {
+        double pcs[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) pcs[j] = rpx[ch * kRing + ((head + (unsigned)j) & (kRing - 1))];
+        int res = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j < limit) {                                         // wave-uniform
+                const double qv = Wc * (pcs[j] + acc);               // meaningful in lanes (c, j): their sums are complete (riemersma.c:298-311)
+                const int bi = nearest(readlane_f64(qv, j), readlane_f64(qv, 16 + j), readlane_f64(qv, 32 + j));
+                res = lane == j ? bi : res;
+                const double err = pcs[j] - prw[bi];                 // original pixel - chosen colour (riemersma.c:333-340)
+                acc = (dph == j ? 0.0 : acc) + err * wl[j];          // lane (c, j) starts the sum of step + 16 with term 0
+            }
+        }
+        if (lane < limit) out[rpos[(head + (unsigned)lane) & (kRing - 1)]] = (OutT)res;
+        head += 16;
+    };
 
     const unsigned long long total = 1ULL << (2 * L);
     const double *pr = img, *pg = img + plane_stride, *pb = img + 2 * plane_stride;
+    // A block of 64 aligned curve positions is an 8 x 8 sub-square: the lane's place inside it (levels 0..2 of the curve) never
+    // changes, and the levels above act on it as ONE signed permutation + offset per block, worked out on scalars.
+    unsigned xl = 0, yl = 0;
+    hilbert_d2xy(3, (unsigned long long)lane, xl, yl);
+    const bool needs_skip = width < (1u << L) || height < (1u << L);
     unsigned long long d0 = 0;
     while (d0 < total) {
-        if (L >= 3) {                                                // skip whole out-of-image aligned sub-squares
+        if (L >= 3 && needs_skip) {                                  // skip whole out-of-image aligned sub-squares
             bool skipped = false;
             for (int j = L; j >= 3; j--) {
                 const unsigned long long span = 1ULL << (2 * j);
@@ -827,90 +906,44 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
         const unsigned long long dl = d0 + (unsigned long long)lane;
         unsigned x = 0, y = 0;
         bool inb = false;
-        double R = 0, G = 0, B = 0;
-        if (dl < total) {
+        if (L >= 3) {
+            // levels 3 .. L-1 on (selx ? yl : xl) * sgnx + ox (and the same for y): a flip negates and reflects the offset, a swap
+            // exchanges the two triples, then the quadrant offset is added -- hilbert_d2xy's loop body on the coefficients
+            int selx = 0, sgnx = 1, ox = 0, sely = 1, sgny = 1, oy = 0;
+            unsigned long long t = d0 >> 6;
+            for (int lv = 3; lv < L; lv++) {
+                const int sidx = 1 << lv;
+                const int rx = 1 & (int)(t >> 1);
+                const int ry = 1 & ((int)t ^ rx);
+                if (ry == 0) {
+                    if (rx == 1) { sgnx = -sgnx; ox = sidx - 1 - ox; sgny = -sgny; oy = sidx - 1 - oy; }
+                    int tmp = selx; selx = sely; sely = tmp;
+                    tmp = sgnx; sgnx = sgny; sgny = tmp;
+                    tmp = ox; ox = oy; oy = tmp;
+                }
+                ox += sidx * rx; oy += sidx * ry;
+                t >>= 2;
+            }
+            x = (unsigned)((int)(selx ? yl : xl) * sgnx + ox);
+            y = (unsigned)((int)(sely ? yl : xl) * sgny + oy);
+            inb = x < width && y < height;
+        } else if (dl < total) {
             hilbert_d2xy(L, dl, x, y);
             inb = x < width && y < height;
-            if (inb) { const size_t p = (size_t)y * width + x; R = pr[p]; G = pg[p]; B = pb[p]; }
         }
         const unsigned long long mask = __ballot(inb);
-        int myidx = 0;
-        // nearest palette entry of the query (qx, qy, qz): per-lane best of its own entries (ascending index, strict '<'),
-        // then the lowest lane among the wave-wide minima = lowest palette index on ties
-        auto nearest = [&](const double qx, const double qy, const double qz) -> int {
-            double bd = INFINITY; int bj = 0;
-            if constexpr (PER > 0) {
-#pragma unroll
-                for (int m = 0; m < PER; m++) {
-                    const double e0 = qx - ex[m], e1 = qy - ey[m], e2 = qz - ez[m];
-                    const double dd = (e0 * e0 + e1 * e1) + e2 * e2;
-                    if (dd < bd) { bd = dd; bj = lane * PER + m; }
-                }
-            } else {
-                for (int m = 0; m < per; m++) {
-                    const int j = lane * per + m;
-                    if (j < k) {
-                        const double e0 = qx - pwt[j], e1 = qy - pwt[k + j], e2 = qz - pwt[2 * k + j];
-                        const double dd = (e0 * e0 + e1 * e1) + e2 * e2;
-                        if (dd < bd) { bd = dd; bj = j; }
-                    }
-                }
-            }
-            return __builtin_amdgcn_readlane(bj, wave_argmin_nonneg_f64(bd));
-        };
-        if (mask == ~0ULL) {
-            // the whole block lies inside the image (all but the edges): the pixels go through LDS so that lane c reads its
-            // channel of pixel t directly, and the 16 steps of a turn of the error queue are unrolled so that the queue is a
-            // ring of registers with compile-time positions (no 15-register shift per pixel)
-            spx[lane] = R; spx[64 + lane] = G; spx[128 + lane] = B;
-            __builtin_amdgcn_wave_barrier();
-            double pc_next = spx[ch * 64];
-            // the newest queue entry (previous pixel minus its chosen colour) is materialised only where the sum needs
-            // it -- as the LAST of the 16 terms -- so the LDS read of the chosen colour is in flight during the other 15
-            double pend_pc = q[15], pend_chosen = 0.0;                   // q[15] - 0: the entry as it stands
-#pragma unroll 1
-            for (int t0 = 0; t0 < 64; t0 += 16) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int t = t0 + j;
-                    const double pc = pc_next;
-                    pc_next = spx[ch * 64 + ((t + 1) & 63)];            // next pixel's channel, in flight during this step
-                    // ring: at step j the oldest entry sits in q[j], the newest (pending) belongs in q[(j + 15) & 15]
-                    double e = q[j] * qw[0];                            // riemersma.c:286-296 (0 + x == x)
-#pragma unroll
-                    for (int i = 1; i < 15; i++) e = e + q[(i + j) & 15] * qw[i];
-                    const double newest = pend_pc - pend_chosen;         // riemersma.c:333-340
-                    q[(j + 15) & 15] = newest;
-                    e = e + newest * qw[15];
-                    const double qv = Wc * (pc + e);
-                    const int bi = nearest(readlane_f64(qv, 0), readlane_f64(qv, 1), readlane_f64(qv, 2));
-                    if (lane == t) myidx = bi;
-                    pend_pc = pc; pend_chosen = praw[ch * k + bi];
-                }
-            }
-            // 64 steps are four full turns of the ring: q[0] is the oldest entry again, only the pending one is missing
-            q[15] = pend_pc - pend_chosen;
-        } else {
-            for (int t = 0; t < 64; t++) {
-                if (!((mask >> t) & 1ULL)) continue;                       // wave-uniform
-                // pixel t: its channel `lane` lands in lanes 0..2
-                const double pR = readlane_f64(R, t), pG = readlane_f64(G, t), pB = readlane_f64(B, t);
-                const double pc = lane == 0 ? pR : (lane == 1 ? pG : pB);
-                double e = q[0] * qw[0];                                   // riemersma.c:286-296 (0 + x == x)
-#pragma unroll
-                for (int i = 1; i < 16; i++) e = e + q[i] * qw[i];
-                const double qv = Wc * (pc + e);
-                const int bi = nearest(readlane_f64(qv, 0), readlane_f64(qv, 1), readlane_f64(qv, 2));
-                if (lane == t) myidx = bi;
-                const double chosen = praw[ch * k + bi];
-#pragma unroll
-                for (int i = 0; i < 15; i++) q[i] = q[i + 1];
-                q[15] = pc - chosen;                                       // original pixel - chosen colour (riemersma.c:333-340)
-            }
+        if (inb) {                                                   // append to the ring in curve order
+            const size_t p = (size_t)y * width + x;
+            const unsigned slot = (count + (unsigned)__popcll(mask & ((1ULL << lane) - 1ULL))) & (kRing - 1);
+            rpx[slot] = pr[p]; rpx[kRing + slot] = pg[p]; rpx[2 * kRing + slot] = pb[p];
+            rpos[slot] = (unsigned)p;
         }
-        if (inb) out[(size_t)y * width + x] = (OutT)myidx;
+        count += (unsigned)__popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+        while (count - head >= 16u) group(16);
         d0 += 64;
     }
+    if (count != head) group((int)(count - head));
 }
 
 template <typename OutT>
@@ -930,7 +963,8 @@ static void launch_dither_t(const double *d_img, size_t plane_stride, size_t wid
 
 void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
                    void *d_out, int elem_bytes, hipStream_t s) {
-    size_t lds = ((size_t)6 * k + 3 * 64) * sizeof(double);      // palette (raw + weighted) + one block of pixels
+    if (width * height >> 32) throw HipError("patolette_amd: the dither kernel numbers pixels with 32 bits");
+    size_t lds = ((size_t)6 * k + 3 * 128) * sizeof(double) + 128 * sizeof(unsigned int);      // palette (raw + weighted) + the ring of pending pixels
     if (lds > 150 * 1024) throw HipError("patolette_amd: palette too large for the dither kernel (K <= 3200)");
     DitherWeights wts;
     {
