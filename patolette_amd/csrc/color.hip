@@ -7,6 +7,7 @@
 // Arithmetic follows the reference expression by expression in f64 with contraction off;
 // only pow() differs (ocml vs glibc, last-ulp).  Bound: 48 B/px of HBM traffic; ~9 f64 pow
 // per pixel make the ICtCp chain VALU-heavy, still under the HBM time at 16 B/lane loads.
+#define PAMD_POW_TABLES_IN_LDS
 #include "color_device.h"
 #include "common.h"
 #include "devutil.h"
@@ -26,22 +27,14 @@ __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ d
     const bool do_sum = stats != nullptr && sumk.M0 != 0.0;
     constexpr bool kLut = std::is_same<SRC, SrcU8>::value && (WHICH == PAMD_SRGB_TO_ICTCP || WHICH == PAMD_SRGB_TO_CIELUV);
     __shared__ double glut[kLut ? 256 : 1];                // companding of the 256 possible 8-bit values (sRGB.c:70-89)
+    pow_tables_to_lds();
+    __syncthreads();
     if constexpr (kLut) {
         for (int b = threadIdx.x; b < 256; b += blockDim.x) glut[b] = dc::gamma_decode((double)b / 255.0);
         __syncthreads();
     }
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double c[3];
-        if constexpr (kLut) {
-            unsigned r, g, b;
-            src.load_bytes(i, r, g, b);
-            c[0] = glut[r]; c[1] = glut[g]; c[2] = glut[b];
-            dev_convert_linear<WHICH>(c);
-        } else {
-            src.load(i, c);
-            dev_convert<WHICH>(c);
-        }
+    auto finish = [&](const size_t i, double (&c)[3]) {
         dst[i] = c[0]; dst[n + i] = c[1]; dst[2 * n + i] = c[2];
 #pragma unroll
         for (int p = 0; p < 3; p++) { mn[p] = fmin(mn[p], c[p]); mx[p] = fmax(mx[p], c[p]); bad |= !(fabs(c[p]) < 0x1.ffffffp127); }
@@ -49,6 +42,20 @@ __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ d
 #pragma unroll
             for (int p = 0; p < 3; p++) bin_add(c[p], sumk, acc[2 * p], acc[2 * p + 1]);
         }
+    };
+    // the pow chains are VALU work (nine pow per pixel for ICtCp) during which nothing was in flight: the NEXT pixel's
+    // components are requested before this pixel's chain starts
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double nxt[3] = {0, 0, 0};
+    unsigned nr = 0, ng = 0, nb = 0;
+    if (i < n) { if constexpr (kLut) src.load_bytes(i, nr, ng, nb); else src.load(i, nxt); }
+    for (; i < n; i += stride) {
+        double c[3];
+        if constexpr (kLut) { c[0] = glut[nr]; c[1] = glut[ng]; c[2] = glut[nb]; }
+        else { c[0] = nxt[0]; c[1] = nxt[1]; c[2] = nxt[2]; }
+        if (i + stride < n) { if constexpr (kLut) src.load_bytes(i + stride, nr, ng, nb); else src.load(i + stride, nxt); }
+        if constexpr (kLut) dev_convert_linear<WHICH>(c); else dev_convert<WHICH>(c);
+        finish(i, c);
     }
     if (do_sum) {                                          // block-uniform
         __shared__ double ssum[6 * 4];
@@ -203,6 +210,8 @@ void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned 
 }
 
 __global__ __launch_bounds__(256) void k_pow(const double *__restrict__ x, double y, double *__restrict__ out, size_t n) {
+    pow_tables_to_lds();
+    __syncthreads();
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = pamd_pow(x[i], y);
 }

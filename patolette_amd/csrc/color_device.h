@@ -23,6 +23,22 @@ struct ConvertStats {                // filled by k_convert / k_weight_stats (or
 // this one ~70: log2 by a 128-entry table + degree-8 series, the product y*log2(x) and the argument of exp2 carried
 // as double-double, exp2 by a 64-entry table + degree-7 series (tables: tools/gen_pow_tables.py).  Error <= 0.51 ulp:
 // 99.8 % of results are bit-identical to glibc's correctly rounded pow, the rest are its neighbours.
+// The two tables (4 KB) are read at data-dependent places in the middle of every pow: from global memory that is an L1 round
+// trip on the critical path, nine times in a row per ICtCp pixel.  A translation unit that defines PAMD_POW_TABLES_IN_LDS before
+// including this header keeps a copy in LDS: each of its kernels calls pow_tables_to_lds() (+ a barrier) before its first pow.
+#ifdef PAMD_POW_TABLES_IN_LDS
+__shared__ double s_pow_log[128][3];
+__shared__ double s_pow_exp[64][2];
+__device__ __forceinline__ void pow_tables_to_lds() {
+    for (int i = threadIdx.x; i < 128 * 3; i += blockDim.x) (&s_pow_log[0][0])[i] = (&powtab::kLog[0][0])[i];
+    for (int i = threadIdx.x; i < 64 * 2; i += blockDim.x) (&s_pow_exp[0][0])[i] = (&powtab::kExp[0][0])[i];
+}
+#define PAMD_POW_LOG s_pow_log
+#define PAMD_POW_EXP s_pow_exp
+#else
+#define PAMD_POW_LOG kLog
+#define PAMD_POW_EXP kExp
+#endif
 __device__ __forceinline__ double pamd_pow(double x, double y) {
     using namespace powtab;
     if (!(x > 0.0)) return x == 0.0 ? (y > 0 ? 0.0 : (y == 0 ? 1.0 : INFINITY)) : NAN;
@@ -30,7 +46,7 @@ __device__ __forceinline__ double pamd_pow(double x, double y) {
     const double m = __builtin_amdgcn_frexp_mant(x) * 2.0;                 // [1, 2)
     const int e = __builtin_amdgcn_frexp_exp(x) - 1;
     const int i = (int)((m - 1.0) * 128.0);
-    const double r = kLog[i][0], Thi = kLog[i][1], Tlo = kLog[i][2];
+    const double r = PAMD_POW_LOG[i][0], Thi = PAMD_POW_LOG[i][1], Tlo = PAMD_POW_LOG[i][2];
     const double ph = m * r, pl = __builtin_fma(m, r, -ph);                  // m*r exactly = ph + pl
     const double zh = ph - 1.0, zl = pl;                                     // z = m*r - 1 exactly = zh + zl, |z| < 2^-8
     const double a = zh * kInvLn2Hi, ae = __builtin_fma(zh, kInvLn2Hi, -a);
@@ -47,7 +63,7 @@ __device__ __forceinline__ double pamd_pow(double x, double y) {
     const long long k = (long long)kd;
     const int j = (int)(k & 63), n = (int)(k >> 6);
     const double q = f * __builtin_fma(f, __builtin_fma(f, __builtin_fma(f, __builtin_fma(f, __builtin_fma(f, __builtin_fma(f, kE7, kE6), kE5), kE4), kE3), kE2), kE1);
-    const double Th = kExp[j][0], Tl = kExp[j][1];
+    const double Th = PAMD_POW_EXP[j][0], Tl = PAMD_POW_EXP[j][1];
     return ldexp(Th + __builtin_fma(Th, q, Tl), n);
 }
 
