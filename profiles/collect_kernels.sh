@@ -2,9 +2,9 @@
 # Run on the GPU box from the repo root:  sh profiles/collect_kernels.sh <tag> <config>
 # For the configurations that are not the default bench line (c4km, c4map ...): kernel-trace stats, the two HBM-traffic
 # PMC passes and the two SQ-counter passes of a short run (2 steps, 1 warm-up), each pass on its own.
-TAG=${1:-r01}; CFG=${2:-c4km}
+TAG=${1:-r02}; CFG=${2:-c4km}
 R=$PWD; OUT=$R/gpurun_out/prof/${TAG}_$CFG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-B="python $R/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --extra-streams 0"
+B="python $R/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-extras --extra-streams 0"
 $B > $OUT/bench_$CFG.json 2> $OUT/bench_$CFG.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $B > $OUT/bench_${CFG}_traced.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- $B --no-profile > /dev/null 2> $OUT/pmc_fetch.err

@@ -29,8 +29,10 @@ def short(name):
         return "k_cov"
     if base in ("k_nn_map_lut", "k_nn_map_mid"):
         return "k_nn_map"
-    if base in ("k_km_assign_count", "k_km_assign_lut", "k_km_assign_mid"):
+    if base in ("k_km_assign_count", "k_km_assign_lut", "k_km_assign_mid", "k_km_assign_plain"):
         return "k_km_assign"
+    if base in ("k_km_update", "k_km_update_direct"):
+        return "k_km_update"
     return base
 
 
@@ -41,7 +43,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recurs
         rows[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in rows.values())
 with open(os.path.join(root, "profiles", "%s_%s_kernel_stats.txt" % (outtag, cfg)), "w") as out:
-    out.write("rocprofv3 --kernel-trace --stats -- python bench.py --config %s --no-cpu-baseline --extra-streams 0\n" % cfg)
+    out.write("rocprofv3 --kernel-trace --stats -- python bench.py --config %s --no-cpu-baseline --no-extras --extra-streams 0\n" % cfg)
     out.write("%-86s %7s %12s %10s %10s %10s %6s\n" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
     for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
         out.write("%-86s %7d %12.1f %10.2f %10.2f %10.2f %6.1f\n" % (k[:86], len(v), sum(v), sum(v) / len(v), min(v), max(v), 100 * sum(v) / tot))

@@ -37,13 +37,32 @@ def main():
     dist.barrier()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert float(t.item()) == float(world)
+    # within-image sharding (patolette_amd/split.py): each rank holds half of one node's pixels; the all-reduced moment table and
+    # the cut must equal, bit for bit, what the whole node gives in one process
+    from patolette_amd import split as psplit
+    rng = np.random.default_rng(77)
+    npx = 30001
+    c = rng.random((npx, 3))
+    wts = 1.0 + 2.0 * rng.random(npx)
+    axis = np.array([0.6, -0.3, 0.74])
+    bink = psplit.make_bink(2, 15)
+    lo, hi = pdist.shard(npx, rank, world)
+    hi += lo
+    reduce_fn = lambda a, op: psplit.allreduce_dist(dist, a, op)      # noqa: E731
+    cut, _, red = psplit.split_node_sharded(c[lo:hi], wts[lo:hi], axis, bink, reduce_fn)
+    cut1, _, red1 = psplit.split_node_sharded(c, wts, axis, bink, lambda a, op: a)
+    split_ok = cut == cut1 and np.array_equal(red["parts"].view(np.uint64), red1["parts"].view(np.uint64)) and \
+        np.array_equal(red["count"], red1["count"]) and np.array_equal(red["size"], red1["size"])
+    flag = torch.tensor([1.0 if split_ok else 0.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    split_ok = float(flag.item()) == 1.0
     if rank == 0:
         assert len(res) == count
         single = [oracle_quantize(w, h, im, K, dither=False, kmeans_niter=0) for im in images]
         ok = all(r[0] and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2]) for r, s in zip(res, single))
         shards = [pdist.shard(count, r, world) for r in range(world)]
         with open(out_path, "w") as f:
-            f.write("OK" if ok and shards == [(0, 3), (3, 2)] else "MISMATCH")
+            f.write("OK" if ok and split_ok and shards == [(0, 3), (3, 2)] else "MISMATCH")
     else:
         assert res is None
     dist.barrier()
