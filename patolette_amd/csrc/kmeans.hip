@@ -1282,12 +1282,17 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
 }
 
 // --------------------------------------------------------------------------------------------
-// Few samples (the default: 512^2 of them, ~1000 per centroid): the stable counting sort costs more than the sums it feeds
-// (three launches and a k x chunks table per iteration).  Here ONE block per centroid finds its members itself: it scans
-// the one-byte assignments of all samples (nx bytes from L2 per block: 64 KB at a time, four SWAR compares per sixteen
-// samples), lists the matching sample numbers in LDS in sample order, and replays the centroid's sequential f32 chains
-// from there -- each wavefront gathers just its own coordinate.  Same sums in the same order as k_km_update.
+// Few samples (the default: 512^2 of them, ~1000 per centroid): the global stable counting sort costs more than the sums
+// it feeds (three launches and a k x chunks table per iteration).  Here the assignment kernel sorts each block of 1024
+// samples LOCALLY (stable counting sort in LDS: sample numbers grouped by centroid, sample order kept inside a group, plus
+// the 257 group offsets of the block), and ONE block per centroid then collects its members block by block -- two offsets
+// and ~4 sample numbers per block of samples instead of the block's 1024 assignments -- into a list in LDS and replays the
+// centroid's sequential f32 chains from there, each wavefront gathering just its own coordinate.  Same sums in the same
+// order as k_km_update; two launches per iteration, nothing else moves.
 // --------------------------------------------------------------------------------------------
+constexpr int kKmDirectCap = 16384;                                    // listed members between two chain replays (64 KB of LDS)
+constexpr int kKmSortBlock = 1024;                                     // samples sorted together by one block of k_km_assign_sort
+
 // inclusive prefix sum over the 64 lanes through DPP row shifts and row broadcasts (a __shfl_up loop is six LDS round trips)
 __device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
@@ -1298,8 +1303,18 @@ __device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2 and 3
     return v;
 }
-
-constexpr int kKmDirectCap = 16384;                                    // listed members between two chain replays (64 KB of LDS)
+// inclusive prefix over the threads of a block of up to 1024 (wsum: 16 words of LDS); *total = the block's sum
+__device__ __forceinline__ unsigned block_scan_incl_u32(const unsigned v, unsigned *wsum, unsigned *total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    const unsigned inc = wave_scan_incl_u32(v);
+    __syncthreads();                                                   // wsum may still be read from a previous call
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    unsigned pre = 0, all = 0;
+    for (int w = 0; w < nw; w++) { const unsigned t = wsum[w]; all += t; pre += w < wid ? t : 0u; }
+    *total = all;
+    return pre + inc;
+}
 
 // km_assign_one with two centroids per instruction: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 round each half like the scalar
 // instruction, so centroids 2p and 2p+1 (SIMD lanes l, l+1 of the reference's kernel) take four packed instructions instead of
@@ -1346,25 +1361,57 @@ __device__ __forceinline__ int km_assign_one_pk(const float x0, const float x1, 
     return (int)cur_i;
 }
 
-__global__ __launch_bounds__(256) void k_km_assign_plain(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, unsigned char *__restrict__ assign) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
+// Full scan + the block-local stable counting sort: sixteen wavefronts, wavefront w = the block's w-th run of 64 consecutive
+// samples.  sorted_idx[block][.] = sample numbers inside the block (u16) grouped by centroid, sample order kept inside a group;
+// offs[block][j] = where centroid j's group starts (offs[block][256] = the number of samples of the block).
+__global__ __launch_bounds__(1024) void k_km_assign_sort(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k,
+                                                         unsigned short *__restrict__ sorted_idx, unsigned short *__restrict__ offs) {
+    __shared__ unsigned char cnt[16][256];                             // members of (step, centroid): 64 at most
+    __shared__ unsigned short stepbase[16][256];                       // start of centroid j's group + its members in earlier steps
+    __shared__ unsigned int wsum[16];
+    const int lane = threadIdx.x & 63, step = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 16 * 256 / 4; i += 1024) reinterpret_cast<unsigned int *>(&cnt[0][0])[i] = 0u;
+    __syncthreads();
     const scalar_c4_t t4 = (scalar_c4_t)(unsigned long long)c4;
     const scalar_c8_t t8 = (scalar_c8_t)(unsigned long long)(c4 + k);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride)
-        assign[i] = (unsigned char)km_assign_one_pk(s.x[i], s.y[i], s.z[i], t4, t8, k);
+    const size_t blk0 = (size_t)blockIdx.x * kKmSortBlock;
+    const size_t i = blk0 + (size_t)threadIdx.x;
+    const bool v = i < nx;
+    const int a = v ? km_assign_one_pk(s.x[i], s.y[i], s.z[i], t4, t8, k) : 0;
+    const unsigned long long m = match_mask(a, 8, __ballot(v));
+    const unsigned rk = (unsigned)__popcll(m & ((1ULL << lane) - 1ULL)); // rank among the step's samples of the same centroid
+    if (v && rk == 0u) cnt[step][a] = (unsigned char)__popcll(m);      // group leader
+    __syncthreads();
+    // thread j < 256: centroid j's counts over the sixteen steps -> exclusive prefix; then the groups' starts by a block scan
+    unsigned tot = 0;
+    unsigned short pre[16];
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int st = 0; st < 16; st++) { pre[st] = (unsigned short)tot; tot += cnt[st][threadIdx.x]; }
+    }
+    unsigned total = 0;
+    const unsigned start = block_scan_incl_u32(tot, wsum, &total) - tot;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int st = 0; st < 16; st++) stepbase[st][threadIdx.x] = (unsigned short)(start + pre[st]);
+        unsigned short *ob = offs + (size_t)blockIdx.x * 257;
+        ob[threadIdx.x] = (unsigned short)start;
+        if (threadIdx.x == 255) ob[256] = (unsigned short)total;
+    }
+    __syncthreads();
+    if (v) sorted_idx[blk0 + (unsigned)stepbase[step][a] + rk] = (unsigned short)threadIdx.x;
 }
 
 template <bool W>
-__global__ __launch_bounds__(256) void k_km_update_direct(KmSamples s, const unsigned char *__restrict__ assign, unsigned long long nx, int k,
-                                                         float *cent, float *hassign, float4 *c4, unsigned int *ticket, DevMT *mt) {
+__global__ __launch_bounds__(256) void k_km_update_lists(KmSamples s, const unsigned short *__restrict__ sorted_idx, const unsigned short *__restrict__ offs,
+                                                        unsigned long long nx, int k, float *cent, float *hassign, float4 *c4,
+                                                        unsigned int *ticket, DevMT *mt) {
     __shared__ float4 stage[4][2][64];
     extern __shared__ unsigned int members[];                              // [kKmDirectCap] sample numbers, in sample order
     __shared__ float res[4];
     __shared__ int s_last;
-    __shared__ unsigned int wtot[4];
-    static_assert(kKmDirectCap >= 4 * 64 * 16 * 4, "one round of assignments must fit the member list");
+    __shared__ unsigned int wsum[16];
     const int kidx = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const unsigned pat = (unsigned)kidx * 0x01010101u;
     float acc = 0.f;
     size_t total = 0;
     unsigned fill = 0;                                                    // block-uniform
@@ -1375,68 +1422,26 @@ __global__ __launch_bounds__(256) void k_km_update_direct(KmSamples s, const uns
         else if (wid == 2) acc = km_chain_over<W, 2>([&](const size_t i) { return make_float4(0.f, 0.f, s.z[members[i]], W ? s.w[members[i]] : 0.f); }, n, stage[2], lane, acc);
         else if (W) acc = km_chain_over<W, 3>([&](const size_t i) { return make_float4(0.f, 0.f, 0.f, s.w[members[i]]); }, n, stage[3], lane, acc);
     };
-    // Rounds of 16384 samples: a lane holds 64 CONSECUTIVE one-byte assignments (four 16-byte loads), a wavefront 4096, so the
-    // members come out in sample order lane by lane; the next round's bytes are requested before this round's are looked at.
-    constexpr int R = 4;
-    constexpr unsigned kRound = 4u * 64u * 16u * R;
-    uint4 cur[R], nxt[R];
-    auto fetch = [&](const unsigned long long s0, uint4 (&v)[R]) {
-        const unsigned long long first = s0 + (unsigned)(wid * 64 + lane) * (16u * R);
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const unsigned long long at = first + 16u * (unsigned)r;
-            if (at + 16 <= nx) v[r] = *reinterpret_cast<const uint4 *>(assign + at);
-            else {                                                        // the ragged end: bytes past nx read as "not mine"
-                unsigned wv[4] = {~pat, ~pat, ~pat, ~pat};
-                for (unsigned bq = 0; bq < 16u && at + bq < nx; bq++)
-                    wv[bq >> 2] = (wv[bq >> 2] & ~(0xffu << (8 * (bq & 3)))) | ((unsigned)assign[at + bq] << (8 * (bq & 3)));
-                v[r] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-            }
-        }
-    };
-    fetch(0, nxt);
-    for (unsigned long long s0 = 0; s0 < nx; s0 += kRound) {
-#pragma unroll
-        for (int r = 0; r < R; r++) cur[r] = nxt[r];
-        if (s0 + kRound < nx) fetch(s0 + kRound, nxt);
-        unsigned long long mine = 0;                                      // bit b set <=> byte b of the lane's 64 is this centroid's
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const unsigned wv[4] = {cur[r].x, cur[r].y, cur[r].z, cur[r].w};
-            unsigned nib16 = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned x = wv[q] ^ pat;                           // zero bytes = matches
-                const unsigned y = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;       // bit 7 of a byte stays clear <=> its low seven bits were zero (no carries between bytes)
-                const unsigned z = ~(y | x | 0x7f7f7f7fu);                // bit 7 of byte b set <=> byte b matched
-                // the four flags (bits 7, 15, 23, 31) as a nibble, byte order kept: flag i moves from bit 8 i to bit 21 + i, no two
-                // partial products meet
-                nib16 |= (((((z >> 7) & 0x01010101u) * 0x00204081u) >> 21) & 0xfu) << (4 * q);
-            }
-            mine |= (unsigned long long)nib16 << (16 * r);
-        }
-        const unsigned c = (unsigned)__popcll(mine);
-        const unsigned inc = wave_scan_incl_u32(c);                       // DPP: no LDS round trips
-        if (lane == 63) wtot[wid] = inc;
-        __syncthreads();
-        const unsigned round_total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        if (fill + round_total > (unsigned)kKmDirectCap) {                // block-uniform: make room first (a round holds <= 16384)
-            replay();
-            fill = 0;
+    const unsigned long long nblocks = (nx + kKmSortBlock - 1) / kKmSortBlock;
+    for (unsigned long long c0 = 0; c0 < nblocks; c0 += 256) {            // 256 blocks of samples at a time: one per thread
+        const unsigned long long b = c0 + threadIdx.x;
+        unsigned o0 = 0, nb = 0;
+        if (b < nblocks) { o0 = offs[b * 257 + kidx]; nb = (unsigned)offs[b * 257 + kidx + 1] - o0; }
+        unsigned chunk_total = 0;
+        const unsigned excl = block_scan_incl_u32(nb, wsum, &chunk_total) - nb;
+        unsigned done = 0;
+        while (done < chunk_total) {                                      // block-uniform; one trip unless the list fills up
+            const unsigned take = min((unsigned)kKmDirectCap - fill, chunk_total - done);
+            const unsigned lo = max(excl, done), hi = min(excl + nb, done + take);
+            for (unsigned q = lo; q < hi; q++)
+                members[fill + q - done] = (unsigned)(b * kKmSortBlock) + (unsigned)sorted_idx[b * kKmSortBlock + o0 + (q - excl)];
+            fill += take; done += take;
             __syncthreads();
+            if (fill == (unsigned)kKmDirectCap) { replay(); fill = 0; __syncthreads(); }
         }
-        unsigned at = fill + inc - c;
-        for (int w = 0; w < wid; w++) at += wtot[w];
-        const unsigned first = (unsigned)s0 + (unsigned)(wid * 64 + lane) * (16u * R);
-        while (mine) {                                                    // a lane holds a member every fourth round on average (1 / k of its 64)
-            const int bit = __builtin_ctzll(mine);
-            mine &= mine - 1ULL;
-            members[at++] = first + (unsigned)bit;
-        }
-        fill += round_total;
-        total += round_total;
-        __syncthreads();
+        total += chunk_total;
     }
+    __syncthreads();
     replay();
     if (lane == 0) res[wid] = acc;
     __syncthreads();
@@ -1455,7 +1460,8 @@ void KMeansWork::reserve(size_t nx, int k) {
     sx.reserve(nx); sy.reserve(nx); sz.reserve(nx); sw.reserve(nx);
     assign.reserve(nx); sorted.reserve(nx);
     const int nchunks = (int)ceil_div(nx, (size_t)chunk_len_for(nx));
-    table.reserve((size_t)k * (size_t)(nchunks > 0 ? nchunks : 1));
+    table.reserve(std::max((size_t)k * (size_t)(nchunks > 0 ? nchunks : 1),
+                           (ceil_div(nx, (size_t)1024) * 257 + 1) / 2 + 1));        // also the u16 group offsets of k_km_assign_sort
     rowtot.reserve(k);
     cent.reserve(3 * (size_t)k); hassign.reserve(k); c4.reserve(2 * (size_t)k + 2);        // + the pairwise copy (km_store_c4)
     perm.reserve(nx);
@@ -1511,14 +1517,14 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         { KTIME("k_km_bounds", s, 12.0 * nx); hipLaunchKernelGGL(k_km_bounds, (int)std::min<size_t>(ceil_div(nx, 256), 2048), 256, 0, s, ks, nx, w.bkeys.p); }
         hipLaunchKernelGGL(k_km_bounds_fold, 1, 64, 0, s, w.bkeys.p, (KmGridDev *)w.grid.p);
     }
-    // few samples: no sort at all -- one block per centroid finds its members in the one-byte assignments (k_km_update_direct)
+    // few samples: block-local sorts in the assignment kernel, one block per centroid collects its members (k_km_update_lists)
     const size_t direct_max = getenv("PAMD_KM_DIRECT_MAX") ? (size_t)atoll(getenv("PAMD_KM_DIRECT_MAX")) : ((size_t)1 << 19);
     const bool use_direct = !use_lut && k <= 256 && nx <= direct_max && nx < ((size_t)1 << 32);
     if (use_direct) {
         static PerDeviceOnce attr4;
         if (attr4.first()) {
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_direct<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 4));
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_direct<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 4));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 4));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 4));
         }
     }
     static const bool mid_enabled = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
@@ -1528,17 +1534,19 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     const unsigned long long long_min = getenv("PAMD_KM_LONG_MIN") ? (unsigned long long)atoll(getenv("PAMD_KM_LONG_MIN")) : 8192ULL;
     for (int it = 0; it < niter; it++) {
         if (use_direct) {
-            unsigned char *a8 = (unsigned char *)w.assign.p;
+            unsigned short *sidx = (unsigned short *)w.assign.p;             // 2 of the 4 bytes per sample of the assignment buffer
+            unsigned short *offs = (unsigned short *)w.table.p;              // 257 x blocks x 2 bytes
+            const int sblocks = (int)ceil_div(nx, (size_t)kKmSortBlock);
             {
-                KTIME("k_km_assign", s, 13.0 * nx);
-                hipLaunchKernelGGL(k_km_assign_plain, (int)std::min<size_t>(ceil_div(nx, 256), 8192), 256, 0, s, ks, nx, w.c4.p, k, a8);
+                KTIME("k_km_assign", s, 14.0 * nx);
+                hipLaunchKernelGGL(k_km_assign_sort, sblocks, 1024, 0, s, ks, nx, w.c4.p, k, sidx, offs);
             }
             {
-                KTIME("k_km_update", s, (weighted ? 17.0 : 13.0) * nx);
-                if (weighted) hipLaunchKernelGGL(k_km_update_direct<true>, k, 256, kKmDirectCap * 4, s, ks, (const unsigned char *)a8, (unsigned long long)nx, k,
-                                                 w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
-                else hipLaunchKernelGGL(k_km_update_direct<false>, k, 256, kKmDirectCap * 4, s, ks, (const unsigned char *)a8, (unsigned long long)nx, k,
-                                        w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+                KTIME("k_km_update", s, (weighted ? 18.0 : 14.0) * nx);
+                if (weighted) hipLaunchKernelGGL(k_km_update_lists<true>, k, 256, kKmDirectCap * 4, s, ks, (const unsigned short *)sidx, (const unsigned short *)offs,
+                                                 (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+                else hipLaunchKernelGGL(k_km_update_lists<false>, k, 256, kKmDirectCap * 4, s, ks, (const unsigned short *)sidx, (const unsigned short *)offs,
+                                        (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
             }
             continue;
         }

@@ -29,9 +29,9 @@ def short(name):
         return "k_cov"
     if base in ("k_nn_map_lut", "k_nn_map_mid"):
         return "k_nn_map"
-    if base in ("k_km_assign_count", "k_km_assign_lut", "k_km_assign_mid", "k_km_assign_plain"):
+    if base in ("k_km_assign_count", "k_km_assign_lut", "k_km_assign_mid", "k_km_assign_plain", "k_km_assign_sort"):
         return "k_km_assign"
-    if base in ("k_km_update", "k_km_update_direct"):
+    if base in ("k_km_update", "k_km_update_direct", "k_km_update_lists"):
         return "k_km_update"
     return base
 
