@@ -140,6 +140,43 @@ void patolette_amd_batch_dmap(size_t count, size_t width, size_t height, const v
                               const patolette__QuantizationOptions *options, double *const *palettes, void *d_palette_maps,
                               int map_elem_bytes, int *exit_codes);
 
+/* ---- ONE image over several GPUs (SURVEY.md 8(f)-4, 8(e) last row) ------------------------
+ * The reference has no distributed code; this is the path's own sharding.  Every GPU of a group holds a contiguous slice
+ * of the image's pixels (image order: slice r+1 follows slice r) and runs the whole path on it; the only data that crosses
+ * GPUs are the per-node reductions of patolette.c's stages -- colour bounds and column sums (matrix2D.c:229), projection
+ * extrema (sort.c:43-59), 512-bucket moment tables (cells.c:82-112, local.c:118-134), the children's centred moments
+ * (cluster.c:111-152) -- and the KMeans subsample (refine.c:127-163, 262 144 x 12 bytes by default).  Those reductions are
+ * integers, ordered-key minima / maxima, or sums of addends on fixed grids (DESIGN.md 4.1 "order-independent sums"): exact in
+ * any grouping, so every GPU takes the same decisions and the result does not depend on how the pixels are dealt out --
+ * the palette is identical on every GPU and bit-identical to what one GPU computes for the whole image with
+ * patolette_amd_set_invariant_sums(1); each GPU's index map is its slice of that image's map.
+ *
+ * The library does not link a communication library: the caller lends it ONE collective, an in-place element-wise SUM over
+ * the group (RCCL all-reduce through torch.distributed in patolette_amd.dist; any MPI / RCCL binding will do).  dtype: 0 =
+ * f64, 1 = i64, 2 = i32.  `buffer` is device memory unless host_buffers is set (then the library stages through pinned
+ * host memory -- for CPU-side transports such as gloo).  The call returns when the reduced values are in `buffer`; non-zero =
+ * failure (exit code -1).  Minima, maxima and exclusive prefixes over the ranks are taken from a SUM over a table with one
+ * row per rank.  Every rank must make the same call (same palette_size, options, total_pixels). */
+typedef int (*patolette_amd_allreduce_sum_fn)(void *ctx, void *buffer, size_t count, int dtype);
+typedef struct patolette_amd__Comm {
+    int rank, size;
+    patolette_amd_allreduce_sum_fn allreduce_sum;
+    void *ctx;
+    int host_buffers;
+} patolette_amd__Comm;
+/* slice_data: planar f64 (x | y | z, plane stride slice_pixels) of pixels [slice_begin, slice_begin + slice_pixels) of an
+ * image of total_pixels pixels, host memory; slice_weights: NULL or slice_pixels doubles (all ranks alike); palette:
+ * palette_size x 3 column-major, the same on every rank; slice_map: slice_pixels entries (NULL with palette_only).
+ * Not available per slice: dithering (one serial chain over the whole image: exit code -1) and derived saliency weights
+ * (pass explicit weights).  Exit codes as patolette(); every slice must hold at least one pixel. */
+void patolette_amd_slice(size_t total_pixels, size_t slice_begin, size_t slice_pixels, const double *slice_data,
+                         const double *slice_weights, size_t palette_size, const patolette__QuantizationOptions *options,
+                         const patolette_amd__Comm *comm, double *palette, size_t *slice_map, int *exit_code);
+/* 1: the children's moments of every split are summed product by product on the exact grids (tiling-invariant, what the
+ * sliced path always does; 190 instead of 157 us per 4096^2 level in the partition kernel, +7 % on the whole step); 0 (default): per-thread partial sums first.  Applies to
+ * the calling thread's later calls.  Returns the previous setting. */
+int patolette_amd_set_invariant_sums(int on);
+
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
 /* patolette__EIGEN_solve (math/eigen.c:83-140: LAPACK dsyev 'V','L', n = 3) as the split loop's host side solves it:
  * a column-major 3x3 (lower triangle read) -> w ascending, z = eigenvectors as columns; returns LAPACK's info (0 = ok).

@@ -30,6 +30,15 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+ALLREDUCE_SUM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+
+class Comm(C.Structure):
+    """patolette_amd__Comm: the element-wise in-place SUM a group of GPUs lends to patolette_amd_slice."""
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("allreduce_sum", ALLREDUCE_SUM_FN), ("ctx", C.c_void_p),
+                ("host_buffers", C.c_int)]
+
+
 # every symbol include/patolette.h and include/patolette_amd.h declare
 SYMBOLS = {
     # --- include/patolette.h (the reference's ABI)
@@ -50,6 +59,9 @@ SYMBOLS = {
     "patolette_amd_batch_dmap": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.POINTER(dp), C.c_double,
                                         C.c_size_t, C.POINTER(QuantizationOptions), C.POINTER(dp), C.c_void_p, C.c_int,
                                         C.POINTER(C.c_int)]),
+    "patolette_amd_slice": (None, [C.c_size_t, C.c_size_t, C.c_size_t, dp, dp, C.c_size_t, C.POINTER(QuantizationOptions),
+                                   C.POINTER(Comm), dp, zp, C.POINTER(C.c_int)]),
+    "patolette_amd_set_invariant_sums": (C.c_int, [C.c_int]),
     "patolette_amd_eigen_sym3": (C.c_int, [dp, dp, dp]),
     "patolette_amd_principal_axis": (C.c_int, [dp, dp]),
     "patolette_amd_fill_image": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),

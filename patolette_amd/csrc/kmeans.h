@@ -26,6 +26,9 @@ struct KMeansWork {
 };
 
 void kmeans_gather(const double *d_planar, size_t N, bool weighted, const int *d_perm, size_t nx, KMeansWork &w, hipStream_t s);
+// the same for a GPU that holds pixels [begin, begin + n_local) of the image: foreign samples are written as zero bits
+void kmeans_gather_slice(const double *d_planar, size_t n_local, bool weighted, const int *d_perm, size_t nx, size_t begin,
+                         KMeansWork &w, hipStream_t s);
 void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s);
 
 }  // namespace pamd

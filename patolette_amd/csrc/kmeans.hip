@@ -40,6 +40,22 @@ __global__ __launch_bounds__(256) void k_km_gather(const double *__restrict__ pl
     }
 }
 
+// one image over several GPUs: this GPU holds pixels [begin, begin + n_local) of the image; samples outside it are left as zero
+// bits (the group then SUMs the bit patterns as integers: every element has exactly one non-zero addend)
+template <bool W>
+__global__ __launch_bounds__(256) void k_km_gather_slice(const double *__restrict__ planar, size_t n_local, const int *__restrict__ perm,
+                                                         size_t nx, size_t begin, KmSamples s) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride) {
+        const size_t g = perm ? (size_t)perm[i] : i;
+        const bool mine = g >= begin && g - begin < n_local;
+        const size_t p = mine ? g - begin : 0;
+        s.x[i] = mine ? (float)planar[p] : 0.0f; s.y[i] = mine ? (float)planar[n_local + p] : 0.0f;
+        s.z[i] = mine ? (float)planar[2 * n_local + p] : 0.0f;
+        if constexpr (W) s.w[i] = mine ? (float)planar[3 * n_local + p] : 0.0f;
+    }
+}
+
 __device__ __forceinline__ float4 make_c4(float v0, float v1, float v2) {
     return make_float4(v0, v1, v2, __builtin_fmaf(v2, v2, __builtin_fmaf(v0, v0, v1 * v1)));
 }
@@ -1477,6 +1493,18 @@ void kmeans_gather(const double *d_planar, size_t N, bool weighted, const int *d
     KTIME("k_km_gather", s, (weighted ? 48.0 : 36.0) * nx);
     if (weighted) hipLaunchKernelGGL(k_km_gather<true>, (int)g, 256, 0, s, d_planar, N, d_perm, nx, ks);
     else hipLaunchKernelGGL(k_km_gather<false>, (int)g, 256, 0, s, d_planar, N, d_perm, nx, ks);
+    HIP_CHECK(hipGetLastError());
+}
+
+void kmeans_gather_slice(const double *d_planar, size_t n_local, bool weighted, const int *d_perm, size_t nx, size_t begin,
+                         KMeansWork &w, hipStream_t s) {
+    KmSamples ks{w.sx.p, w.sy.p, w.sz.p, w.sw.p};
+    size_t g = ceil_div(nx, 256);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    KTIME("k_km_gather", s, (weighted ? 48.0 : 36.0) * nx);
+    if (weighted) hipLaunchKernelGGL(k_km_gather_slice<true>, (int)g, 256, 0, s, d_planar, n_local, d_perm, nx, begin, ks);
+    else hipLaunchKernelGGL(k_km_gather_slice<false>, (int)g, 256, 0, s, d_planar, n_local, d_perm, nx, begin, ks);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -78,7 +78,7 @@ __global__ void k_put_nodes(NodeDev *table, const NodeIn *stage, const int *ids,
     if (i >= n) return;
     const NodeIn in = stage[i];
     NodeDev &d = table[ids[i]];
-    d.begin = in.begin; d.n = in.n; d.buf = in.buf; d.slot = in.slot; d.child0 = in.child0; d.nchild = in.nchild;
+    d.begin = in.begin; d.n = in.n; d.gn = in.gn; d.buf = in.buf; d.slot = in.slot; d.child0 = in.child0; d.nchild = in.nchild;
     for (int j = 0; j < 3; j++) { d.axis[j] = in.axis[j]; d.mean[j] = in.mean[j]; }
     d.sw = in.sw; d.klin = in.klin; d.kquad = in.kquad;
     node_reset_outputs(d);
@@ -88,7 +88,7 @@ __global__ void k_get_nodes(const NodeDev *table, NodeOut *stage, const int *ids
     if (i >= n) return;
     const NodeDev &d = table[ids[i]];
     NodeOut o;
-    o.begin = d.begin; o.n = d.n; o.buf = d.buf; o.degenerate = d.degenerate; o.split = d.split; o.pad = 0;
+    o.begin = d.begin; o.n = d.n; o.gn = d.gn; o.buf = d.buf; o.degenerate = d.degenerate; o.split = d.split; o.pad = 0;
     o.sw = d.sw;
     for (int j = 0; j < 3; j++) o.mean[j] = d.mean[j];
     for (int q = 0; q < 7; q++) {                          // slot sums are exact (binned parts), any order
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup 
     for (size_t i = tid; i < (size_t)a.nr; i += stride) {
         const NodeIn in = a.recs[i];
         NodeDev &d = table[a.ids[i]];
-        d.begin = in.begin; d.n = in.n; d.buf = in.buf; d.slot = in.slot; d.child0 = in.child0; d.nchild = in.nchild;
+        d.begin = in.begin; d.n = in.n; d.gn = in.gn; d.buf = in.buf; d.slot = in.slot; d.child0 = in.child0; d.nchild = in.nchild;
         for (int j = 0; j < 3; j++) { d.axis[j] = in.axis[j]; d.mean[j] = in.mean[j]; }
         d.sw = in.sw; d.klin = in.klin; d.kquad = in.kquad;
         node_reset_outputs(d);
@@ -137,6 +137,65 @@ __global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup 
     for (size_t i = tid; i < a.nbk; i += stride) { a.hsize[i] = 0ULL; a.hcount[i] = 0u; }
 }
 
+// ---- one image over several GPUs (patolette_amd_slice): the node table's reductions, packed for ONE collective ----
+// The caller's collective is an element-wise SUM.  Extrema and per-rank counts travel in a table with one row per rank
+// (zero except the sender's own row): after the SUM every rank holds every rank's row and takes the minimum, the maximum
+// and the number of members on lower ranks (the node-wide slot of its first member: sort.c:61-79's round-robin rule).
+__global__ void k_shard_pack_keys(const NodeDev *table, const int *ids, int n, int rank, int size, unsigned long long *buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const NodeDev &d = table[ids[i]];
+    unsigned long long a = ~0ULL, b = 0ULL;
+    for (int k = 0; k < kSlots; k++) { a = d.minkey[k] < a ? d.minkey[k] : a; b = d.maxkey[k] > b ? d.maxkey[k] : b; }
+    for (int r = 0; r < size; r++) {
+        unsigned long long *row = buf + ((size_t)r * n + i) * 3;
+        row[0] = r == rank ? a : 0ULL; row[1] = r == rank ? b : 0ULL; row[2] = r == rank ? d.n : 0ULL;
+    }
+}
+__global__ void k_shard_unpack_keys(NodeDev *table, const int *ids, int n, int rank, int size, const unsigned long long *buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    NodeDev &d = table[ids[i]];
+    unsigned long long a = ~0ULL, b = 0ULL, before = 0ULL;
+    for (int r = 0; r < size; r++) {
+        const unsigned long long *row = buf + ((size_t)r * n + i) * 3;
+        a = row[0] < a ? row[0] : a; b = row[1] > b ? row[1] : b;
+        if (r < rank) before += row[2];
+    }
+    for (int k = 0; k < kSlots; k++) { d.minkey[k] = ~0ULL; d.maxkey[k] = 0ULL; }
+    d.minkey[0] = a; d.maxkey[0] = b; d.gslot0 = before;
+}
+// centred moments: slot sums are exact (binned parts), so is their SUM over the ranks
+__global__ void k_shard_pack_acc(const NodeDev *table, const int *ids, int n, double *buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const NodeDev &d = table[ids[i]];
+    for (int q = 0; q < 7; q++) {
+        double s0 = 0, s1 = 0;
+        for (int k = 0; k < kSlots; k++) { s0 += d.acc[k][q][0]; s1 += d.acc[k][q][1]; }
+        buf[(size_t)i * 14 + 2 * q] = s0; buf[(size_t)i * 14 + 2 * q + 1] = s1;
+    }
+}
+__global__ void k_shard_unpack_acc(NodeDev *table, const int *ids, int n, const double *buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    NodeDev &d = table[ids[i]];
+    for (int q = 0; q < 7; q++) {
+        for (int k = 1; k < kSlots; k++) { d.acc[k][q][0] = 0; d.acc[k][q][1] = 0; }
+        d.acc[0][q][0] = buf[(size_t)i * 14 + 2 * q]; d.acc[0][q][1] = buf[(size_t)i * 14 + 2 * q + 1];
+    }
+}
+// k_cut / the host sized the children from the GROUP's bucket counts; their segments on this GPU are what k_scan found
+__global__ void k_shard_children_local(NodeDev *table, const int *round_nodes, int nround) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nround) return;
+    const NodeDev &nd = table[round_nodes[i]];
+    for (int k = 0; k < nd.nchild; k++) {
+        NodeDev &ch = table[nd.child0 + k];
+        ch.begin = nd.cbegin[k]; ch.n = nd.cbegin[k + 1] - nd.cbegin[k];
+    }
+}
+
 struct Bounds {
     double cmax, range, wmax; int e_lin, e_quad; double lo[3], hi[3];
     bool have_sum = false; double sum[3] = {0, 0, 0};        // column sums of the converted image, when the conversion took them
@@ -149,9 +208,19 @@ static int exp_bound(double v) {                 // smallest E with 2^E > v (v >
 }
 
 // --------------------------------------------------------------------------------------------
+struct Shard {                       // this GPU's part of an image dealt out over a group (patolette_amd_slice)
+    size_t total = 0, begin = 0;     // pixels of the whole image; first pixel of the slice
+    patolette_amd__Comm comm{};
+};
+
 struct Engine {
     int device = -1;
     hipStream_t stream = nullptr;
+    const Shard *shard = nullptr;    // set for the duration of a sliced call
+    bool invariant = getenv("PAMD_INVARIANT_SUMS") && atoi(getenv("PAMD_INVARIANT_SUMS")) != 0;   // tiling-invariant children moments (always on while `shard` is set)
+    DevBuf<unsigned char> commbuf;
+    PinBuf<unsigned char> h_comm;
+    DevBuf<int> shard_ids;
     DevBuf<double> src, wsrc, cvt, bufA, bufB, aux;
     DevBuf<unsigned short> bkt;
     DevBuf<NodeDev> nodes;
@@ -240,13 +309,80 @@ static Engine &engine() {
     return *h.e;
 }
 
+// ---- the group's collective (element-wise in-place SUM lent by the caller) ----
+static size_t comm_elem(int dtype) { return dtype == 2 ? 4 : 8; }
+static void comm_sum_dev(Engine &E, void *d, size_t count, int dtype) {         // d: device memory
+    if (!count) return;
+    HIP_CHECK(hipStreamSynchronize(E.stream));
+    const patolette_amd__Comm &c = E.shard->comm;
+    int rc;
+    if (c.host_buffers) {
+        const size_t bytes = count * comm_elem(dtype);
+        E.h_comm.reserve(bytes);
+        HIP_CHECK(hipMemcpy(E.h_comm.p, d, bytes, hipMemcpyDeviceToHost));
+        rc = c.allreduce_sum(c.ctx, E.h_comm.p, count, dtype);
+        HIP_CHECK(hipMemcpy(d, E.h_comm.p, bytes, hipMemcpyHostToDevice));
+    } else rc = c.allreduce_sum(c.ctx, d, count, dtype);
+    if (rc != 0) throw HipError("patolette_amd: the caller's all-reduce reported a failure");
+}
+static void comm_sum_host(Engine &E, void *h, size_t count, int dtype) {        // h: host memory
+    if (!count) return;
+    const patolette_amd__Comm &c = E.shard->comm;
+    const size_t bytes = count * comm_elem(dtype);
+    int rc;
+    if (c.host_buffers) rc = c.allreduce_sum(c.ctx, h, count, dtype);
+    else {
+        E.commbuf.reserve(bytes);
+        HIP_CHECK(hipMemcpy(E.commbuf.p, h, bytes, hipMemcpyHostToDevice));
+        rc = c.allreduce_sum(c.ctx, E.commbuf.p, count, dtype);
+        HIP_CHECK(hipMemcpy(h, E.commbuf.p, bytes, hipMemcpyDeviceToHost));
+    }
+    if (rc != 0) throw HipError("patolette_amd: the caller's all-reduce reported a failure");
+}
+// every rank's row of n values (bit patterns travel as i64: one non-zero addend per element)
+static std::vector<unsigned long long> comm_gather_u64(Engine &E, const unsigned long long *mine, size_t n) {
+    const patolette_amd__Comm &c = E.shard->comm;
+    std::vector<unsigned long long> all((size_t)c.size * n, 0ULL);
+    for (size_t i = 0; i < n; i++) all[(size_t)c.rank * n + i] = mine[i];
+    comm_sum_host(E, all.data(), all.size(), 1);
+    return all;
+}
+// projection extrema + member counts of the nodes whose ids sit at d_ids (device): folded, exchanged, written back
+static void shard_exchange_keys(Engine &E, const int *d_ids, int n) {
+    if (!n) return;
+    const patolette_amd__Comm &c = E.shard->comm;
+    const size_t cnt = (size_t)c.size * n * 3;
+    E.commbuf.reserve(cnt * 8);
+    hipLaunchKernelGGL(k_shard_pack_keys, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, d_ids, n, c.rank, c.size, (unsigned long long *)E.commbuf.p);
+    HIP_CHECK(hipGetLastError());
+    comm_sum_dev(E, E.commbuf.p, cnt, 1);
+    hipLaunchKernelGGL(k_shard_unpack_keys, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, d_ids, n, c.rank, c.size, (const unsigned long long *)E.commbuf.p);
+    HIP_CHECK(hipGetLastError());
+}
+static void shard_exchange_acc(Engine &E, const int *d_ids, int n) {
+    if (!n) return;
+    E.commbuf.reserve((size_t)n * 14 * 8);
+    hipLaunchKernelGGL(k_shard_pack_acc, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, d_ids, n, (double *)E.commbuf.p);
+    HIP_CHECK(hipGetLastError());
+    comm_sum_dev(E, E.commbuf.p, (size_t)n * 14, 0);
+    hipLaunchKernelGGL(k_shard_unpack_acc, (n + 63) / 64, 64, 0, E.stream, E.nodes.p, d_ids, n, (const double *)E.commbuf.p);
+    HIP_CHECK(hipGetLastError());
+}
+static const int *shard_upload_ids(Engine &E, const std::vector<int> &ids) {
+    E.shard_ids.reserve(ids.size());
+    HIP_CHECK(hipStreamSynchronize(E.stream));
+    HIP_CHECK(hipMemcpy(E.shard_ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+    return E.shard_ids.p;
+}
+
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // host mirror of one tree node
 struct HNode {
-    unsigned long long begin = 0, n = 0;
+    unsigned long long begin = 0, n = 0;     // segment on this GPU
+    unsigned long long gn = 0;               // members over the whole group (= n unless the image is sliced over GPUs)
     int buf = 0;
     double sw = 0, mean[3] = {0, 0, 0}, cov6[6] = {0, 0, 0, 0, 0, 0}, dist = 0;
     int left = -1, right = -1;
@@ -274,11 +410,11 @@ static void build_tiles(const std::vector<int> &round, const std::vector<HNode> 
 static NodeIn make_nodedev(const HNode &h, const Bounds &b) {
     NodeIn d;
     std::memset(&d, 0, sizeof d);
-    d.begin = h.begin; d.n = h.n; d.buf = h.buf; d.slot = -1; d.child0 = -1; d.nchild = 0;
+    d.begin = h.begin; d.n = h.n; d.gn = h.gn; d.buf = h.buf; d.slot = -1; d.child0 = -1; d.nchild = 0;
     for (int j = 0; j < 3; j++) d.mean[j] = h.mean[j];
     d.sw = h.sw;
     int P = 1;
-    while ((1ULL << P) < (h.n > 1 ? h.n : 2)) P++;
+    while ((1ULL << P) < (h.gn > 1 ? h.gn : 2)) P++;
     d.klin = make_bink(b.e_lin, P);
     d.kquad = make_bink(b.e_quad, P);
     return d;
@@ -361,6 +497,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                              std::vector<double> &centers, size_t &len, bool verbose = false) {
     hipStream_t s = E.stream;
     const size_t planes = weighted ? 4 : 3;
+    const Shard *sh = E.shard;                                  // the image is dealt out over a group of GPUs: N is this GPU's part
+    const size_t Nt = sh ? sh->total : N;                       // pixels of the whole image
+    const bool inv_sums = sh || E.invariant;
     E.bufA.reserve(planes * N); E.bufB.reserve(planes * N); E.bkt.reserve(N);
     E.nodes.reserve(4 * K + 64);
     std::vector<HNode> hn;
@@ -369,18 +508,19 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
 
     // ---------------- global quantiser (global.c:388-443) ----------------
     // unweighted PCA of all pixels: mean, centred covariance, dsyev
-    HNode root; root.begin = 0; root.n = N; root.buf = 0; root.sw = (double)N;
+    HNode root; root.begin = 0; root.n = N; root.gn = Nt; root.buf = 0; root.sw = (double)Nt;
     E.h_dbl.reserve(16 * kBuckets * 2 + 64);
     if (bnd.have_sum) {
-        const double inv = 1 / (double)N;                       // matrix2D.c:229; the sums came with the conversion pass
+        const double inv = 1 / (double)Nt;                      // matrix2D.c:229; the sums came with the conversion pass
         for (int j = 0; j < 3; j++) root.mean[j] = bnd.sum[j] * inv;
     } else {
-        int rootP = 1; while ((1ULL << rootP) < (N > 1 ? N : 2)) rootP++;
+        int rootP = 1; while ((1ULL << rootP) < (Nt > 1 ? Nt : 2)) rootP++;
         E.sum6.reserve(kSum3Slots * 6);
         launch_sum3(E.cvt.p, N, make_bink(bnd.e_lin, rootP), E.sum6.p, s);
+        if (sh) comm_sum_dev(E, E.sum6.p, kSum3Slots * 6, 0);
         HIP_CHECK(hipMemcpyAsync(E.h_dbl.p, E.sum6.p, kSum3Slots * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
         E.sync();
-        const double inv = 1 / (double)N;                       // matrix2D.c:229
+        const double inv = 1 / (double)Nt;                      // matrix2D.c:229
         for (int j = 0; j < 3; j++) {
             double p0 = 0, p1 = 0;                              // slot partials are exact multiples of the bin grids
             for (int sl = 0; sl < kSum3Slots; sl++) { p0 += E.h_dbl.p[sl * 6 + 2 * j]; p1 += E.h_dbl.p[sl * 6 + 2 * j + 1]; }
@@ -401,6 +541,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     }
     launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
     std::vector<NodeOut> got;
+    if (sh) shard_exchange_acc(E, shard_upload_ids(E, {0}), 1);
     get_nodes(E, {0}, got);
     absorb_moments(hn[0], got[0]);
     double axis[3];
@@ -419,7 +560,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     HIP_CHECK(hipMemsetAsync(E.hsize.p, 0, kBuckets * sizeof(unsigned long long), s));
     HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, kBuckets * sizeof(unsigned int), s));
     launch_minmax(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
+    if (sh) shard_exchange_keys(E, shard_upload_ids(E, {0}), 1);
     launch_hist(qroot, true, E.tilesA.p, (int)tA.size(), N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+    if (sh) { comm_sum_dev(E, E.hist.p, hs, 0); comm_sum_dev(E, E.hcount.p, kBuckets, 2); }
     const int gq_kmax = (int)std::min<size_t>(K, kGqMaxK);
     E.gq.reserve(1); E.h_gq.reserve(1);
     launch_gq_dp(E.hist.p, E.hcount.p, gq_kmax, E.gq.p, s);
@@ -473,7 +616,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                     s1[q] += hh[(size_t)(qi * 2 + 1) * kBuckets + b];
                 }
             }
-            c.n = cnt;
+            c.n = cnt; c.gn = cnt;                                   // sliced image: the segment on this GPU follows from the partition
             c.sw = weighted ? (s0[3] + s1[3]) : (double)cnt;
             const double inv = 1 / c.sw;
             for (int q = 0; q < 3; q++) c.mean[q] = (s0[q] + s1[q]) * inv;
@@ -499,9 +642,14 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     upload_ints(E, tile0, E.node_tile0, E.h_tile0);
     E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
     launch_partition(qroot, E.tilesP.p, (int)tP.size(), N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, false, s);
+    if (sh) { hipLaunchKernelGGL(k_shard_children_local, 1, 64, 0, s, E.nodes.p, E.round_nodes.p, 1); HIP_CHECK(hipGetLastError()); }
     launch_cov_children(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
+    if (sh) shard_exchange_acc(E, shard_upload_ids(E, base_ids), (int)base_ids.size());
     get_nodes(E, base_ids, got);
-    for (size_t i = 0; i < base_ids.size(); i++) absorb_moments(hn[base_ids[i]], got[i]);
+    for (size_t i = 0; i < base_ids.size(); i++) {
+        absorb_moments(hn[base_ids[i]], got[i]);
+        if (sh) { hn[base_ids[i]].begin = got[i].begin; hn[base_ids[i]].n = got[i].n; }
+    }
     E.stats.n_base_clusters = (size_t)kbase;
     if (verbose) printf("patolette ======== Base cluster count: %zu\n", (size_t)kbase);     // patolette.c:227-229
     E.stats.ms_gq = now_ms() - t0;
@@ -513,9 +661,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     const double spec_beta = 1.0 / 64;
     size_t count = result.size();
     E.stats.split_evals = 0; E.stats.split_px = 0; E.stats.lq_rounds = 0;
-    auto known = [&](const HNode &h) { return h.nosplit || h.n <= 1 || h.split_done; };
+    auto known = [&](const HNode &h) { return h.nosplit || h.gn <= 1 || h.split_done; };
     auto benefit = [&](const HNode &h) -> double {
-        if (h.nosplit || h.n <= 1) return 0;                    // children == NULL -> 0 (local.c:262-264)
+        if (h.nosplit || h.gn <= 1) return 0;                    // children == NULL -> 0 (local.c:262-264)
         return h.dist - (hn[h.left].dist + hn[h.right].dist);
     };
     if (count < K) {
@@ -631,14 +779,25 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 HIP_CHECK(hipGetLastError());
             }
             launch_minmax(qlq, E.tilesA.p, ntA, rpx, E.nodes.p, s);
+            if (sh) shard_exchange_keys(E, d_ids, nr);
             launch_hist(qlq, false, E.tilesA.p, ntA, rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+            if (sh) {
+                comm_sum_dev(E, E.hist.p, lqs * nr, 0);
+                if (weighted) comm_sum_dev(E, E.hsize.p, (size_t)nr * kBuckets, 1);
+                comm_sum_dev(E, E.hcount.p, (size_t)nr * kBuckets, 2);
+            }
             launch_cut(weighted, E.nodes.p, d_ids, nr, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s);
-            launch_partition(qlq, E.tilesP.p, ntP, rpx, d_ids, d_tP0, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s);
+            launch_partition(qlq, E.tilesP.p, ntP, rpx, d_ids, d_tP0, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s, inv_sums);
+            if (sh) {
+                hipLaunchKernelGGL(k_shard_children_local, (nr + 63) / 64, 64, 0, s, E.nodes.p, d_ids, nr);
+                HIP_CHECK(hipGetLastError());
+                shard_exchange_acc(E, (const int *)(E.packet.p + o_cids), (int)cids.size());
+            }
             get_nodes_dev(E, (const int *)(E.packet.p + o_cids), (int)cids.size(), got);
             for (size_t i = 0; i < cids.size(); i++) {
                 HNode &c = hn[cids[i]];
                 const NodeOut &d = got[i];
-                c.begin = d.begin; c.n = d.n; c.buf = d.buf; c.sw = d.sw;
+                c.begin = d.begin; c.n = d.n; c.gn = d.gn; c.buf = d.buf; c.sw = d.sw;
                 for (int j = 0; j < 3; j++) c.mean[j] = d.mean[j];
                 absorb_moments(c, d);
             }
@@ -670,28 +829,50 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
     const int mppc = (int)(ms / k);                                                // refine.c:87
     // Clustering.cpp:272-278 (fewer points than centroids) and :295-304 (a NaN / Inf among the f32 inputs) throw; refine.c:91
     // swallows the exception and the palette stays the initial centres
-    bool ok = N >= k && !nonfinite;
-    size_t nx = N;
+    const Shard *sh = E.shard;                                                     // sliced image: N is this GPU's part, the sample set is the whole image's
+    const size_t Nt = sh ? sh->total : N;
+    bool ok = Nt >= k && !nonfinite;
+    size_t nx = Nt;
     E.stats.kmeans_samples = 0;
     if (ok) {
-        const bool sub = N > k * (size_t)mppc;                                     // Clustering.cpp:311-319
+        const bool sub = Nt > k * (size_t)mppc;                                    // Clustering.cpp:311-319
         if (sub) nx = k * (size_t)mppc;
         E.km.reserve(nx, (int)k);
         const int *dperm = nullptr;
         if (sub) {
             // faiss draws the subsample from rand_perm(N, seed 1234): a pure function of (N, nx), so the
             // index list is kept on the device between calls (a batch of same-sized images pays once)
-            if (E.perm_N != N || E.perm_nx != nx) {
+            if (E.perm_N != Nt || E.perm_nx != nx) {
                 std::vector<int32_t> perm(nx);
-                hm::rand_perm_prefix(N, nx, 1234u, perm.data());                   // random.cpp:184-194
+                hm::rand_perm_prefix(Nt, nx, 1234u, perm.data());                  // random.cpp:184-194
                 E.perm_dev.reserve(nx);
                 HIP_CHECK(hipMemcpyAsync(E.perm_dev.p, perm.data(), nx * sizeof(int), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                E.perm_N = N; E.perm_nx = nx;
+                E.perm_N = Nt; E.perm_nx = nx;
             }
             dperm = E.perm_dev.p;
         }
-        if (nx == k) {                                                             // Clustering.cpp:331-352: centroids = first k input vectors
+        if (sh) {
+            // every GPU contributes the samples that fall into its slice (zero bits elsewhere); the integer SUM of the bit
+            // patterns hands every GPU the whole sample set, and each runs the same deterministic iterations on it
+            kmeans_gather_slice(E.cvt.p, N, weighted, dperm, nx, sh->begin, E.km, s);
+            comm_sum_dev(E, E.km.sx.p, nx, 2); comm_sum_dev(E, E.km.sy.p, nx, 2); comm_sum_dev(E, E.km.sz.p, nx, 2);
+            if (weighted) comm_sum_dev(E, E.km.sw.p, nx, 2);
+            if (nx == k) {                                                         // Clustering.cpp:331-352: centroids = first k input vectors
+                std::vector<float> f(3 * k);
+                HIP_CHECK(hipMemcpy(f.data(), E.km.sx.p, k * sizeof(float), hipMemcpyDeviceToHost));
+                HIP_CHECK(hipMemcpy(f.data() + k, E.km.sy.p, k * sizeof(float), hipMemcpyDeviceToHost));
+                HIP_CHECK(hipMemcpy(f.data() + 2 * k, E.km.sz.p, k * sizeof(float), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < k; i++) for (int j = 0; j < 3; j++) cent[3 * i + j] = f[(size_t)j * k + i];
+            } else {
+                HIP_CHECK(hipMemcpyAsync(E.km.cent.p, cent.data(), 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                kmeans_iterate(E.km, nx, (int)k, weighted, niter, s);
+                HIP_CHECK(hipMemcpyAsync(cent.data(), E.km.cent.p, 3 * k * sizeof(float), hipMemcpyDeviceToHost, s));
+                E.sync();
+                E.stats.kmeans_samples = nx;
+            }
+        } else if (nx == k) {                                                      // Clustering.cpp:331-352: centroids = first k input vectors
             std::vector<double> first(3 * k);
             for (int j = 0; j < 3; j++) HIP_CHECK(hipMemcpy(first.data() + (size_t)j * k, E.cvt.p + (size_t)j * N, k * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t i = 0; i < k; i++) for (int j = 0; j < 3; j++) cent[3 * i + j] = (float)first[(size_t)j * k + i];
@@ -722,28 +903,40 @@ static Bounds read_bounds(Engine &E, bool weighted) {
     E.sync();
     Bounds b;
     b.cmax = 0; b.range = 0;
+    unsigned long long kmin[3], kmax[3], kw = 0ULL, nonfinite = cs.nonfinite_f32 != 0u ? 1ULL : 0ULL;
+    double parts[3][2];
     for (int p = 0; p < 3; p++) {
-        unsigned long long ka = ~0ULL, kb = 0ULL;
-        for (int t = 0; t < kStatSlots; t++) { ka = std::min(ka, cs.minkey[t][p]); kb = std::max(kb, cs.maxkey[t][p]); }
+        kmin[p] = ~0ULL; kmax[p] = 0ULL;
+        for (int t = 0; t < kStatSlots; t++) { kmin[p] = std::min(kmin[p], cs.minkey[t][p]); kmax[p] = std::max(kmax[p], cs.maxkey[t][p]); }
+        parts[p][0] = 0; parts[p][1] = 0;                      // slot partials are exact multiples of the bin grids
+        for (int t = 0; t < kStatSlots; t++) { parts[p][0] += cs.sum[t][p][0]; parts[p][1] += cs.sum[t][p][1]; }
+    }
+    for (int t = 0; t < kStatSlots; t++) kw = std::max(kw, cs.wmaxkey[t]);
+    if (E.shard) {                                             // one image over several GPUs: the bounds and sums of ALL its pixels
+        const unsigned long long mine[8] = {kmin[0], kmin[1], kmin[2], kmax[0], kmax[1], kmax[2], kw, nonfinite};
+        const std::vector<unsigned long long> all = comm_gather_u64(E, mine, 8);
+        for (int r = 0; r < E.shard->comm.size; r++) {
+            const unsigned long long *row = all.data() + (size_t)r * 8;
+            for (int p = 0; p < 3; p++) { kmin[p] = std::min(kmin[p], row[p]); kmax[p] = std::max(kmax[p], row[3 + p]); }
+            kw = std::max(kw, row[6]); nonfinite |= row[7];
+        }
+        comm_sum_host(E, &parts[0][0], 6, 0);
+    }
+    for (int p = 0; p < 3; p++) {
+        const unsigned long long ka = kmin[p], kb = kmax[p];
         double mn = key_f64(ka), mx = key_f64(kb);
         if (!(mn <= mx)) { mn = 0; mx = 0; }
         b.lo[p] = mn; b.hi[p] = mx;
         b.cmax = std::max(b.cmax, std::max(std::fabs(mn), std::fabs(mx)));
         b.range = std::max(b.range, mx - mn);
     }
-    unsigned long long kw = 0ULL;
-    for (int t = 0; t < kStatSlots; t++) kw = std::max(kw, cs.wmaxkey[t]);
     b.wmax = weighted ? std::max(1.0, key_f64(kw)) : 1.0;
     const double lin = b.wmax * std::max(b.cmax, 1.0);
     const double quad = 3.0 * b.wmax * std::max(std::max(b.range, b.cmax), 1e-300) * std::max(std::max(b.range, b.cmax), 1e-300);
     b.e_lin = exp_bound(lin);
     b.e_quad = exp_bound(std::max(quad, 1e-300));
-    for (int p = 0; p < 3; p++) {                              // slot partials are exact multiples of the bin grids
-        double p0 = 0, p1 = 0;
-        for (int t = 0; t < kStatSlots; t++) { p0 += cs.sum[t][p][0]; p1 += cs.sum[t][p][1]; }
-        b.sum[p] = p0 + p1;
-    }
-    b.nonfinite = cs.nonfinite_f32 != 0u;
+    for (int p = 0; p < 3; p++) b.sum[p] = parts[p][0] + parts[p][1];
+    b.nonfinite = nonfinite != 0ULL;
     return b;
 }
 
@@ -775,8 +968,11 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     // the root mean of the global quantiser (matrix2D.c:229) rides along with the conversion where the colour space bounds
     // the values a priori: |I| <= 1, |Ct|, |Cp| <= 0.5 (2^1); L <= 100, |u|, |v| < 256 (2^8).  sRGB passes user data through.
     BinK sumk{0.0, 0.0};
+    if (E.shard && opt->dither && !opt->palette_only)
+        throw HipError("patolette_amd: dithering is one serial chain over the whole image; it is not available per slice");
     {
-        int rootP = 1; while ((1ULL << rootP) < (N > 1 ? N : 2)) rootP++;
+        const size_t Nt = E.shard ? E.shard->total : N;        // a slice sums on the grids of the whole image
+        int rootP = 1; while ((1ULL << rootP) < (Nt > 1 ? Nt : 2)) rootP++;
         if (which == PAMD_SRGB_TO_ICTCP) sumk = make_bink(1, rootP);
         else if (which == PAMD_SRGB_TO_CIELUV) sumk = make_bink(8, rootP);
     }
@@ -1159,6 +1355,43 @@ void patolette_amd_quantize_rows(size_t width, size_t height, const double *rows
         fprintf(stderr, "patolette: %s\n", ex.what());
         *exit_code = -1;
     }
+}
+
+void patolette_amd_slice(size_t total_pixels, size_t slice_begin, size_t slice_pixels, const double *slice_data,
+                         const double *slice_weights, size_t palette_size, const patolette__QuantizationOptions *options,
+                         const patolette_amd__Comm *comm, double *palette, size_t *slice_map, int *exit_code) {
+    *exit_code = validate(total_pixels, 1, palette_size);
+    if (*exit_code != 0) return;
+    if (!comm || !comm->allreduce_sum || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size || slice_pixels == 0 ||
+        slice_begin > total_pixels || slice_pixels > total_pixels - slice_begin || !slice_data ||
+        (!options->palette_only && !slice_map)) {
+        *exit_code = -1;
+        return;
+    }
+    Shard sh;
+    sh.total = total_pixels; sh.begin = slice_begin; sh.comm = *comm;
+    Engine *Ep = nullptr;
+    try {
+        Engine &E = engine();
+        Ep = &E;
+        E.init();
+        E.shard = &sh;
+        run_host(E, slice_pixels, 1, slice_data, slice_weights, 0.0, palette_size, options, palette, slice_map);
+        E.shard = nullptr;
+        *exit_code = 0;
+    } catch (const std::exception &ex) {
+        if (Ep) Ep->shard = nullptr;
+        engine().last_error = ex.what();
+        fprintf(stderr, "patolette: %s\n", ex.what());
+        *exit_code = -1;
+    }
+}
+
+int patolette_amd_set_invariant_sums(int on) {
+    Engine &E = engine();
+    const int before = E.invariant ? 1 : 0;
+    E.invariant = on != 0;
+    return before;
 }
 
 int patolette_amd_saliency_weights(size_t width, size_t height, const double *data, double tile_size, double *weights_out) {

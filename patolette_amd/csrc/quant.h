@@ -21,14 +21,14 @@ constexpr int kSlots = 16;             // accumulator copies per node: same-addr
 
 // host -> device (k_put_nodes)
 struct NodeIn {
-    unsigned long long begin, n;
+    unsigned long long begin, n, gn;   // gn: members over ALL GPUs of a within-image shard group (= n on one GPU)
     int buf, slot, child0, nchild;
     double axis[3], mean[3], sw;
     BinK klin, kquad;
 };
 // device -> host (k_get_nodes)
 struct NodeOut {
-    unsigned long long begin, n;
+    unsigned long long begin, n, gn;
     int buf, degenerate, split, pad;
     double sw, mean[3];
     double acc[7][2];                  // slot sums: 6 covariance sums (xx,yx,zx,yy,zy,zz) + distortion, 2 binned parts each
@@ -37,7 +37,9 @@ struct NodeOut {
 struct NodeDev {
     // ---- inputs (host or k_cut writes them)
     unsigned long long begin;          // first pixel slot of the segment
-    unsigned long long n;              // pixels
+    unsigned long long n;              // pixels (of this GPU's slice of the image)
+    unsigned long long gn;             // pixels over all GPUs sharing the image (= n when one GPU holds it all)
+    unsigned long long gslot0;         // members held by lower-ranked GPUs: the node-wide slot of this GPU's first member
     int buf;                           // ping-pong buffer holding the segment
     int slot;                          // histogram slot in the current round (-1: not being split)
     int child0;                        // id of first child record (children are consecutive)
@@ -58,7 +60,7 @@ struct NodeDev {
 __device__ __forceinline__ void node_reset_outputs(NodeDev &d) {
     for (int i = 0; i < kSlots; i++) { d.minkey[i] = ~0ULL; d.maxkey[i] = 0ULL; }
     for (int i = 0; i < kSlots; i++) for (int q = 0; q < 7; q++) { d.acc[i][q][0] = 0; d.acc[i][q][1] = 0; }
-    d.degenerate = 0; d.split = -1;
+    d.degenerate = 0; d.split = -1; d.gslot0 = 0;
 }
 __device__ __forceinline__ void node_minmax(const NodeDev &d, double &mn, double &mx) {
     unsigned long long a = ~0ULL, b = 0ULL;
@@ -99,7 +101,8 @@ void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int n
                 const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s);
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
-                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s);
+                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s,
+                      bool invariant = false);
 void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s);
 void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
                       NodeDev *d_nodes, hipStream_t s);

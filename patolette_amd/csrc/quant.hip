@@ -137,13 +137,14 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
         const double sc = 1 / (mx - mn);
         const BinK klin = nd.klin, kquad = nd.kquad;
         const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
+        const unsigned long long gslot0 = nd.gslot0;
         if (threadIdx.x == 0) nd.degenerate = degenerate ? 1 : 0;
 
         // two pixels per trip: both sets of loads are issued before either is consumed
         auto one = [&](const size_t p, const double x, const double y, const double z, const double w) {
             unsigned b;
             if (degenerate) {
-                b = (unsigned)((p - nd.begin) % kBuckets);
+                b = (unsigned)((p - nd.begin + gslot0) % kBuckets);   // the node-wide slot (sort.c:61-79)
             } else {
                 double ratio = (project(x, y, z, a0, a1, a2) - mn) * sc;
                 unsigned long long bq = (unsigned long long)((double)kBuckets * ratio);
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
             NodeDev &ch = nodes[nd.child0 + side];
             ch.begin = side == 0 ? nd.begin : nd.begin + nL;
             ch.n = side == 0 ? nL : nR;
+            ch.gn = ch.n;                                                   // the table holds the counts of every GPU sharing the image
             ch.buf = 1 - nd.buf;
             ch.slot = -1; ch.child0 = -1; ch.nchild = 0;
             ch.klin = nd.klin; ch.kquad = nd.kquad;
@@ -407,8 +409,12 @@ __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ round_nod
     if (threadIdx.x == 0) nd.cbegin[nch] = base;
 }
 
-template <bool W, bool COV>
-__global__ __launch_bounds__(256, 5) void k_scatter(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
+// INV (with COV): every product is split onto the exact grids before it is added, so the children's moments no longer depend
+// on where the tile boundaries fall -- the same bits for any tiling, hence for any way of dealing an image out over several
+// GPUs (patolette_amd_slice).  The default adds each thread's products in plain f64 first (a fixed order for a fixed tiling:
+// deterministic, but the roundings move with the tile boundaries) and splits the 14 partials once per run of tiles.
+template <bool W, bool COV, bool INV = false>
+__global__ __launch_bounds__(256, INV ? 4 : 5) void k_scatter(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
                                                     const unsigned char *__restrict__ lut, const unsigned long long *__restrict__ tileoff) {
     constexpr int R = kTileP / 256;
     __shared__ unsigned long long off[R][4][kMaxChildren];
@@ -421,10 +427,11 @@ __global__ __launch_bounds__(256, 5) void k_scatter(QuantBuffers qb, const Tile 
     // when the node changes or the block is done.
     const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int tfirst = (int)blockIdx.x * per, tlast = min(ntiles, tfirst + per);
-    double pl[7], pr[7];
+    constexpr int NP = INV ? 14 : 7;
+    double pl[NP], pr[NP];
     if constexpr (COV) {
 #pragma unroll
-        for (int i = 0; i < 7; i++) { pl[i] = 0; pr[i] = 0; }
+        for (int i = 0; i < NP; i++) { pl[i] = 0; pr[i] = 0; }
     }
     for (int ti = tfirst; ti < tlast; ti++) {
         const Tile t = tiles[ti];
@@ -473,10 +480,12 @@ __global__ __launch_bounds__(256, 5) void k_scatter(QuantBuffers qb, const Tile 
         // COV (binary splits only): the children's centred moments are accumulated while their pixels pass through
         // registers -- pca.c:62-101 / cluster.c:111-152 about the child means k_cut already wrote
         double m0[2], m1[2], m2[2];
+        BinK kinv{0.0, 0.0};
         if constexpr (COV) {
             const NodeDev &c0 = nodes[nd.child0], &c1 = nodes[nd.child0 + 1];
             m0[0] = c0.mean[0]; m1[0] = c0.mean[1]; m2[0] = c0.mean[2];
             m0[1] = c1.mean[0]; m1[1] = c1.mean[1]; m2[1] = c1.mean[2];
+            if constexpr (INV) kinv = nd.kquad;
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -495,8 +504,18 @@ __global__ __launch_bounds__(256, 5) void k_scatter(QuantBuffers qb, const Tile 
                     const double ex = x - (right ? m0[1] : m0[0]), ey = y - (right ? m1[1] : m1[0]), ez = z - (right ? m2[1] : m2[0]);
                     const double wx = w * ex, wy = w * ey, wz = w * ez;
                     const double q[7] = {wx * ex, wy * ex, wz * ex, wy * ey, wz * ey, wz * ez, ((ex * ex + ey * ey) + ez * ez) * w};
+                    if constexpr (INV) {
 #pragma unroll
-                    for (int i = 0; i < 7; i++) { pl[i] = __builtin_fma(q[i], lf, pl[i]); pr[i] = __builtin_fma(q[i], rf, pr[i]); }
+                        for (int i = 0; i < 7; i++) {
+                            double v0, v1;
+                            bin_split(q[i], kinv, v0, v1);
+                            pl[2 * i] = __builtin_fma(v0, lf, pl[2 * i]); pl[2 * i + 1] = __builtin_fma(v1, lf, pl[2 * i + 1]);
+                            pr[2 * i] = __builtin_fma(v0, rf, pr[2 * i]); pr[2 * i + 1] = __builtin_fma(v1, rf, pr[2 * i + 1]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 7; i++) { pl[i] = __builtin_fma(q[i], lf, pl[i]); pr[i] = __builtin_fma(q[i], rf, pr[i]); }
+                    }
                 }
             }
         }
@@ -505,11 +524,16 @@ __global__ __launch_bounds__(256, 5) void k_scatter(QuantBuffers qb, const Tile 
             if (flush) {
                 const BinK kq = nd.kquad;
                 double a[28];
+                if constexpr (INV) {
 #pragma unroll
-                for (int i = 0; i < 7; i++) {
-                    bin_split(pl[i], kq, a[2 * i], a[2 * i + 1]);
-                    bin_split(pr[i], kq, a[14 + 2 * i], a[14 + 2 * i + 1]);
-                    pl[i] = 0; pr[i] = 0;
+                    for (int i = 0; i < 14; i++) { a[i] = pl[i]; a[14 + i] = pr[i]; pl[i] = 0; pr[i] = 0; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 7; i++) {
+                        bin_split(pl[i], kq, a[2 * i], a[2 * i + 1]);
+                        bin_split(pr[i], kq, a[14 + 2 * i], a[14 + 2 * i + 1]);
+                        pl[i] = 0; pr[i] = 0;
+                    }
                 }
                 block_sum<28>(a, sm);
                 if (threadIdx.x == 0) {
@@ -720,15 +744,19 @@ void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int n
 
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
-                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s) {
-    if (!nptiles) return;
-    { KTIME("k_count", s, 2.0 * px); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt); }
+                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s, bool invariant) {
+    if (!nround) return;
+    if (nptiles) { KTIME("k_count", s, 2.0 * px); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt); }
+    // (a GPU holding none of the round's pixels still needs the children's -- empty -- segments: k_scan runs regardless)
     { KTIME("k_scan", s, 12.0 * kMaxChildren * nptiles); hipLaunchKernelGGL(k_scan, nround, 1024, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff); }
-    {
+    if (nptiles) {
         KTIME(fuse_cov ? "k_scatter_cov" : "k_scatter", s, (qb.weighted ? 66.0 : 50.0) * px);
         if (fuse_cov) {
-            const int g = std::min(nptiles, 256 * 5);            // 5 resident blocks per CU, each loops over its run of tiles
-            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
+            const int g = std::min(nptiles, 256 * (invariant ? 4 : 5));   // resident blocks per CU, each loops over its run of tiles
+            if (invariant) {
+                if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
+                else hipLaunchKernelGGL((k_scatter<false, true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
+            } else if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
             else hipLaunchKernelGGL((k_scatter<false, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
         } else {
             if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);

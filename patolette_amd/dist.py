@@ -226,3 +226,86 @@ def quantize_batch_sharded(width, height, images, palette_size, dist=None, quant
                     m = g_map[r][j] if narrow_maps else g_map[r][j].astype(np.uintp)
                 out.append((True, np.asfortranarray(g_pal[r][j]), m, msg))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# ONE image over the GPUs of a group: every rank holds a contiguous slice of the pixels
+# --------------------------------------------------------------------------------------------
+_TORCH_DTYPES = {0: ("float64", "<f8", np.float64), 1: ("int64", "<i8", np.int64), 2: ("int32", "<i4", np.int32)}
+
+
+class _DevMem:
+    """A span of device memory the library lends to the collective, seen by torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def make_comm(dist):
+    """patolette_amd__Comm over a torch.distributed process group: the one collective `patolette_amd_slice` needs, an
+    in-place element-wise SUM.  backend "nccl" (= RCCL): on the library's device buffers, no copies; any other backend
+    (gloo): on the pinned host staging the library provides.  Keep the returned object alive during the call."""
+    import torch
+    from . import _native
+    on_host = dist.get_backend() != "nccl"
+    device = collective_device(dist)
+
+    def allreduce(_ctx, ptr, count, dtype):
+        try:
+            name, typestr, npdt = _TORCH_DTYPES[dtype]
+            if on_host:
+                a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(npdt))), shape=(count,))
+                t = torch.from_numpy(a)                      # shares the staging memory: reduced in place
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            else:
+                t = torch.as_tensor(_DevMem(ptr, count, typestr), device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize(device)               # the library reads the buffer from its own stream next
+            return 0
+        except Exception as ex:                              # never let an exception cross the C frame
+            import sys
+            print("patolette_amd.dist: all-reduce failed: %r" % (ex,), file=sys.stderr)
+            return 1
+
+    cb = _native.ALLREDUCE_SUM_FN(allreduce)
+    comm = _native.Comm(dist.get_rank(), dist.get_world_size(), cb, None, 1 if on_host else 0)
+    comm._keepalive = cb
+    return comm
+
+
+def quantize_image_sharded(total_pixels, slice_begin, slice_colors, palette_size, dist, weights=None, palette_only=False,
+                           color_space=2, kmeans_niter=32, kmeans_max_samples=512 ** 2, verbose=False):
+    """One image dealt out over the ranks of `dist`: this rank passes pixels
+    [slice_begin, slice_begin + len(slice_colors)) of an image of `total_pixels` pixels -- `shard(total_pixels, rank, world)`
+    gives the usual split -- as (n, 3) float64 sRGB, optionally its slice of explicit weights.  Returns
+    (success, palette (K,3) F-ordered, slice_map (n,) uintp | None, message): the palette is the same on every rank and
+    bit-identical to `patolette_amd.quantize(..., dither=False, tile_size=0)` of the whole image on one GPU after
+    `patolette_amd_set_invariant_sums(1)`; slice_map is this rank's part of that image's index map (they stay where they are:
+    gather them with `gather_to_root` if one rank needs the whole map).  Dithering and derived saliency weights are
+    whole-image stages and not available per slice.  Import torch before patolette_amd in such a process."""
+    from . import _native
+    colors = np.asarray(slice_colors)
+    if colors.ndim != 2 or colors.shape[1] != 3:
+        raise ValueError("slice_colors must be (n, 3)")
+    n = colors.shape[0]
+    data = np.asfortranarray(colors, dtype=np.float64)       # planar x | y | z, as patolette() takes it
+    w = None
+    if weights is not None:
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
+        if w.size != n:
+            raise ValueError("weights must hold one value per pixel of the slice")
+    opts = _native.QuantizationOptions(False, bool(palette_only), int(color_space), int(kmeans_niter), int(kmeans_max_samples),
+                                       bool(verbose))
+    comm = make_comm(dist)
+    palette = np.zeros((palette_size, 3), dtype=np.float64, order="F")
+    pmap = None if palette_only else np.zeros(n, dtype=np.uintp)
+    code = C.c_int(0)
+    L = _native.lib()
+    L.patolette_amd_slice(int(total_pixels), int(slice_begin), n, data.ctypes.data_as(_native.dp) if n else None,
+                          w.ctypes.data_as(_native.dp) if w is not None else None, int(palette_size), C.byref(opts), C.byref(comm),
+                          palette.ctypes.data_as(_native.dp), pmap.ctypes.data_as(_native.zp) if pmap is not None and n else None,
+                          C.byref(code))
+    message = L.get_patolette_exit_code_info_message(code.value).decode("UTF-8")
+    if code.value != 0:
+        return (False, None, None, message)
+    return (True, palette, pmap, message)

@@ -1,7 +1,8 @@
-"""Within-image sharding over several GPUs: the exchange protocol, as a host-side prototype.
+"""Within-image sharding over several GPUs: the exchange protocol in numpy.
 
-NOT wired into the HIP path (no multi-GPU lease exists to measure it; DESIGN.md section 6 has the full design).  What this
-module pins down -- and tests/test_dist.py runs on two gloo ranks -- is the property that makes the sharding EXACT:
+The HIP path implements this protocol as `patolette_amd_slice` (pipeline.hip; Python: `patolette_amd.dist.quantize_image_sharded`;
+`-m gpu` tests: tests/test_gpu_slice.py).  This module is its host-side model: it needs no GPU, so tests/test_dist.py can pin down
+-- on two gloo ranks and on arbitrary dealings of the pixels -- the property that makes the sharding EXACT:
 
 Every per-node reduction of the split loop (projection extrema, per-bucket moments, children's centred moments) is either an
 integer, an ordered-key minimum / maximum, or a sum of two-part "binned" addends that lie on fixed grids (devutil.h

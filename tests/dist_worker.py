@@ -53,6 +53,22 @@ def main():
     cut1, _, red1 = psplit.split_node_sharded(c, wts, axis, bink, lambda a, op: a)
     split_ok = cut == cut1 and np.array_equal(red["parts"].view(np.uint64), red1["parts"].view(np.uint64)) and \
         np.array_equal(red["count"], red1["count"]) and np.array_equal(red["size"], red1["size"])
+    # the collective patolette_amd_slice borrows (patolette_amd.dist.make_comm), called through its C function pointer on
+    # host staging as the library does with a gloo group: SUM of f64 / i64 / i32, and the one-row-per-rank table that
+    # carries minima, maxima and exclusive prefixes
+    import ctypes as C
+    comm = pdist.make_comm(dist)
+    comm_ok = comm.rank == rank and comm.size == world and comm.host_buffers == 1
+    for dtype, npdt in ((0, np.float64), (1, np.int64), (2, np.int32)):
+        a = (np.arange(7) + 10 * rank).astype(npdt)
+        rc = comm.allreduce_sum(None, a.ctypes.data_as(C.c_void_p), a.size, dtype)
+        comm_ok = comm_ok and rc == 0 and np.array_equal(a, sum((np.arange(7) + 10 * r) for r in range(world)).astype(npdt))
+    table = np.zeros((world, 3), dtype=np.uint64)
+    table[rank] = [np.uint64(0xFFFFFFFFFFFFFF00 + rank), np.uint64(5 + rank), np.uint64(100 * (rank + 1))]
+    rc = comm.allreduce_sum(None, table.ctypes.data_as(C.c_void_p), table.size, 1)
+    comm_ok = comm_ok and rc == 0 and int(table[:, 0].min()) == 0xFFFFFFFFFFFFFF00 and int(table[:, 1].max()) == 5 + world - 1 and \
+        int(table[:rank, 2].sum()) == sum(100 * (r + 1) for r in range(rank))
+    split_ok = split_ok and comm_ok
     flag = torch.tensor([1.0 if split_ok else 0.0], dtype=torch.float64)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     split_ok = float(flag.item()) == 1.0

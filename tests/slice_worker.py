@@ -1,0 +1,111 @@
+"""Worker of tests/test_gpu_slice.py: ONE image dealt out over the ranks of a process group (patolette_amd_slice).
+
+Every rank quantises its contiguous slice of the pixels; the per-node reductions cross the group through the one
+collective the library borrows (an in-place SUM: gloo on pinned host staging, or nccl = RCCL on the device buffers).
+Each rank then quantises the WHOLE image alone (tiling-invariant sums switched on) and demands the same bits:
+the same palette, and its slice of the same index map.  With gloo, several ranks may share one GPU (the test box has one).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (before patolette_amd: both link a HIP runtime)
+import torch.distributed as dist  # noqa: E402
+
+
+def noise(rng, n):
+    return rng.random((n, 3))
+
+
+def smooth(w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    r = 0.5 + 0.5 * np.sin(x / 37.0) * np.cos(y / 53.0)
+    g = (x + y) / float(w + h)
+    b = 0.5 + 0.5 * np.cos((x - y) / 71.0)
+    return np.stack([r, g, b], axis=-1).reshape(-1, 3)
+
+
+def cases(rng):
+    out = []
+    # (name, colors, weights, K, kwargs, split fractions or None = even)
+    out.append(("ictcp noise 1024^2 K256 kmeans32", noise(rng, 1024 * 1024), None, 256, dict(color_space=2, kmeans_niter=32), None))
+    n = 700 * 500
+    out.append(("cieluv weighted 700x500 K64 kmeans4, uneven", smooth(700, 500) * 0.9 + 0.1 * noise(rng, n),
+                0.25 + 4.0 * rng.random(n), 64, dict(color_space=1, kmeans_niter=4), 0.1))
+    out.append(("srgb 64x64 K16 no kmeans, a 3-pixel slice", noise(rng, 4096), None, 16, dict(color_space=0, kmeans_niter=0), 1.0 - 3.0 / 4096))
+    two = np.where((np.arange(300 * 200) % 7 < 3)[:, None], np.array([[0.2, 0.4, 0.6]]), np.array([[0.9, 0.1, 0.3]]))
+    out.append(("two colours (degenerate nodes) K8", two, None, 8, dict(color_space=2, kmeans_niter=2), 0.37))
+    out.append(("constant image K4", np.full((5000, 3), 0.25), None, 4, dict(color_space=2, kmeans_niter=2), 0.5))
+    out.append(("200x200 K16 kmeans without subsampling", smooth(200, 200), None, 16, dict(color_space=2, kmeans_niter=8), 0.45))
+    out.append(("weighted ictcp 512x512 K200, large weights", noise(rng, 512 * 512), 1.0 + np.floor(50 * rng.random(512 * 512)), 200,
+                dict(color_space=2, kmeans_niter=3), 0.6))
+    out.append(("palette only 300x300 K32", smooth(300, 300), None, 32, dict(color_space=1, kmeans_niter=2, palette_only=True), None))
+    out.append(("K = pixels (KMeans starts from the first K vectors)", noise(rng, 40), None, 40, dict(color_space=0, kmeans_niter=2), 0.5))
+    out.append(("more colours requested than pixels", noise(rng, 30), None, 100, dict(color_space=2, kmeans_niter=2), 0.4))
+    return out
+
+
+def main():
+    out_path, backend = sys.argv[1], sys.argv[2]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(1, ndev)                 # gloo: ranks may share a GPU
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend=backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import patolette_amd as p
+    from patolette_amd import _native
+    from patolette_amd import dist as pdist
+    L = _native.lib()
+    assert L.patolette_amd_set_device(dev) == 0
+    rng = np.random.default_rng(20260927)            # the same image on every rank
+    notes, ok = [], True
+    for name, colors, weights, K, kw, frac in cases(rng):
+        n = colors.shape[0]
+        if frac is None or world != 2:
+            bounds = [pdist.shard(n, r, world) for r in range(world)]
+        else:
+            n0 = max(1, min(n - 1, int(round(n * frac))))
+            bounds = [(0, n0), (n0, n - n0)]
+        b, c = bounds[rank]
+        res = pdist.quantize_image_sharded(n, b, colors[b:b + c], K, dist, weights=None if weights is None else weights[b:b + c], **kw)
+        # the whole image on this GPU alone, product by product on the exact grids
+        L.patolette_amd_set_invariant_sums(1)
+        one = p.quantize(n, 1, colors, K, dither=False, tile_size=0, weights=weights, **kw)
+        L.patolette_amd_set_invariant_sums(0)
+        fast = p.quantize(n, 1, colors, K, dither=False, tile_size=0, weights=weights, **kw)
+        same = res[0] and one[0] and np.array_equal(res[1], one[1])
+        if not kw.get("palette_only"):
+            same = same and np.array_equal(res[2], one[2][b:b + c])
+        else:
+            same = same and res[2] is None
+        rows = int((one[1][:, 0] != -1).sum()) if one[0] else -1
+        fast_same = fast[0] and np.array_equal(fast[1], one[1])
+        notes.append("%s: %s (rows %d, slice %d+%d; default sums %s the invariant ones)"
+                     % (name, "same" if same else "DIFFERS", rows, b, c, "equal" if fast_same else "differ from"))
+        ok = ok and same
+    # dithering is a whole-image chain: refused per slice, on every rank alike (no collective is entered)
+    comm = pdist.make_comm(dist)
+    opts = _native.QuantizationOptions(True, False, 2, 0, 512 ** 2, False)
+    import ctypes as C
+    px = np.asfortranarray(rng.random((64, 3)))
+    pal = np.zeros((4, 3), order="F")
+    mp = np.zeros(64, dtype=np.uintp)
+    code = C.c_int(0)
+    L.patolette_amd_slice(64 * world, 64 * rank, 64, px.ctypes.data_as(_native.dp), None, 4, C.byref(opts), C.byref(comm),
+                          pal.ctypes.data_as(_native.dp), mp.ctypes.data_as(_native.zp), C.byref(code))
+    notes.append("dither per slice -> exit code %d" % code.value)
+    ok = ok and code.value == -1
+    with open("%s.%d" % (out_path, rank), "w") as f:
+        f.write(("OK\n" if ok else "MISMATCH\n") + "\n".join(notes) + "\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

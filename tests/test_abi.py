@@ -84,3 +84,32 @@ def test_batch_entry_rejects_malformed_weights(native):
     from patolette_amd import dist as pdist
     with pytest.raises(ValueError):
         pdist.quantize_batch_sharded(4, 3, imgs, 2, weights=[np.ones(12), np.ones(11)], quantize_fn=lambda *a, **k: None)
+
+
+def test_slice_entry_validation_needs_no_gpu(native):
+    """patolette_amd_slice rejects malformed calls before touching a device or the caller's collective."""
+    import numpy as np
+    from patolette_amd import _native
+    calls = []
+    cb = _native.ALLREDUCE_SUM_FN(lambda ctx, buf, count, dtype: calls.append(1) or 0)
+    comm = _native.Comm(0, 2, cb, None, 1)
+    opts = _native.QuantizationOptions(False, False, 2, 0, 512 ** 2, False)
+    px = np.zeros(3 * 10)
+    pal = np.zeros(3 * 4)
+    mp = np.zeros(10, dtype=np.uintp)
+
+    def call(total, begin, count, K, comm_ref, data=px, pmap=mp):
+        code = C.c_int(99)
+        native.lib().patolette_amd_slice(total, begin, count, data.ctypes.data_as(_native.dp) if data is not None else None, None, K,
+                                   C.byref(opts), comm_ref, pal.ctypes.data_as(_native.dp),
+                                   pmap.ctypes.data_as(_native.zp) if pmap is not None else None, C.byref(code))
+        return code.value
+    assert call(0, 0, 10, 4, C.byref(comm)) == -2                     # no pixels
+    assert call(20, 0, 10, 0, C.byref(comm)) == -3                    # no colours
+    assert call(20, 0, 10, 4, None) == -1                             # no group
+    assert call(20, 15, 10, 4, C.byref(comm)) == -1                   # slice beyond the image
+    assert call(20, 0, 0, 4, C.byref(comm)) == -1                     # empty slice
+    assert call(20, 0, 10, 4, C.byref(comm), pmap=None) == -1         # a map is wanted but there is nowhere to put it
+    bad = _native.Comm(2, 2, cb, None, 1)
+    assert call(20, 0, 10, 4, C.byref(bad)) == -1                     # rank outside the group
+    assert not calls
