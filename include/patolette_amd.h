@@ -172,6 +172,12 @@ typedef struct patolette_amd__Comm {
 void patolette_amd_slice(size_t total_pixels, size_t slice_begin, size_t slice_pixels, const double *slice_data,
                          const double *slice_weights, size_t palette_size, const patolette__QuantizationOptions *options,
                          const patolette_amd__Comm *comm, double *palette, size_t *slice_map, int *exit_code);
+/* the same with the slice (and its weights) resident in HBM and the slice's index map left there (elements of
+ * map_elem_bytes: 1 when palette_size <= 256, else 4), as patolette_amd_device() */
+void patolette_amd_slice_device(size_t total_pixels, size_t slice_begin, size_t slice_pixels, const double *d_slice_data,
+                                const double *d_slice_weights, size_t palette_size, const patolette__QuantizationOptions *options,
+                                const patolette_amd__Comm *comm, double *palette, void *d_slice_map, int map_elem_bytes,
+                                int *exit_code);
 /* 1: the children's moments of every split are summed product by product on the exact grids (tiling-invariant, what the
  * sliced path always does; 190 instead of 157 us per 4096^2 level in the partition kernel, +7 % on the whole step); 0 (default): per-thread partial sums first.  Applies to
  * the calling thread's later calls.  Returns the previous setting. */

@@ -1299,6 +1299,34 @@ static const char *kMessages[8] = {                                        // pa
         return ret_fail;                                                     \
     }
 
+static int slice_args_ok(size_t total_pixels, size_t slice_begin, size_t slice_pixels, const void *slice_data,
+                         const patolette__QuantizationOptions *options, const patolette_amd__Comm *comm, const void *slice_map) {
+    return comm && comm->allreduce_sum && comm->size >= 1 && comm->rank >= 0 && comm->rank < comm->size && slice_pixels > 0 &&
+           slice_begin <= total_pixels && slice_pixels <= total_pixels - slice_begin && slice_data &&
+           (options->palette_only || slice_map);
+}
+// runs `body` on the calling thread's engine with the slice description attached
+template <typename F>
+static void slice_entry(size_t total_pixels, size_t slice_begin, const patolette_amd__Comm *comm, int *exit_code, F body) {
+    Shard sh;
+    sh.total = total_pixels; sh.begin = slice_begin; sh.comm = *comm;
+    Engine *Ep = nullptr;
+    try {
+        Engine &E = engine();
+        Ep = &E;
+        E.init();
+        E.shard = &sh;
+        body(E);
+        E.shard = nullptr;
+        *exit_code = 0;
+    } catch (const std::exception &ex) {
+        if (Ep) Ep->shard = nullptr;
+        engine().last_error = ex.what();
+        fprintf(stderr, "patolette: %s\n", ex.what());
+        *exit_code = -1;
+    }
+}
+
 extern "C" {
 
 void patolette(size_t width, size_t height, const double *data, const double *weights, size_t palette_size,
@@ -1362,29 +1390,25 @@ void patolette_amd_slice(size_t total_pixels, size_t slice_begin, size_t slice_p
                          const patolette_amd__Comm *comm, double *palette, size_t *slice_map, int *exit_code) {
     *exit_code = validate(total_pixels, 1, palette_size);
     if (*exit_code != 0) return;
-    if (!comm || !comm->allreduce_sum || comm->size < 1 || comm->rank < 0 || comm->rank >= comm->size || slice_pixels == 0 ||
-        slice_begin > total_pixels || slice_pixels > total_pixels - slice_begin || !slice_data ||
-        (!options->palette_only && !slice_map)) {
-        *exit_code = -1;
-        return;
-    }
-    Shard sh;
-    sh.total = total_pixels; sh.begin = slice_begin; sh.comm = *comm;
-    Engine *Ep = nullptr;
-    try {
-        Engine &E = engine();
-        Ep = &E;
-        E.init();
-        E.shard = &sh;
+    if (!slice_args_ok(total_pixels, slice_begin, slice_pixels, slice_data, options, comm, slice_map)) { *exit_code = -1; return; }
+    slice_entry(total_pixels, slice_begin, comm, exit_code, [&](Engine &E) {
         run_host(E, slice_pixels, 1, slice_data, slice_weights, 0.0, palette_size, options, palette, slice_map);
-        E.shard = nullptr;
-        *exit_code = 0;
-    } catch (const std::exception &ex) {
-        if (Ep) Ep->shard = nullptr;
-        engine().last_error = ex.what();
-        fprintf(stderr, "patolette: %s\n", ex.what());
-        *exit_code = -1;
-    }
+    });
+}
+
+void patolette_amd_slice_device(size_t total_pixels, size_t slice_begin, size_t slice_pixels, const double *d_slice_data,
+                                const double *d_slice_weights, size_t palette_size, const patolette__QuantizationOptions *options,
+                                const patolette_amd__Comm *comm, double *palette, void *d_slice_map, int map_elem_bytes,
+                                int *exit_code) {
+    *exit_code = validate(total_pixels, 1, palette_size);
+    if (*exit_code != 0) return;
+    if (!slice_args_ok(total_pixels, slice_begin, slice_pixels, d_slice_data, options, comm, d_slice_map)) { *exit_code = -1; return; }
+    slice_entry(total_pixels, slice_begin, comm, exit_code, [&](Engine &E) {
+        std::vector<double> pal(3 * palette_size);
+        run_device(E, slice_pixels, 1, Pixels{d_slice_data, nullptr, 3}, d_slice_weights, palette_size, options, pal.data(), d_slice_map,
+                   map_elem_bytes);
+        std::memcpy(palette, pal.data(), 3 * palette_size * sizeof(double));
+    });
 }
 
 int patolette_amd_set_invariant_sums(int on) {
