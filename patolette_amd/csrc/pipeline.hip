@@ -387,6 +387,11 @@ struct HNode {
     double sw = 0, mean[3] = {0, 0, 0}, cov6[6] = {0, 0, 0, 0, 0, 0}, dist = 0;
     int left = -1, right = -1;
     bool split_done = false, nosplit = false;
+    // filled when the moments arrive (leaf_bound): the principal axis (dsyev semantics) and an upper bound of the benefit
+    // of ANY split of the node
+    int axis_state = 0;                      // 0 not solved yet, 1 axis valid, -1 the solver failed (-> nosplit when evaluated)
+    double axis[3] = {0, 0, 0};
+    double ub = 0;
 };
 
 static void build_tiles(const std::vector<int> &round, const std::vector<HNode> &hn, int tile, std::vector<Tile> &out,
@@ -484,9 +489,38 @@ static void absorb_moments(HNode &h, const NodeOut &d) {
 
 // principal axis from the node's covariance sums (pca.c:62-101 divides by sum(w), then dsyev)
 static bool node_axis(const HNode &h, double axis[3]) {
+    if (h.axis_state != 0) {
+        for (int j = 0; j < 3; j++) axis[j] = h.axis[j];
+        return h.axis_state > 0;
+    }
     double c6[6];
     for (int q = 0; q < 6; q++) c6[q] = h.cov6[q] / h.sw;
     return hm::principal_axis(c6, axis);
+}
+
+// Solve the node's 3x3 once, when its moments arrive: the axis its split evaluation will use, and an upper bound of the
+// benefit of splitting it.  The benefit (local.c:256-274: distortion minus the children's) is the between-group scatter
+// sum_g sw_g |mu_g - mu|^2 of the two children; the mean difference has ONE direction u, and the scatter between groups
+// along u cannot exceed the node's total scatter along u, u' S u <= lambda_max(S) = sw * lambda_max(cov).  That holds for
+// any two-way partition, so it bounds the benefit of the cut the reference will choose -- about three times tighter than
+// the distortion (the trace of S) for a roundish cluster.  The margins cover the roundings of the computed sums (~1e-15
+// relative to the distortion) with six orders to spare.
+static constexpr bool kUseEigenBound = true;
+static bool g_lq_eigen_bound = !(getenv("PAMD_LQ_EIGEN_BOUND") && atoi(getenv("PAMD_LQ_EIGEN_BOUND")) == 0);
+static void leaf_bound(HNode &h) {
+    h.ub = h.dist;
+    h.axis_state = 0;
+    if (h.gn <= 1 || !(h.sw > 0)) { h.ub = 0; return; }          // never split (local.c:262-264)
+    double c6[6];
+    for (int q = 0; q < 6; q++) c6[q] = h.cov6[q] / h.sw;
+    double a[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+    double w[3];
+    if (hm::eigen_sym3(a, w) != 0) { h.axis_state = -1; return; }
+    h.axis[0] = a[6]; h.axis[1] = a[7]; h.axis[2] = a[8]; h.axis_state = 1;
+    if (kUseEigenBound && g_lq_eigen_bound) {
+        const double b = w[2] * h.sw * (1.0 + 1e-9) + 1e-9 * h.dist;
+        if (b == b && b < h.ub) h.ub = b;                          // NaN / larger: keep the distortion
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -649,6 +683,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     for (size_t i = 0; i < base_ids.size(); i++) {
         absorb_moments(hn[base_ids[i]], got[i]);
         if (sh) { hn[base_ids[i]].begin = got[i].begin; hn[base_ids[i]].n = got[i].n; }
+        leaf_bound(hn[base_ids[i]]);
     }
     E.stats.n_base_clusters = (size_t)kbase;
     if (verbose) printf("patolette ======== Base cluster count: %zu\n", (size_t)kbase);     // patolette.c:227-229
@@ -677,7 +712,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 if (known(h)) {
                     double b = benefit(h);
                     if (best < 0 || b > bv) { bv = b; best = (int)j; }
-                } else if (h.dist > max_unknown) max_unknown = h.dist;
+                } else if (h.ub > max_unknown) max_unknown = h.ub;
             }
             // first maximum among ALL entries = first maximum among the known ones iff every unknown
             // benefit (<= that node's distortion) is strictly below it
@@ -717,7 +752,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 for (int id : leaves) {
                     HNode &h = hn[id];
                     if (known(h)) continue;                     // n <= 1 / nosplit: never split
-                    if (h.dist >= thr) round.push_back(id); else keep.push_back(id);
+                    if (h.ub >= thr) round.push_back(id); else keep.push_back(id);
                 }
                 leaves.swap(keep);
             }
@@ -800,6 +835,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 c.begin = d.begin; c.n = d.n; c.gn = d.gn; c.buf = d.buf; c.sw = d.sw;
                 for (int j = 0; j < 3; j++) c.mean[j] = d.mean[j];
                 absorb_moments(c, d);
+                leaf_bound(c);
             }
             for (int id : todo) { hn[id].split_done = true; E.stats.split_evals++; E.stats.split_px += hn[id].n; }
             for (int id : cids) leaves.push_back(id);
