@@ -39,6 +39,8 @@ CONFIGS = {
     "c3sal": (4096, 4096, 256, 2, 32, 512 ** 2, False, "saliency", "configs[2] + saliency weights (tile_size 512) from an 8-bit image resident in HBM"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+EVENT_SAMPLE = 4                      # the roofline kernel carries HIP events on every 4th launch inside the timed region (4 and the
+                                      # 9 launches per image are coprime: every split level is sampled over the steps)
 
 
 class Runner:
@@ -299,7 +301,7 @@ def main():
         _native.profile(False)
     barrier()
     if not args.no_profile:
-        _native.profile(True, only=dom_name)
+        _native.profile(True, only=dom_name, sample=EVENT_SAMPLE)
     gathered, works = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -442,7 +444,8 @@ def main():
                                            "262 144 mt19937 draws + 1 MB upload, ~2 ms) is built in the first warm-up step and reused; a pool of <= 3 "
                                            "distinct images rotates through the steps",
                    "kernel_events_in_timed_region": ("none" if args.no_profile else
-                                                     ("dominant kernel only (%s); per-kernel table from one extra untimed step" % dom_name
+                                                     ("dominant kernel only (%s), every %d-th launch (two event records cost ~12 us per launch); "
+                                                      "per-kernel table from one extra untimed step" % (dom_name, EVENT_SAMPLE)
                                                       if dom_name else "all kernels")),
                    "final_gather": ("RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region" if dist is not None else "none (1 GPU)")},
         "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "throughput_concurrent": conc,

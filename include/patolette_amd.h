@@ -246,6 +246,8 @@ void patolette_amd_profile_enable(int on);   /* also resets the accumulated numb
 /* restrict the timing to the kernel of this name (NULL or "" = every kernel): two event records per launch
  * cost ~7 us, so a throughput measurement times only the kernel it reports the roofline of */
 void patolette_amd_profile_only(const char *kernel_name);
+/* with a kernel selected by patolette_amd_profile_only: put events on every `period`-th of its launches only (1 = all) */
+void patolette_amd_profile_sample(int period);
 /* number of distinct kernels seen; entry i: name (<= 63 chars), accumulated ms, launch count and the
  * ALGORITHMIC HBM bytes of those launches (per-unit figures in DESIGN.md) */
 int  patolette_amd_profile_count(void);

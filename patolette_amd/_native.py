@@ -99,6 +99,7 @@ SYMBOLS = {
     "patolette_amd_last_map_palette": (C.c_size_t, [dp, C.c_size_t]),
     "patolette_amd_profile_enable": (None, [C.c_int]),
     "patolette_amd_profile_only": (None, [C.c_char_p]),
+    "patolette_amd_profile_sample": (None, [C.c_int]),
     "patolette_amd_profile_count": (C.c_int, []),
     "patolette_amd_profile_get": (C.c_int, [C.c_int, C.c_char_p, dp, zp, dp]),
 }
@@ -133,9 +134,11 @@ def last_stats():
     return s.as_dict()
 
 
-def profile(enable=True, only=None):
-    """Per-kernel HIP-event timing on/off (resets the counters); `only` restricts it to one kernel name."""
+def profile(enable=True, only=None, sample=1):
+    """Per-kernel HIP-event timing on/off (resets the counters); `only` restricts it to one kernel name, `sample` to every
+    sample-th launch of that kernel."""
     lib().patolette_amd_profile_only(only.encode() if only else None)
+    lib().patolette_amd_profile_sample(int(sample) if only else 1)
     lib().patolette_amd_profile_enable(1 if enable else 0)
 
 

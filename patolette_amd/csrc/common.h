@@ -40,6 +40,8 @@ struct KernelTimer {
     struct Rec { hipEvent_t a, b; int id; double bytes; };
     bool enabled = false;
     std::string only;                // when not empty: time just the kernel of this name
+    unsigned sample_period = 1;      // ... and of that kernel every sample_period-th launch (two event records cost ~12 us)
+    unsigned long long only_seen = 0;
     std::vector<std::string> names;
     std::vector<double> total_ms, total_bytes;
     std::vector<size_t> launches;
@@ -59,6 +61,7 @@ struct ScopedKernel {
     hipStream_t s;
     ScopedKernel(const char *name, hipStream_t stream, double bytes)
         : on(ktimer().enabled && (ktimer().only.empty() || ktimer().only == name)), s(stream) {
+        if (on && !ktimer().only.empty() && ktimer().sample_period > 1) on = (ktimer().only_seen++ % ktimer().sample_period) == 0;
         if (on) ktimer().begin(ktimer().id_of(name), s, bytes);
     }
     ~ScopedKernel() { if (on) ktimer().end(s); }

@@ -121,8 +121,9 @@ __global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup 
         d.begin = in.begin; d.n = in.n; d.gn = in.gn; d.buf = in.buf; d.slot = in.slot; d.child0 = in.child0; d.nchild = in.nchild;
         for (int j = 0; j < 3; j++) { d.axis[j] = in.axis[j]; d.mean[j] = in.mean[j]; }
         d.sw = in.sw; d.klin = in.klin; d.kquad = in.kquad;
-        node_reset_outputs(d);
     }
+    for (size_t i = tid; i < (size_t)a.nr * kNodeResetElems; i += stride)        // outputs of the round's nodes, one store per thread
+        node_reset_element(table[a.ids[i / kNodeResetElems]], (int)(i % kNodeResetElems));
     for (size_t t = tid; t < (size_t)a.ntA; t += stride) {
         const int r = node_of_tile(a.tA0, a.nr, (int)t);
         const unsigned long long o = (unsigned long long)((int)t - a.tA0[r]) * kTileA, n = a.recs[r].n;
@@ -809,7 +810,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             RoundSetup rs{(const NodeIn *)(E.packet.p + o_recs), d_ids, (const int *)(E.packet.p + o_tA0), d_tP0, nr, ntA, ntP,
                           E.tilesA.p, E.tilesP.p, E.hist.p, lqs * nr, E.hsize.p, E.hcount.p, (size_t)nr * kBuckets};
             {
-                const size_t work = std::max<size_t>(std::max<size_t>(ntP, lqs * nr / 4), 256);
+                const size_t work = std::max<size_t>(std::max<size_t>(std::max<size_t>(ntP, lqs * nr / 4), (size_t)nr * kNodeResetElems), 256);
                 hipLaunchKernelGGL(k_round_setup, (unsigned)std::min<size_t>((work + 255) / 256, 2048), 256, 0, s, E.nodes.p, rs);
                 HIP_CHECK(hipGetLastError());
             }
@@ -1829,7 +1830,8 @@ void patolette_amd_profile_enable(int on) {
     t.reset();
     t.enabled = on != 0;
 }
-void patolette_amd_profile_only(const char *kernel_name) { ktimer().only = kernel_name ? kernel_name : ""; }
+void patolette_amd_profile_only(const char *kernel_name) { ktimer().only = kernel_name ? kernel_name : ""; ktimer().only_seen = 0; }
+void patolette_amd_profile_sample(int period) { ktimer().sample_period = period > 1 ? (unsigned)period : 1u; }
 int patolette_amd_profile_count(void) { return (int)ktimer().names.size(); }
 int patolette_amd_profile_get(int i, char *name64, double *total_ms, size_t *launches, double *total_bytes) {
     KernelTimer &t = ktimer();

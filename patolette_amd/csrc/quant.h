@@ -62,6 +62,14 @@ __device__ __forceinline__ void node_reset_outputs(NodeDev &d) {
     for (int i = 0; i < kSlots; i++) for (int q = 0; q < 7; q++) { d.acc[i][q][0] = 0; d.acc[i][q][1] = 0; }
     d.degenerate = 0; d.split = -1; d.gslot0 = 0;
 }
+// the same, spread over threads: element e of kNodeResetElems (one store each, the scalars ride with element 0)
+constexpr int kNodeResetElems = kSlots * 14 + 2 * kSlots;
+__device__ __forceinline__ void node_reset_element(NodeDev &d, int e) {
+    if (e < kSlots * 14) (&d.acc[0][0][0])[e] = 0.0;
+    else if (e < kSlots * 15) d.minkey[e - kSlots * 14] = ~0ULL;
+    else d.maxkey[e - kSlots * 15] = 0ULL;
+    if (e == 0) { d.degenerate = 0; d.split = -1; d.gslot0 = 0; }
+}
 __device__ __forceinline__ void node_minmax(const NodeDev &d, double &mn, double &mx) {
     unsigned long long a = ~0ULL, b = 0ULL;
     for (int i = 0; i < kSlots; i++) { a = d.minkey[i] < a ? d.minkey[i] : a; b = d.maxkey[i] > b ? d.maxkey[i] : b; }

@@ -45,6 +45,34 @@ __device__ __forceinline__ T block_scan_incl(T v, T *smem) {          // smem: >
     if (wid > 0) v += smem[wid - 1];
     return v;
 }
+// the same for N values per thread at once: three barriers in all instead of three per value.  smem: >= N * 16 entries
+template <typename T, int N>
+__device__ __forceinline__ void block_scan_incl_vec(T (&v)[N], T *smem) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < N; i++) { T t = __shfl_up(v[i], o, 64); if (lane >= o) v[i] += t; }
+    }
+    __syncthreads();
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < N; i++) smem[i * 16 + wid] = v[i];
+    }
+    __syncthreads();
+    if (wid == 0 && lane < 16 * N) {                       // lanes [16 i, 16 i + 16) scan value i's wave totals
+        const int i = lane >> 4, e = lane & 15;
+        T s = (i < N && e < nw) ? smem[i * 16 + e] : T(0);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { T t = __shfl_up(s, o, 16); if (e >= o) s += t; }
+        if (i < N && e < nw) smem[i * 16 + e] = s;
+    }
+    __syncthreads();
+    if (wid > 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += smem[i * 16 + wid - 1];
+    }
+}
 
 // --------------------------------------------------------------------------------------------
 // root mean: sum of each plane (GQ's PCA is UNWEIGHTED, global.c:407 -> pca.c:151-168)
@@ -214,8 +242,8 @@ template <bool W>
 __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restrict__ round_nodes, const double *__restrict__ hist,
                                              const unsigned long long *__restrict__ hsize, const unsigned int *__restrict__ hcount,
                                              unsigned char *lut) {
-    __shared__ double sd[16];
-    __shared__ unsigned long long su[16];
+    __shared__ double sd[4 * 16];
+    __shared__ unsigned long long su[2 * 16];
     __shared__ double best_v[8];
     __shared__ int best_i[8];
     __shared__ double tot[8];
@@ -227,14 +255,19 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
     const double *gh = hist + slot * (size_t)(kNQ_LQ * 2 * kBuckets);
     constexpr int NQ = W ? 4 : 3;
     double p[NQ][2];
+    {
+        // all prefixes of the table in three block scans (the parts are exact in any order): first parts, second parts, sizes
+        double v0[NQ], v1[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        p[q][0] = block_scan_incl<double>(gh[(q * 2 + 0) * kBuckets + b], sd);
-        p[q][1] = block_scan_incl<double>(gh[(q * 2 + 1) * kBuckets + b], sd);
+        for (int q = 0; q < NQ; q++) { v0[q] = gh[(q * 2 + 0) * kBuckets + b]; v1[q] = gh[(q * 2 + 1) * kBuckets + b]; }
+        block_scan_incl_vec<double, NQ>(v0, sd);
+        block_scan_incl_vec<double, NQ>(v1, sd);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { p[q][0] = v0[q]; p[q][1] = v1[q]; }
     }
-    unsigned long long cnt = block_scan_incl<unsigned long long>((unsigned long long)hcount[slot * kBuckets + b], su);
-    unsigned long long siz = cnt;
-    if constexpr (W) siz = block_scan_incl<unsigned long long>(hsize[slot * kBuckets + b], su);
+    unsigned long long cs[2] = {(unsigned long long)hcount[slot * kBuckets + b], W ? hsize[slot * kBuckets + b] : 0ULL};
+    block_scan_incl_vec<unsigned long long, 2>(cs, su);
+    const unsigned long long cnt = cs[0], siz = W ? cs[1] : cs[0];
     __syncthreads();
     if (b == kBuckets - 1) {
 #pragma unroll
@@ -285,7 +318,6 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
             ch.buf = 1 - nd.buf;
             ch.slot = -1; ch.child0 = -1; ch.nchild = 0;
             ch.klin = nd.klin; ch.kquad = nd.kquad;
-            node_reset_outputs(ch);
             double s0[NQ], s1[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
@@ -299,6 +331,9 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
             ch.axis[0] = ch.axis[1] = ch.axis[2] = 0;
         }
     }
+    // the children's accumulators and outputs start empty: one store per thread instead of ~500 from the thread above
+    for (int i = b; i < 2 * kNodeResetElems; i += kBuckets)
+        node_reset_element(nodes[nd.child0 + i / kNodeResetElems], i % kNodeResetElems);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -379,6 +414,38 @@ __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ round_nod
     const int a = t0 + (int)threadIdx.x * C, b = min(t1, a + C);
     unsigned long long base = nd.begin;
     const int nch = nd.nchild;
+    if (nch == 2) {
+        // a binary split (every round of the local quantiser): both children in one pass -- their counts sit side by side
+        // in a tile's record (one 8-byte load), one vector scan, one 16-byte store of the two offsets per tile
+        __shared__ unsigned long long sv[2 * 16];
+        __shared__ unsigned long long tot2[2];
+        unsigned long long sum[2] = {0, 0};
+        for (int g = a; g < b; g += 8) {
+            uint2 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = g + q < b ? *reinterpret_cast<const uint2 *>(tilecnt + (size_t)(g + q) * kMaxChildren) : make_uint2(0u, 0u);
+#pragma unroll
+            for (int q = 0; q < 8; q++) { sum[0] += v[q].x; sum[1] += v[q].y; }
+        }
+        unsigned long long inc[2] = {sum[0], sum[1]};
+        block_scan_incl_vec<unsigned long long, 2>(inc, sv);
+        if (threadIdx.x == blockDim.x - 1) { tot2[0] = inc[0]; tot2[1] = inc[1]; }
+        __syncthreads();
+        const unsigned long long base1 = base + tot2[0];
+        unsigned long long run0 = base + inc[0] - sum[0], run1 = base1 + inc[1] - sum[1];
+        for (int g = a; g < b; g += 8) {
+            uint2 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = g + q < b ? *reinterpret_cast<const uint2 *>(tilecnt + (size_t)(g + q) * kMaxChildren) : make_uint2(0u, 0u);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (g + q < b) *reinterpret_cast<ulonglong2 *>(tileoff + (size_t)(g + q) * kMaxChildren) = make_ulonglong2(run0, run1);
+                run0 += v[q].x; run1 += v[q].y;
+            }
+        }
+        if (threadIdx.x == 0) { nd.cbegin[0] = base; nd.cbegin[1] = base1; nd.cbegin[2] = base1 + tot2[1]; }
+        return;
+    }
     for (int k = 0; k < nch; k++) {
         unsigned long long sum = 0;
         for (int g = a; g < b; g += 8) {
@@ -658,20 +725,30 @@ static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntile
 // downwards with a strict '<', starting from t = n-1), so the cut table is bit-identical.  All kmax steps are run;
 // the host applies the bias termination test (global.c:99-187) to the downloaded table step by step.
 // --------------------------------------------------------------------------------------------
-__global__ void k_gq_prefix(const double *__restrict__ hist, const unsigned int *__restrict__ hcount, GqDpDev *g) {
-    // thread q builds one inclusive prefix sequentially (cells.c:114-136): 0 = w0, 1..3 = w1[r], 4 = w2
-    const int q = threadIdx.x;
-    if (q == 0) { unsigned long long a = 0; g->w0[0] = 0; for (int b = 0; b < kBuckets; b++) { a += hcount[b]; g->w0[b + 1] = a; } }
-    else if (q <= 4) {
-        const int hq = q - 1;                                  // GQ quantities 0..2 = sum c, 3 = sum |c|^2
-        double *dst = q <= 3 ? g->w1[q - 1] : g->w2;
-        double a = 0; dst[0] = 0;
-        for (int b = 0; b < kBuckets; b++) {
-            const double h = hist[(size_t)(hq * 2 + 0) * kBuckets + b] + hist[(size_t)(hq * 2 + 1) * kBuckets + b];
-            // the host mirrors: table[b+1] = H(q,b), then table[i] += table[i-1]
-            a = h + a;
-            dst[b + 1] = a;
-        }
+__global__ __launch_bounds__(512) void k_gq_prefix(const double *__restrict__ hist, const unsigned int *__restrict__ hcount, GqDpDev *g) {
+    // Five inclusive prefixes, each built sequentially as cells.c:114-136 does (0 = w0, 1..3 = w1[r], 4 = w2).  The 512-step
+    // chains run out of LDS: the table is staged with coalesced loads first (a chain that loads from global memory inside
+    // its loop pays a memory round trip per step: 35 us instead of 6).
+    __shared__ double sh[4][kBuckets + 1];
+    __shared__ unsigned long long sc[kBuckets + 1];
+    const int b = threadIdx.x;                               // one bucket per thread
+#pragma unroll
+    for (int hq = 0; hq < 4; hq++)                           // GQ quantities 0..2 = sum c, 3 = sum |c|^2
+        sh[hq][b + 1] = hist[(size_t)(hq * 2 + 0) * kBuckets + b] + hist[(size_t)(hq * 2 + 1) * kBuckets + b];
+    sc[b + 1] = hcount[b];
+    if (b < 4) sh[b][0] = 0;
+    if (b == 4) sc[0] = 0;
+    __syncthreads();
+    if (b == 0) { unsigned long long a = 0; for (int i = 1; i <= kBuckets; i++) { a += sc[i]; sc[i] = a; } }
+    else if ((b & 63) == 0 && b <= 256) {                    // four more wavefronts, one chain each
+        double *t = sh[(b >> 6) - 1];
+        double a = 0;
+        for (int i = 1; i <= kBuckets; i++) { a = t[i] + a; t[i] = a; }    // the host mirrors: table[i] += table[i-1]
+    }
+    __syncthreads();
+    for (int i = b; i <= kBuckets; i += 512) {
+        g->w0[i] = sc[i];
+        g->w1[0][i] = sh[0][i]; g->w1[1][i] = sh[1][i]; g->w1[2][i] = sh[2][i]; g->w2[i] = sh[3][i];
     }
 }
 __device__ __forceinline__ double gq_distortion(const GqDpDev *g, int a, int b) {      // cells.c:141-182
@@ -718,7 +795,7 @@ __global__ __launch_bounds__(256) void k_gq_dp(GqDpDev *g, int k) {
 
 void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, GqDpDev *d_g, hipStream_t s) {
     KTIME("k_gq_dp", s, (double)kmax * 513 * 513 * 8);
-    hipLaunchKernelGGL(k_gq_prefix, 1, 64, 0, s, d_hist, d_hcount, d_g);
+    hipLaunchKernelGGL(k_gq_prefix, 1, 512, 0, s, d_hist, d_hcount, d_g);
     hipLaunchKernelGGL(k_gq_init, 3, 256, 0, s, d_g);
     for (int k = 2; k <= kmax; k++) hipLaunchKernelGGL(k_gq_dp, kBuckets + 1, 256, 0, s, d_g, k);
     HIP_CHECK(hipGetLastError());
