@@ -858,7 +858,12 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
 }
 
 // second half of the sort: samples -> (x,y,z,w) records grouped by centroid, sample order kept
-template <bool W, typename AT>
+// PAIR (k <= 256, long chunks): a record is 16 bytes, HBM is written in 32-byte sectors.  Records of one centroid leave a
+// wavefront one at a time, four trips apart on average, so both halves of almost every sector used to reach memory separately
+// (WRITE_SIZE 1.86x the algorithmic bytes at 67 M samples).  Here a record bound for an EVEN slot waits in LDS (one place per
+// centroid and wavefront) until its odd neighbour turns up and the two are stored back to back by one lane; what is left over at
+// the end of the chunk -- at most one record per centroid -- goes out alone.  Same records in the same places.
+template <bool W, typename AT, bool PAIR = false>
 __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const AT *__restrict__ assign, size_t nx, int k, int nbits,
                                                     int chunk_len, int nchunks, const unsigned int *__restrict__ table,
                                                     const unsigned int *__restrict__ rowtot, float4 *sorted) {
@@ -867,6 +872,11 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const AT *__res
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     unsigned int *rowbase = lds_u;                                   // [k] exclusive prefix of rowtot
     unsigned int *cnt = lds_u + k + (size_t)wid * k;
+    // PAIR: behind the 5 k counters, per wavefront: first slot of every centroid in this chunk [k], waiting records [k], and
+    // this trip's records by lane [64]
+    unsigned int *first = lds_u + 5 * k + (size_t)wid * k;
+    float4 *pend = reinterpret_cast<float4 *>(lds_u + 9 * k) + (size_t)wid * (k + 64);
+    float4 *stage = pend + k;
     {   // block-wide exclusive scan of rowtot[0..k): each thread owns a contiguous run
         const int per = (k + 255) / 256;
         const int j0 = threadIdx.x * per, j1 = (j0 + per < k) ? j0 + per : k;
@@ -888,9 +898,14 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const AT *__res
     // next free slot of every centroid for THIS chunk: row base + what earlier chunks hold (one strided read of the
     // count table per chunk instead of one random read per sample)
     // (only when a chunk holds more samples than there are centroids; short chunks read their few entries directly)
-    const bool prebase = chunk_len >= 2 * k;
-    if (prebase) { for (int j = lane; j < k; j += 64) cnt[j] = rowbase[j] + table[(size_t)j * nchunks + chunk]; }
-    else { for (int j = lane; j < k; j += 64) cnt[j] = 0u; }
+    const bool prebase = PAIR || chunk_len >= 2 * k;
+    if (prebase) {
+        for (int j = lane; j < k; j += 64) {
+            const unsigned c0 = rowbase[j] + table[(size_t)j * nchunks + chunk];
+            cnt[j] = c0;
+            if constexpr (PAIR) first[j] = c0;
+        }
+    } else { for (int j = lane; j < k; j += 64) cnt[j] = 0u; }
     const size_t lo = (size_t)chunk * chunk_len;
     const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
     const unsigned long long lt = (1ULL << lane) - 1ULL;
@@ -917,11 +932,46 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const AT *__res
             unsigned run = 0;
             if (v[u]) run = cnt[a[u]];                                 // read before the leader bumps it
             const unsigned r = (unsigned)__popcll(m & lt);
-            if (v[u]) {
+            if constexpr (PAIR) {
+                const unsigned dst = run + r;
+                if (v[u]) stage[lane] = rec[u];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // the even neighbour of an odd slot: the previous lane of this centroid in this trip, else the record waiting in
+                // LDS, else (the chunk's first record of the centroid sits on an odd slot) nobody.  Read first, then a barrier:
+                // a later lane of the same centroid may put the NEXT waiting record into the same place below
+                float4 other = make_float4(0.f, 0.f, 0.f, 0.f);
+                bool have = false;
+                if (v[u] && (dst & 1u)) {
+                    if (r > 0) { other = stage[63 - __clzll(m & lt)]; have = true; }
+                    else if (dst > first[a[u]]) { other = pend[a[u]]; have = true; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (v[u]) {
+                    if (dst & 1u) {
+                        if (have) sorted[dst - 1] = other;
+                        sorted[dst] = rec[u];
+                    } else if (((m >> lane) >> 1) == 0ULL) {
+                        pend[a[u]] = rec[u];                           // last of its centroid in this trip: wait for the neighbour
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else if (v[u]) {
                 const size_t dst = prebase ? (size_t)run + r : (size_t)rowbase[a[u]] + table[(size_t)a[u] * nchunks + chunk] + run + r;
                 sorted[dst] = rec[u];
             }
             if (v[u] && r == 0) cnt[a[u]] = run + (unsigned)__popcll(m);   // leader
+        }
+    }
+    if constexpr (PAIR) {
+        // records still waiting: the centroid's last slot in this chunk is even
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < k; j += 64) {
+            const unsigned c1 = cnt[j];
+            if (c1 > first[j] && (c1 & 1u)) sorted[c1 - 1] = pend[j];
         }
     }
 }
@@ -1517,6 +1567,7 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     const int cblocks = (nchunks + 3) / 4;
     const size_t lds_cnt = (size_t)8 * k * sizeof(unsigned int);     // k float4 + 4 x k counters
     const size_t lds_sct = (size_t)5 * k * sizeof(unsigned int);
+    const size_t lds_sct_pair = (size_t)9 * k * sizeof(unsigned int) + (size_t)4 * (k + 64) * sizeof(float4);
     static PerDeviceOnce attr;
     if (attr.first()) {
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_count, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
@@ -1611,7 +1662,16 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         {
             KTIME("k_km_scatter", s, (weighted ? 36.0 : 32.0) * nx - (use_mid ? 3.0 : 0.0) * nx);
             const unsigned char *a8 = (const unsigned char *)w.assign.p;               // k_km_assign_mid leaves one byte per sample
-            if (use_mid) {
+            static const bool pair_on = !(getenv("PAMD_KM_PAIR") && atoi(getenv("PAMD_KM_PAIR")) == 0);
+            if (use_mid && pair_on && chunk_len >= 2 * k) {
+                static PerDeviceOnce attr3;
+                if (attr3.first()) {
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true, unsigned char, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 256 * 4 + 4 * (256 + 64) * 16));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false, unsigned char, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 256 * 4 + 4 * (256 + 64) * 16));
+                }
+                if (weighted) hipLaunchKernelGGL((k_km_scatter<true, unsigned char, true>), cblocks, 256, lds_sct_pair, s, ks, a8, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+                else hipLaunchKernelGGL((k_km_scatter<false, unsigned char, true>), cblocks, 256, lds_sct_pair, s, ks, a8, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+            } else if (use_mid) {
                 if (weighted) hipLaunchKernelGGL((k_km_scatter<true, unsigned char>), cblocks, 256, lds_sct, s, ks, a8, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
                 else hipLaunchKernelGGL((k_km_scatter<false, unsigned char>), cblocks, 256, lds_sct, s, ks, a8, nx, k, nbits, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
             } else {
