@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
 // centroid's sequential f32 chains from there, each wavefront gathering just its own coordinate.  Same sums in the same
 // order as k_km_update; two launches per iteration, nothing else moves.
 // --------------------------------------------------------------------------------------------
-constexpr int kKmDirectCap = 16384;                                    // listed members between two chain replays (64 KB of LDS)
+constexpr int kKmDirectCap = 4096;                                     // listed member records between two chain replays (64 KB of LDS)
 constexpr int kKmSortBlock = 1024;                                     // samples sorted together by one block of k_km_assign_sort
 
 // inclusive prefix sum over the 64 lanes through DPP row shifts and row broadcasts (a __shfl_up loop is six LDS round trips)
@@ -1428,10 +1428,11 @@ __device__ __forceinline__ int km_assign_one_pk(const float x0, const float x1, 
 }
 
 // Full scan + the block-local stable counting sort: sixteen wavefronts, wavefront w = the block's w-th run of 64 consecutive
-// samples.  sorted_idx[block][.] = sample numbers inside the block (u16) grouped by centroid, sample order kept inside a group;
+// samples.  sorted_rec[block][.] = the block's samples themselves (x, y, z, w) grouped by centroid, sample order kept inside a
+// group (16 KB per block, so the update reads a centroid's members of a block as one run instead of chasing sample numbers);
 // offs[block][j] = where centroid j's group starts (offs[block][256] = the number of samples of the block).
-__global__ __launch_bounds__(1024) void k_km_assign_sort(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k,
-                                                         unsigned short *__restrict__ sorted_idx, unsigned short *__restrict__ offs) {
+__global__ __launch_bounds__(1024) void k_km_assign_sort(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, const bool weighted,
+                                                         float4 *__restrict__ sorted_rec, unsigned short *__restrict__ offs) {
     __shared__ unsigned char cnt[16][256];                             // members of (step, centroid): 64 at most
     __shared__ unsigned short stepbase[16][256];                       // start of centroid j's group + its members in earlier steps
     __shared__ unsigned int wsum[16];
@@ -1443,7 +1444,9 @@ __global__ __launch_bounds__(1024) void k_km_assign_sort(KmSamples s, size_t nx,
     const size_t blk0 = (size_t)blockIdx.x * kKmSortBlock;
     const size_t i = blk0 + (size_t)threadIdx.x;
     const bool v = i < nx;
-    const int a = v ? km_assign_one_pk(s.x[i], s.y[i], s.z[i], t4, t8, k) : 0;
+    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v) { rec.x = s.x[i]; rec.y = s.y[i]; rec.z = s.z[i]; if (weighted) rec.w = s.w[i]; }
+    const int a = v ? km_assign_one_pk(rec.x, rec.y, rec.z, t4, t8, k) : 0;
     const unsigned long long m = match_mask(a, 8, __ballot(v));
     const unsigned rk = (unsigned)__popcll(m & ((1ULL << lane) - 1ULL)); // rank among the step's samples of the same centroid
     if (v && rk == 0u) cnt[step][a] = (unsigned char)__popcll(m);      // group leader
@@ -1465,15 +1468,15 @@ __global__ __launch_bounds__(1024) void k_km_assign_sort(KmSamples s, size_t nx,
         if (threadIdx.x == 255) ob[256] = (unsigned short)total;
     }
     __syncthreads();
-    if (v) sorted_idx[blk0 + (unsigned)stepbase[step][a] + rk] = (unsigned short)threadIdx.x;
+    if (v) sorted_rec[blk0 + (unsigned)stepbase[step][a] + rk] = rec;      // the sample itself: the update reads its members in runs
 }
 
 template <bool W>
-__global__ __launch_bounds__(256) void k_km_update_lists(KmSamples s, const unsigned short *__restrict__ sorted_idx, const unsigned short *__restrict__ offs,
+__global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restrict__ sorted_rec, const unsigned short *__restrict__ offs,
                                                         unsigned long long nx, int k, float *cent, float *hassign, float4 *c4,
                                                         unsigned int *ticket, DevMT *mt) {
     __shared__ float4 stage[4][2][64];
-    extern __shared__ unsigned int members[];                              // [kKmDirectCap] sample numbers, in sample order
+    extern __shared__ float4 members[];                                    // [kKmDirectCap] member records (x, y, z, w), in sample order
     __shared__ float res[4];
     __shared__ int s_last;
     __shared__ unsigned int wsum[16];
@@ -1483,10 +1486,11 @@ __global__ __launch_bounds__(256) void k_km_update_lists(KmSamples s, const unsi
     unsigned fill = 0;                                                    // block-uniform
     auto replay = [&]() {                                                 // the chains over members[0, fill), continuing `acc`
         const unsigned n = fill;
-        if (wid == 0) acc = km_chain_over<W, 0>([&](const size_t i) { return make_float4(s.x[members[i]], 0.f, 0.f, W ? s.w[members[i]] : 0.f); }, n, stage[0], lane, acc);
-        else if (wid == 1) acc = km_chain_over<W, 1>([&](const size_t i) { return make_float4(0.f, s.y[members[i]], 0.f, W ? s.w[members[i]] : 0.f); }, n, stage[1], lane, acc);
-        else if (wid == 2) acc = km_chain_over<W, 2>([&](const size_t i) { return make_float4(0.f, 0.f, s.z[members[i]], W ? s.w[members[i]] : 0.f); }, n, stage[2], lane, acc);
-        else if (W) acc = km_chain_over<W, 3>([&](const size_t i) { return make_float4(0.f, 0.f, 0.f, s.w[members[i]]); }, n, stage[3], lane, acc);
+        auto rec = [&](const size_t i) { return members[i]; };
+        if (wid == 0) acc = km_chain_over<W, 0>(rec, n, stage[0], lane, acc);
+        else if (wid == 1) acc = km_chain_over<W, 1>(rec, n, stage[1], lane, acc);
+        else if (wid == 2) acc = km_chain_over<W, 2>(rec, n, stage[2], lane, acc);
+        else if (W) acc = km_chain_over<W, 3>(rec, n, stage[3], lane, acc);
     };
     const unsigned long long nblocks = (nx + kKmSortBlock - 1) / kKmSortBlock;
     for (unsigned long long c0 = 0; c0 < nblocks; c0 += 256) {            // 256 blocks of samples at a time: one per thread
@@ -1499,8 +1503,14 @@ __global__ __launch_bounds__(256) void k_km_update_lists(KmSamples s, const unsi
         while (done < chunk_total) {                                      // block-uniform; one trip unless the list fills up
             const unsigned take = min((unsigned)kKmDirectCap - fill, chunk_total - done);
             const unsigned lo = max(excl, done), hi = min(excl + nb, done + take);
-            for (unsigned q = lo; q < hi; q++)
-                members[fill + q - done] = (unsigned)(b * kKmSortBlock) + (unsigned)sorted_idx[b * kKmSortBlock + o0 + (q - excl)];
+            const float4 *src = sorted_rec + b * kKmSortBlock + o0;      // this block of samples' members: one contiguous run
+            for (unsigned q = lo; q < hi; q += 4) {                       // four independent 16-byte loads per trip
+                float4 r4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) r4[u] = q + u < hi ? src[q + u - excl] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (q + u < hi) members[fill + q + u - done] = r4[u];
+            }
             fill += take; done += take;
             __syncthreads();
             if (fill == (unsigned)kKmDirectCap) { replay(); fill = 0; __syncthreads(); }
@@ -1602,8 +1612,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     if (use_direct) {
         static PerDeviceOnce attr4;
         if (attr4.first()) {
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 4));
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 4));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 16));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 16));
         }
     }
     static const bool mid_enabled = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
@@ -1613,18 +1623,17 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     const unsigned long long long_min = getenv("PAMD_KM_LONG_MIN") ? (unsigned long long)atoll(getenv("PAMD_KM_LONG_MIN")) : 8192ULL;
     for (int it = 0; it < niter; it++) {
         if (use_direct) {
-            unsigned short *sidx = (unsigned short *)w.assign.p;             // 2 of the 4 bytes per sample of the assignment buffer
             unsigned short *offs = (unsigned short *)w.table.p;              // 257 x blocks x 2 bytes
             const int sblocks = (int)ceil_div(nx, (size_t)kKmSortBlock);
             {
-                KTIME("k_km_assign", s, 14.0 * nx);
-                hipLaunchKernelGGL(k_km_assign_sort, sblocks, 1024, 0, s, ks, nx, w.c4.p, k, sidx, offs);
+                KTIME("k_km_assign", s, (weighted ? 32.0 : 28.0) * nx);
+                hipLaunchKernelGGL(k_km_assign_sort, sblocks, 1024, 0, s, ks, nx, w.c4.p, k, weighted, w.sorted.p, offs);
             }
             {
-                KTIME("k_km_update", s, (weighted ? 18.0 : 14.0) * nx);
-                if (weighted) hipLaunchKernelGGL(k_km_update_lists<true>, k, 256, kKmDirectCap * 4, s, ks, (const unsigned short *)sidx, (const unsigned short *)offs,
+                KTIME("k_km_update", s, 16.0 * nx);
+                if (weighted) hipLaunchKernelGGL(k_km_update_lists<true>, k, 256, kKmDirectCap * 16, s, (const float4 *)w.sorted.p, (const unsigned short *)offs,
                                                  (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
-                else hipLaunchKernelGGL(k_km_update_lists<false>, k, 256, kKmDirectCap * 4, s, ks, (const unsigned short *)sidx, (const unsigned short *)offs,
+                else hipLaunchKernelGGL(k_km_update_lists<false>, k, 256, kKmDirectCap * 16, s, (const float4 *)w.sorted.p, (const unsigned short *)offs,
                                         (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
             }
             continue;
