@@ -222,6 +222,7 @@ struct Engine {
     DevBuf<unsigned char> commbuf;
     PinBuf<unsigned char> h_comm;
     DevBuf<int> shard_ids;
+    PinBuf<float> h_cent;            // KMeans centroids on their way to / from the device
     DevBuf<double> src, wsrc, cvt, bufA, bufB, aux;
     DevBuf<unsigned short> bkt;
     DevBuf<NodeDev> nodes;
@@ -594,6 +595,13 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     HIP_CHECK(hipMemsetAsync(E.hist.p, 0, hs * sizeof(double), s));
     HIP_CHECK(hipMemsetAsync(E.hsize.p, 0, kBuckets * sizeof(unsigned long long), s));
     HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, kBuckets * sizeof(unsigned int), s));
+    // the root's partition tiles do not depend on the cut: built and uploaded now, behind the kernels instead of between them
+    build_tiles(round, hn, kTileP, tP, &tile0);
+    upload_tiles(E, tP, E.tilesP, E.h_tilesP);
+    E.h_round.reserve(kBuckets);                                // (also receives the bucket counts below: sized once, before any copy uses it)
+    upload_ints(E, round, E.round_nodes, E.h_round);
+    upload_ints(E, tile0, E.node_tile0, E.h_tile0);
+    E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
     launch_minmax(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
     if (sh) shard_exchange_keys(E, shard_upload_ids(E, {0}), 1);
     launch_hist(qroot, true, E.tilesA.p, (int)tA.size(), N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
@@ -669,13 +677,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         for (int id : base_ids) { ids.push_back(id); NodeIn c = make_nodedev(hn[id], bnd); c.klin = d.klin; c.kquad = d.kquad; recs.push_back(c); }
         put_nodes(E, ids, recs);
     }
-    HIP_CHECK(hipMemcpyAsync(E.lut.p, lut.data(), kBuckets, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    build_tiles(round, hn, kTileP, tP, &tile0);
-    upload_tiles(E, tP, E.tilesP, E.h_tilesP);
-    upload_ints(E, round, E.round_nodes, E.h_round);
-    upload_ints(E, tile0, E.node_tile0, E.h_tile0);
-    E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
+    E.h_bytes.reserve(kBuckets);                                // pinned: no synchronisation before the partition
+    std::memcpy(E.h_bytes.p, lut.data(), kBuckets);
+    HIP_CHECK(hipMemcpyAsync(E.lut.p, E.h_bytes.p, kBuckets, hipMemcpyHostToDevice, s));
     launch_partition(qroot, E.tilesP.p, (int)tP.size(), N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, false, s);
     if (sh) { hipLaunchKernelGGL(k_shard_children_local, 1, 64, 0, s, E.nodes.p, E.round_nodes.p, 1); HIP_CHECK(hipGetLastError()); }
     launch_cov_children(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
@@ -915,11 +919,13 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
             for (size_t i = 0; i < k; i++) for (int j = 0; j < 3; j++) cent[3 * i + j] = (float)first[(size_t)j * k + i];
         } else {
             kmeans_gather(E.cvt.p, N, weighted, dperm, nx, E.km, s);
-            HIP_CHECK(hipMemcpyAsync(E.km.cent.p, cent.data(), 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            E.h_cent.reserve(3 * k);                                               // pinned: no synchronisation before the iterations
+            std::memcpy(E.h_cent.p, cent.data(), 3 * k * sizeof(float));
+            HIP_CHECK(hipMemcpyAsync(E.km.cent.p, E.h_cent.p, 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
             kmeans_iterate(E.km, nx, (int)k, weighted, niter, s);
-            HIP_CHECK(hipMemcpyAsync(cent.data(), E.km.cent.p, 3 * k * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(E.h_cent.p, E.km.cent.p, 3 * k * sizeof(float), hipMemcpyDeviceToHost, s));
             E.sync();
+            std::memcpy(cent.data(), E.h_cent.p, 3 * k * sizeof(float));
             E.stats.kmeans_samples = nx;
         }
     }
