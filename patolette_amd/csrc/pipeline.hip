@@ -223,6 +223,9 @@ struct Engine {
     PinBuf<unsigned char> h_comm;
     DevBuf<int> shard_ids;
     PinBuf<float> h_cent;            // KMeans centroids on their way to / from the device
+    PinBuf<ConvertStats> h_cstats;
+    hipEvent_t ev_stats = nullptr;
+    size_t prep_N = 0, prep_planes = 0;   // gq_prepare() has staged the root's tiles and cleared the tables for an image of this size
     DevBuf<double> src, wsrc, cvt, bufA, bufB, aux;
     DevBuf<unsigned short> bkt;
     DevBuf<NodeDev> nodes;
@@ -267,7 +270,7 @@ struct Engine {
     }
     void sync() { HIP_CHECK(hipStreamSynchronize(stream)); if (ktimer().enabled) ktimer().collect(); }
     ~Engine() {                                  // buffers free themselves (DevBuf / PinBuf); only called while the runtime is alive
-        if (stream) { (void)hipSetDevice(device); (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (stream) { (void)hipSetDevice(device); (void)hipStreamSynchronize(stream); if (ev_stats) (void)hipEventDestroy(ev_stats); (void)hipStreamDestroy(stream); }
     }
 };
 
@@ -529,6 +532,34 @@ static void leaf_bound(HNode &h) {
 // GQ + LQ + PALETTE_create on the converted image in E.cvt (planar, stride N, optional w plane)
 // returns centres planar (len,3)
 // --------------------------------------------------------------------------------------------
+// Everything the global quantiser needs that depends on the image SIZE only: workspace, the root's two tilings, cleared bucket
+// tables.  run_device() enqueues it right behind the conversion kernel, so these small copies and fills run while the host waits
+// for the conversion's bounds instead of between the quantiser's kernels.
+static void gq_prepare(Engine &E, size_t N, bool weighted) {
+    hipStream_t s = E.stream;
+    const size_t planes = weighted ? 4 : 3;
+    E.bufA.reserve(planes * N); E.bufB.reserve(planes * N); E.bkt.reserve(N);
+    std::vector<HNode> hn(1);
+    hn[0].begin = 0; hn[0].n = N;
+    const std::vector<int> round = {0};
+    std::vector<Tile> tA, tP;
+    std::vector<int> tile0;
+    build_tiles(round, hn, kTileA, tA, nullptr);
+    upload_tiles(E, tA, E.tilesA, E.h_tilesA);
+    build_tiles(round, hn, kTileP, tP, &tile0);
+    upload_tiles(E, tP, E.tilesP, E.h_tilesP);
+    E.h_round.reserve(kBuckets);                                // (also receives the bucket counts later: sized once, before any copy uses it)
+    upload_ints(E, round, E.round_nodes, E.h_round);
+    upload_ints(E, tile0, E.node_tile0, E.h_tile0);
+    E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
+    const size_t hs = hist_slot_doubles();
+    E.hist.reserve(hs); E.hsize.reserve(kBuckets); E.hcount.reserve(kBuckets); E.lut.reserve(kBuckets);
+    HIP_CHECK(hipMemsetAsync(E.hist.p, 0, hs * sizeof(double), s));
+    HIP_CHECK(hipMemsetAsync(E.hsize.p, 0, kBuckets * sizeof(unsigned long long), s));
+    HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, kBuckets * sizeof(unsigned int), s));
+    E.prep_N = N; E.prep_planes = planes;
+}
+
 static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const Bounds &bnd,
                              std::vector<double> &centers, size_t &len, bool verbose = false) {
     hipStream_t s = E.stream;
@@ -536,7 +567,8 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     const Shard *sh = E.shard;                                  // the image is dealt out over a group of GPUs: N is this GPU's part
     const size_t Nt = sh ? sh->total : N;                       // pixels of the whole image
     const bool inv_sums = sh || E.invariant;
-    E.bufA.reserve(planes * N); E.bufB.reserve(planes * N); E.bkt.reserve(N);
+    if (E.prep_N != N || E.prep_planes != planes) gq_prepare(E, N, weighted);   // (the stage-level entry points come here unprepared)
+    E.prep_N = 0;
     E.nodes.reserve(4 * K + 64);
     std::vector<HNode> hn;
     hn.reserve(4 * K + 64);
@@ -567,15 +599,12 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     QuantBuffers qroot{{E.cvt.p, E.bufA.p}, E.bkt.p, N, weighted};
     QuantBuffers qlq{{E.bufB.p, E.bufA.p}, E.bkt.p, N, weighted};
     std::vector<int> round = {0};
-    std::vector<Tile> tA, tP;
-    std::vector<int> tile0;
-    build_tiles(round, hn, kTileA, tA, nullptr);
-    upload_tiles(E, tA, E.tilesA, E.h_tilesA);
+    const int ntA0 = (int)ceil_div(N, (size_t)kTileA), ntP0 = (int)ceil_div(N, (size_t)kTileP);   // the root's tilings (gq_prepare)
     {
         NodeIn d = make_nodedev(hn[0], bnd);
         put_nodes(E, {0}, {d});
     }
-    launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
+    launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, ntA0, N, E.nodes.p, s);
     std::vector<NodeOut> got;
     if (sh) shard_exchange_acc(E, shard_upload_ids(E, {0}), 1);
     get_nodes(E, {0}, got);
@@ -591,20 +620,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         put_nodes(E, {0}, {d});
     }
     const size_t hs = hist_slot_doubles();
-    E.hist.reserve(hs); E.hsize.reserve(kBuckets); E.hcount.reserve(kBuckets); E.lut.reserve(kBuckets);
-    HIP_CHECK(hipMemsetAsync(E.hist.p, 0, hs * sizeof(double), s));
-    HIP_CHECK(hipMemsetAsync(E.hsize.p, 0, kBuckets * sizeof(unsigned long long), s));
-    HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, kBuckets * sizeof(unsigned int), s));
-    // the root's partition tiles do not depend on the cut: built and uploaded now, behind the kernels instead of between them
-    build_tiles(round, hn, kTileP, tP, &tile0);
-    upload_tiles(E, tP, E.tilesP, E.h_tilesP);
-    E.h_round.reserve(kBuckets);                                // (also receives the bucket counts below: sized once, before any copy uses it)
-    upload_ints(E, round, E.round_nodes, E.h_round);
-    upload_ints(E, tile0, E.node_tile0, E.h_tile0);
-    E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
-    launch_minmax(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
+    launch_minmax(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s);
     if (sh) shard_exchange_keys(E, shard_upload_ids(E, {0}), 1);
-    launch_hist(qroot, true, E.tilesA.p, (int)tA.size(), N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+    launch_hist(qroot, true, E.tilesA.p, ntA0, N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
     if (sh) { comm_sum_dev(E, E.hist.p, hs, 0); comm_sum_dev(E, E.hcount.p, kBuckets, 2); }
     const int gq_kmax = (int)std::min<size_t>(K, kGqMaxK);
     E.gq.reserve(1); E.h_gq.reserve(1);
@@ -680,9 +698,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     E.h_bytes.reserve(kBuckets);                                // pinned: no synchronisation before the partition
     std::memcpy(E.h_bytes.p, lut.data(), kBuckets);
     HIP_CHECK(hipMemcpyAsync(E.lut.p, E.h_bytes.p, kBuckets, hipMemcpyHostToDevice, s));
-    launch_partition(qroot, E.tilesP.p, (int)tP.size(), N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, false, s);
+    launch_partition(qroot, E.tilesP.p, ntP0, N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, false, s);
     if (sh) { hipLaunchKernelGGL(k_shard_children_local, 1, 64, 0, s, E.nodes.p, E.round_nodes.p, 1); HIP_CHECK(hipGetLastError()); }
-    launch_cov_children(qroot, E.tilesA.p, (int)tA.size(), N, E.nodes.p, s);
+    launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s);
     if (sh) shard_exchange_acc(E, shard_upload_ids(E, base_ids), (int)base_ids.size());
     get_nodes(E, base_ids, got);
     for (size_t i = 0; i < base_ids.size(); i++) {
@@ -940,10 +958,17 @@ static void palette_rows(std::vector<double> &pal, size_t len, void (*f)(double[
     }
 }
 
-static Bounds read_bounds(Engine &E, bool weighted) {
-    ConvertStats cs;
-    HIP_CHECK(hipMemcpyAsync(&cs, E.cstats.p, sizeof cs, hipMemcpyDeviceToHost, E.stream));
-    E.sync();
+// between_copy_and_wait: work to enqueue behind the statistics' download while the host is still waiting for it
+static Bounds read_bounds(Engine &E, bool weighted, const std::function<void()> &between_copy_and_wait = nullptr) {
+    E.h_cstats.reserve(1);
+    HIP_CHECK(hipMemcpyAsync(E.h_cstats.p, E.cstats.p, sizeof(ConvertStats), hipMemcpyDeviceToHost, E.stream));
+    if (between_copy_and_wait) {                               // wait for the download alone, not for what is enqueued behind it
+        if (!E.ev_stats) HIP_CHECK(hipEventCreateWithFlags(&E.ev_stats, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(E.ev_stats, E.stream));
+        between_copy_and_wait();
+        HIP_CHECK(hipEventSynchronize(E.ev_stats));
+    } else E.sync();
+    const ConvertStats &cs = *E.h_cstats.p;
     Bounds b;
     b.cmax = 0; b.range = 0;
     unsigned long long kmin[3], kmax[3], kw = 0ULL, nonfinite = cs.nonfinite_f32 != 0u ? 1ULL : 0ULL;
@@ -1001,6 +1026,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     const bool weighted = d_weights != nullptr;
     const double t_start = now_ms();
     E.stats = patolette_amd__Stats{};
+    E.prep_N = 0;
     // S1: colour conversion into the working image (x|y|z|w planar), patolette.c:201-207
     double t0 = now_ms();
     E.cvt.reserve((weighted ? 4 : 3) * N);
@@ -1026,7 +1052,8 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
         HIP_CHECK(hipMemcpyAsync(E.cvt.p + 3 * N, d_weights, N * sizeof(double), hipMemcpyDeviceToDevice, s));
         launch_weight_stats(d_weights, N, E.cstats.p, s);
     }
-    Bounds bnd = read_bounds(E, weighted);
+    // the quantiser's size-only preparations go behind the statistics' download: they run while the host derives the bounds
+    Bounds bnd = read_bounds(E, weighted, [&] { gq_prepare(E, N, weighted); });
     bnd.have_sum = sumk.M0 != 0.0;
     E.stats.ms_convert = now_ms() - t0;
 
