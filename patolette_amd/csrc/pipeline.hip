@@ -726,16 +726,24 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     };
     if (count < K) {
         result.resize(K, -1);
+        // the frontier as two flat arrays (benefit if the node's split is known, else its bound): the greedy steps between two
+        // rounds scan them a few hundred times
+        std::vector<double> fval(K, 0.0);
+        std::vector<char> fkn(K, 0);
+        auto refresh = [&](const size_t j) {
+            const HNode &h = hn[result[j]];
+            fkn[j] = known(h) ? 1 : 0;
+            fval[j] = fkn[j] ? benefit(h) : h.ub;
+        };
+        for (size_t j = 0; j < count; j++) refresh(j);
         for (;;) {
             if (count >= K) break;
             // one greedy step, exact whenever every undecided node is provably not the arg-max
             int best = -1; double bv = 0; double max_unknown = -1;
             for (size_t j = 0; j < count; j++) {
-                const HNode &h = hn[result[j]];
-                if (known(h)) {
-                    double b = benefit(h);
-                    if (best < 0 || b > bv) { bv = b; best = (int)j; }
-                } else if (h.ub > max_unknown) max_unknown = h.ub;
+                if (fkn[j]) {
+                    if (best < 0 || fval[j] > bv) { bv = fval[j]; best = (int)j; }
+                } else if (fval[j] > max_unknown) max_unknown = fval[j];
             }
             // first maximum among ALL entries = first maximum among the known ones iff every unknown
             // benefit (<= that node's distortion) is strictly below it
@@ -745,6 +753,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 const int l = h.left, r = h.right;
                 result[count] = l;                              // local.c:375-376: palette ORDER
                 result[best] = r;
+                refresh(count); refresh((size_t)best);
                 count++;
                 if (verbose) { printf("patolette ======== Processed colors: %zu\r", count); fflush(stdout); }   // local.c:386-389
                 continue;
@@ -763,7 +772,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 // bounded by that distortion, and R better candidates outlast the remaining commits)
                 const size_t R = K - count;
                 std::vector<double> kb;
-                for (size_t j = 0; j < count; j++) if (known(hn[result[j]])) kb.push_back(benefit(hn[result[j]]));
+                for (size_t j = 0; j < count; j++) if (fkn[j]) kb.push_back(fval[j]);
                 if (kb.size() >= R && R > 0) {
                     std::nth_element(kb.begin(), kb.begin() + (R - 1), kb.end(), std::greater<double>());
                     thr = std::max(thr, kb[R - 1] * (1.0 - 1e-9));
@@ -799,6 +808,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 hn.push_back(HNode()); hn.push_back(HNode());
                 todo.push_back(id); ids.push_back(id); recs.push_back(d);
             }
+            for (size_t j = 0; j < count; j++) refresh(j);      // a failed eigen-solve above makes a node known (no split)
             if (todo.empty()) continue;
             const int nr = (int)todo.size();
             size_t rpx = 0;
@@ -862,6 +872,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             }
             for (int id : todo) { hn[id].split_done = true; E.stats.split_evals++; E.stats.split_px += hn[id].n; }
             for (int id : cids) leaves.push_back(id);
+            for (size_t j = 0; j < count; j++) refresh(j);      // the round's nodes are known now
             E.stats.lq_rounds++;
         }
         result.resize(count);
