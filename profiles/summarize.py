@@ -80,4 +80,22 @@ for f in ("bench_%s.json" % cfg, "bench_%s_traced.json" % cfg):
     p = os.path.join(src, f)
     if os.path.exists(p):
         open(os.path.join(root, "profiles", "%s_%s" % (outtag, f)), "w").write(open(p).read())
-print("written profiles/%s_%s_kernel_stats.txt, profiles/traffic_%s.json" % (tag, cfg, cfg))
+# the kept bench lines were produced BEFORE this traffic file existed (bench.py reads the file of the previous collection): bring
+# their roofline.traffic in line with the PMC passes of the same build
+traffic = json.load(open(os.path.join(root, "profiles", "traffic_%s.json" % cfg)))
+for suffix in ("", "_traced"):
+    bp = os.path.join(root, "profiles", "%s_bench_%s%s.json" % (outtag, cfg, suffix))
+    if not os.path.exists(bp):
+        continue
+    lines = open(bp).read().rstrip("\n").split("\n")
+    try:
+        d = json.loads(lines[-1])
+    except ValueError:
+        continue
+    dom = (d.get("roofline") or {}).get("kernel")
+    if dom in traffic.get("kernels", {}):
+        d["roofline"]["traffic"] = traffic["kernels"][dom]["hbm_bytes_per_launch"]
+        d["roofline"]["traffic_source"] = "profiles/traffic_%s.json (PMC passes of the same build, written after this line was produced)" % cfg
+        lines[-1] = json.dumps(d)
+        open(bp, "w").write("\n".join(lines) + "\n")
+print("written profiles/%s_%s_kernel_stats.txt, profiles/traffic_%s.json" % (outtag, cfg, cfg))
