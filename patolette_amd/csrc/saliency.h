@@ -21,6 +21,7 @@ struct SalDev {                      // device-resident scalars of one saliency 
 
 struct SalWork {
     DevBuf<float4> st;               // minimum-barrier state {img, D, U, L} per pixel, row-major
+    DevBuf<float4> skew;             // the same, skewed by one column per row in groups of 64 rows: what the raster scans work on
     DevBuf<float> tmp;
     DevBuf<double> lab, s;           // CIELAB planes, running saliency map
     DevBuf<SalDev> dev;

@@ -303,11 +303,27 @@ __global__ __launch_bounds__(256) void k_sal_pass_e(size_t n, double npx, double
 // State per pixel as one 16-byte record {img, D, U, L} (row-major): a visit reads and writes one record.
 constexpr size_t kMbdPad = 256;      // records of padding on both sides of the state (lanes read past row ends)
 
+// The scans work on a SKEWED copy of the state: record (r, c) lives at [group g][diagonal d][l], g = (r + 63) / 64,
+// l = (r + 63) % 64, d = c + l + 128, so the 64 records a strip touches in one step -- rows 64 s + l, columns t - l: one
+// anti-diagonal -- are 1 KB of consecutive memory instead of 64 different cache lines (the address unit, not HBM, bounded the
+// row-major scan: 110 ns per step).  The backward scan's strips are aligned to the bottom of the image, so one of its steps
+// covers at most two such runs.  Cells of the skewed array that correspond to no pixel are only ever read, their values
+// discarded.
+struct SkewGeom {
+    int dn;                          // diagonals per group: cols + 320 (columns -128 .. cols + 128 of every row of the group)
+    __host__ __device__ size_t idx(int r, int c) const {
+        const int rr = r + 63;
+        return ((size_t)(rr >> 6) * (size_t)dn + (size_t)(c + (rr & 63) + 128)) * 64 + (size_t)(rr & 63);
+    }
+};
+
 struct MbdArgs {
-    float4 *st;                      // first record of the image; kMbdPad readable records before and after it
+    float4 *st;                      // the skewed state (SkewGeom)
+    SkewGeom geo;
     int rows, cols;
     unsigned int *progress;
     unsigned int *stalled;           // set when a strip gave up waiting for the one above it
+    int hs;                          // chunks per flag handshake with the neighbouring strips
 };
 
 __device__ __forceinline__ float wave_shr1(float from_above, float v) {
@@ -345,16 +361,19 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
     const int sx = strip * 64 + lane;
     const bool rowok = sx < R;
     const int rl = min(63, R - 1 - strip * 64);             // last valid lane of this strip
-    // record (sx, -lane): the record of step t is p[DIR * t].  Lanes past the last row shadow the last row (their
-    // results are discarded); columns outside [0, Cn) fall into neighbouring rows or the padding of the buffer and
-    // are only ever read.
-    float4 *p = a.st + (base + (long)min(sx, R - 1) * rs - (long)DIR * lane);
-    const float4 *above = a.st + (base + (long)(strip * 64 - 1) * rs);   // (first row of the strip - 1, 0)
+    // The lane's row and its column at step 0 (one column behind per lane); the record of step t is p[SD * t]: one diagonal
+    // further, 64 records on.  Lanes past the last row and columns outside [0, Cn) land in cells that belong to no pixel (or to
+    // the frame) and are only ever read.
+    constexpr long SD = (long)DIR * 64;
+    (void)rs; (void)base;
+    const int row_l = DIR > 0 ? 1 + sx : a.rows - 2 - sx, col0_l = DIR > 0 ? 1 - lane : a.cols - 2 + lane;
+    float4 *p = a.st + a.geo.idx(row_l, col0_l);
+    const float4 *above = a.st + a.geo.idx(DIR > 0 ? 64 * strip : a.rows - 1 - 64 * strip, DIR > 0 ? 1 : a.cols - 2);   // the row before the strip's first
     const int T = Cn + rl;                                   // steps until the last valid lane is done
 
     float4 ring[kChunk];
     float outU = 0.f, outL = 0.f;                            // this lane's latest result = "previous column" of the next visit
-    { const float4 f = p[DIR * (lane - 1)]; outU = f.x; outL = f.x; }   // frame column: U = L = img, never modified
+    { const float4 f = p[SD * (lane - 1)]; outU = f.x; outL = f.x; }    // frame column: U = L = img, never modified
     float bu = 0.f, bl = 0.f;                                // row above the strip: lane j holds column chunk0 + j
     const int last = rowok ? lane + Cn - 1 : -1;             // this lane visits at steps lane .. last
 
@@ -383,11 +402,15 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
             if (active && !keep) *q = make_float4(ix, m, nu, nl);
         }
     };
-    auto chunk_begin = [&](int t0) -> bool {                             // true: gave up waiting
+    // The handshake with the strip above (a spin on its progress flag and an acquire fence) and with the strip below (a release
+    // fence and a flag store) can be made once per a.hs chunks; the strip then lags its neighbour by two windows of hs * kChunk
+    // steps instead of three chunks.  Measured at 4096 x 4096: a handshake costs ~0.7 us, a step ~90 ns, so hs = 2 trades
+    // 2 100 more steps for half the handshakes and comes out even (1.37 ms per pass either way); hs = 3, 4 are slower.
+    auto chunk_begin = [&](int t0, bool handshake) -> bool {             // true: gave up waiting
         // steps t0 .. t0+kChunk-1 of lane 0 consume scan columns t0 .. t0+kChunk-1 of the row above the strip
         if (t0 >= Cn) return false;
-        if (strip > 0) {
-            const unsigned int need = (unsigned int)min(Cn, t0 + kChunk);
+        if (strip > 0 && handshake) {
+            const unsigned int need = (unsigned int)min(Cn, t0 + a.hs * kChunk);
             // bounded: the strip above always makes progress when all strips are resident (a few hundred single-wave
             // blocks), but a spin must never be able to hang the device -- past ~2 s the pass gives up and reports it
             unsigned spins = 0;
@@ -399,7 +422,7 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
         }
         const int col = t0 + lane;
         if (lane < kChunk && col < Cn) {
-            const float4 f = above[DIR * col];
+            const float4 f = above[SD * col];
             bu = f.z; bl = f.w;
         }
         return false;
@@ -415,30 +438,30 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
     // Blocks of kChunk steps.  The records of the next block are requested during the first half of the current one,
     // so they have landed when the flag handshake at the block boundary drains the memory counter.
 #pragma unroll
-    for (int j = 0; j < kChunk; j++) ring[j] = p[DIR * j];
-    for (int t0 = 0; t0 < T; t0 += kChunk) {
-        if (chunk_begin(t0)) {                                           // let the strips below give up quickly too
+    for (int j = 0; j < kChunk; j++) ring[j] = p[SD * j];
+    for (int t0 = 0, ci = 0; t0 < T; t0 += kChunk, ci = ci + 1 == a.hs ? 0 : ci + 1) {
+        if (chunk_begin(t0, ci == 0)) {                                           // let the strips below give up quickly too
             if (lane == 0) __hip_atomic_store(&a.progress[strip], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         float4 next[kChunk];
-        float4 *q = p + DIR * t0;
+        float4 *q = p + SD * t0;
         // every valid lane visits at every step of the block: after the ramp-up (t0 >= 63) and before lane 0 runs out of columns
         const bool steady = t0 >= 64 && t0 + kChunk <= Cn;
         if (steady) {
 #pragma unroll
             for (int j = 0; j < kChunk; j++) {
-                if (j < kChunk / 2) { next[2 * j] = q[DIR * (kChunk + 2 * j)]; next[2 * j + 1] = q[DIR * (kChunk + 2 * j + 1)]; }
-                visit(t0 + j, q + DIR * j, ring[j], true);
+                if (j < kChunk / 2) { next[2 * j] = q[SD * (kChunk + 2 * j)]; next[2 * j + 1] = q[SD * (kChunk + 2 * j + 1)]; }
+                visit(t0 + j, q + SD * j, ring[j], true);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < kChunk; j++) {
-                if (j < kChunk / 2) { next[2 * j] = q[DIR * (kChunk + 2 * j)]; next[2 * j + 1] = q[DIR * (kChunk + 2 * j + 1)]; }
-                visit(t0 + j, q + DIR * j, ring[j], false);
+                if (j < kChunk / 2) { next[2 * j] = q[SD * (kChunk + 2 * j)]; next[2 * j + 1] = q[SD * (kChunk + 2 * j + 1)]; }
+                visit(t0 + j, q + SD * j, ring[j], false);
             }
         }
-        chunk_end(t0 + kChunk - 1);
+        if (ci + 1 == a.hs) chunk_end(t0 + kChunk - 1);
 #pragma unroll
         for (int j = 0; j < kChunk; j++) ring[j] = next[j];
     }
@@ -470,11 +493,40 @@ __global__ __launch_bounds__(256) void k_mbd_extract(const float4 *__restrict__ 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) D[i] = st[i].y;
 }
 
+// row-major state -> skewed copy: one thread per skewed cell (coalesced writes; the reads are one line per lane)
+__global__ __launch_bounds__(256) void k_mbd_skew(const float4 *__restrict__ st, int rows, int cols, SkewGeom geo, int groups, float4 *__restrict__ sk) {
+    const size_t cells = (size_t)groups * geo.dn * 64, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+        const int l = (int)(i & 63);
+        const size_t gd = i >> 6;
+        const int g = (int)(gd / (size_t)geo.dn), d = (int)(gd - (size_t)g * geo.dn);
+        const int r = 64 * g + l - 63, c = d - l - 128;
+        if (r >= 0 && r < rows && c >= 0 && c < cols) sk[i] = st[(size_t)r * cols + c];
+    }
+}
+// and back: one thread per pixel (coalesced writes)
+__global__ __launch_bounds__(256) void k_mbd_unskew(const float4 *__restrict__ sk, size_t n, int cols, SkewGeom geo, float4 *__restrict__ st) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / (size_t)cols), c = (int)(i - (size_t)r * cols);
+        st[i] = sk[geo.idx(r, c)];
+    }
+}
+
 // pass p of mbd(img, iters) is the forward scan when p is odd, the inverse scan when p is even (patolette.pyx:180-199)
 static void run_mbd_scans(SalWork &w, int rows, int cols, int iters, hipStream_t s) {
     const int strips_f = (int)ceil_div((size_t)rows - 2, 64), strips_i = (int)ceil_div((size_t)rows - 3, 64);
     w.progress.reserve((size_t)strips_f + 1);                // [strips] progress + [1] stall flag
-    MbdArgs ma{w.st.p + kMbdPad, rows, cols, w.progress.p, w.progress.p + strips_f};
+    static const int hs = getenv("PAMD_MBD_HS") ? std::max(1, atoi(getenv("PAMD_MBD_HS"))) : 1;
+    const SkewGeom geo{cols + 320};
+    const int groups = ((rows + 126) >> 6) + 1;              // rows -63 .. rows + 62 (the lanes of the last strips run past the image)
+    const size_t cells = (size_t)groups * geo.dn * 64;
+    w.skew.reserve(cells + 64);
+    {
+        KTIME("k_mbd_skew", s, 32.0 * rows * cols);
+        hipLaunchKernelGGL(k_mbd_skew, stream_grid(cells), 256, 0, s, w.st.p + kMbdPad, rows, cols, geo, groups, w.skew.p);
+    }
+    MbdArgs ma{w.skew.p, geo, rows, cols, w.progress.p, w.progress.p + strips_f, hs};
     w.d_stall = w.progress.p + strips_f;
     HIP_CHECK(hipMemsetAsync(w.d_stall, 0, sizeof(unsigned int), s));
     for (int pass = 0; pass < iters; pass++) {
@@ -482,6 +534,10 @@ static void run_mbd_scans(SalWork &w, int rows, int cols, int iters, hipStream_t
         KTIME("k_mbd_scan", s, 32.0 * rows * cols);
         if (pass % 2 == 1) hipLaunchKernelGGL(k_mbd_scan<1>, strips_f, 64, 0, s, ma);
         else hipLaunchKernelGGL(k_mbd_scan<-1>, strips_i, 64, 0, s, ma);
+    }
+    {
+        KTIME("k_mbd_skew", s, 32.0 * rows * cols);
+        hipLaunchKernelGGL(k_mbd_unskew, stream_grid((size_t)rows * cols), 256, 0, s, w.skew.p, (size_t)rows * cols, cols, geo, w.st.p + kMbdPad);
     }
     HIP_CHECK(hipGetLastError());
 }
