@@ -382,7 +382,10 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
     // written back.  bu / bl hold the row above the strip, one column per lane, and rotate down one lane per step so that
     // lane 0 -- whose "lane above" is that row -- always finds its column in its own register (no readlane round trip
     // through the scalar unit).  The loop-carried chain is shift -> max/min -> sub -> min -> compare -> two selects.
-    auto visit = [&](int t, float4 *q, const float4 cur, const bool steady) {
+    // steady: every valid lane visits; full (with steady): every lane is a valid row -- the record is then stored unconditionally
+    // (unchanged pixels rewrite their own values): no branch around the store, eight instructions less of a step's ~40, and the
+    // lone wavefront's issue rate is what a pass waits for
+    auto visit = [&](int t, float4 *q, const float4 cur, const bool steady, const bool full) {
         const float u1 = wave_shr1(bu, outU), l1 = wave_shr1(bl, outL);
         bu = wave_shl1(bu); bl = wave_shl1(bl);
         const float ix = cur.x, d = cur.y;
@@ -393,7 +396,10 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
         const bool keep = d <= m;
         const bool t1 = b1 <= b2;                               // given !keep this is (b1 < d) && (b1 <= b2)
         const float nu = keep ? cur.z : (t1 ? hu1 : hu2), nl = keep ? cur.w : (t1 ? hl1 : hl2);
-        if (steady) {
+        if (steady && full) {
+            outU = nu; outL = nl;
+            *q = make_float4(ix, keep ? d : m, nu, nl);
+        } else if (steady) {
             outU = nu; outL = nl;
             if (!keep && rowok) *q = make_float4(ix, m, nu, nl);
         } else {
@@ -448,17 +454,23 @@ __global__ __launch_bounds__(64) void k_mbd_scan(MbdArgs a) {
         float4 *q = p + SD * t0;
         // every valid lane visits at every step of the block: after the ramp-up (t0 >= 63) and before lane 0 runs out of columns
         const bool steady = t0 >= 64 && t0 + kChunk <= Cn;
-        if (steady) {
+        if (steady && rl == 63) {
 #pragma unroll
             for (int j = 0; j < kChunk; j++) {
                 if (j < kChunk / 2) { next[2 * j] = q[SD * (kChunk + 2 * j)]; next[2 * j + 1] = q[SD * (kChunk + 2 * j + 1)]; }
-                visit(t0 + j, q + SD * j, ring[j], true);
+                visit(t0 + j, q + SD * j, ring[j], true, true);
+            }
+        } else if (steady) {
+#pragma unroll
+            for (int j = 0; j < kChunk; j++) {
+                if (j < kChunk / 2) { next[2 * j] = q[SD * (kChunk + 2 * j)]; next[2 * j + 1] = q[SD * (kChunk + 2 * j + 1)]; }
+                visit(t0 + j, q + SD * j, ring[j], true, false);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < kChunk; j++) {
                 if (j < kChunk / 2) { next[2 * j] = q[SD * (kChunk + 2 * j)]; next[2 * j + 1] = q[SD * (kChunk + 2 * j + 1)]; }
-                visit(t0 + j, q + SD * j, ring[j], false);
+                visit(t0 + j, q + SD * j, ring[j], false, false);
             }
         }
         if (ci + 1 == a.hs) chunk_end(t0 + kChunk - 1);
