@@ -846,16 +846,20 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 hipLaunchKernelGGL(k_round_setup, (unsigned)std::min<size_t>((work + 255) / 256, 2048), 256, 0, s, E.nodes.p, rs);
                 HIP_CHECK(hipGetLastError());
             }
-            launch_minmax(qlq, E.tilesA.p, ntA, rpx, E.nodes.p, s);
+            // the sweeps of a round alternate their direction through the pixels (the first one runs against the partition that
+            // wrote them): each starts on what the previous one touched last.  PAMD_SWEEP_SNAKE=0: all forward
+            static const bool snake = !(getenv("PAMD_SWEEP_SNAKE") && atoi(getenv("PAMD_SWEEP_SNAKE")) == 0);
+            const bool rev = snake && (E.stats.lq_rounds % 2 == 0);
+            launch_minmax(qlq, E.tilesA.p, ntA, rpx, E.nodes.p, s, rev);
             if (sh) shard_exchange_keys(E, d_ids, nr);
-            launch_hist(qlq, false, E.tilesA.p, ntA, rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+            launch_hist(qlq, false, E.tilesA.p, ntA, rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake && !rev);
             if (sh) {
                 comm_sum_dev(E, E.hist.p, lqs * nr, 0);
                 if (weighted) comm_sum_dev(E, E.hsize.p, (size_t)nr * kBuckets, 1);
                 comm_sum_dev(E, E.hcount.p, (size_t)nr * kBuckets, 2);
             }
             launch_cut(weighted, E.nodes.p, d_ids, nr, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s);
-            launch_partition(qlq, E.tilesP.p, ntP, rpx, d_ids, d_tP0, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s, inv_sums);
+            launch_partition(qlq, E.tilesP.p, ntP, rpx, d_ids, d_tP0, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s, inv_sums, rev);
             if (sh) {
                 hipLaunchKernelGGL(k_shard_children_local, (nr + 63) / 64, 64, 0, s, E.nodes.p, d_ids, nr);
                 HIP_CHECK(hipGetLastError());

@@ -98,8 +98,10 @@ __device__ __forceinline__ double project(double x, double y, double z, const do
     return (x * a0 + y * a1) + z * a2;
 }
 
-__global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes) {
-    const Tile t = tiles[blockIdx.x];
+__global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes, const int from_end) {
+    // tiles are taken from the END: this sweep follows the partition kernel, whose most recently written lines are the last
+    // tiles' (what is still in flight towards HBM is read last; measured on a replica: 80 -> 73 us behind a copy of 403 MB)
+    const Tile t = tiles[from_end ? gridDim.x - 1u - blockIdx.x : blockIdx.x];
     NodeDev &nd = nodes[t.node];
     const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
     const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__r
 // --------------------------------------------------------------------------------------------
 template <bool W, bool GQ>
 __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
-                                              double *hist, unsigned long long *hsize, unsigned int *hcount) {
+                                              double *hist, unsigned long long *hsize, unsigned int *hcount, const int from_end) {
     constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
     constexpr int NQS = GQ ? kNQ_GQ : kNQ_LQ;            // slot stride in quantities
     extern __shared__ double lds[];
@@ -153,8 +155,11 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
 
     // a block walks consecutive tiles (the tiles of one node are consecutive) and flushes its LDS histogram to HBM
     // only when the node changes: far fewer global f64 atomics than one flush per tile
+    // from_end: the blocks take their runs of tiles from the end of the list -- each sweep of a split round starts where the
+    // previous one stopped, on the lines that are still in the caches (k_minmax)
     const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int tfirst = (int)blockIdx.x * per, tlast = min(ntiles, tfirst + per);
+    const int bid = from_end ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
     for (int ti = tfirst; ti < tlast; ti++) {
         const Tile t = tiles[ti];
         NodeDev &nd = nodes[t.node];
@@ -342,10 +347,11 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
 // parent, as the reference's index lists have it.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_count(QuantBuffers qb, const Tile *__restrict__ tiles, const NodeDev *__restrict__ nodes,
-                                               const unsigned char *__restrict__ lut, unsigned int *tilecnt) {
+                                               const unsigned char *__restrict__ lut, unsigned int *tilecnt, const int from_end) {
     __shared__ unsigned int c[kMaxChildren];
     __shared__ unsigned char sl[kBuckets];
-    const Tile t = tiles[blockIdx.x];
+    const unsigned tix = from_end ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const Tile t = tiles[tix];
     const NodeDev &nd = nodes[t.node];
     const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
     if (threadIdx.x < kMaxChildren) c[threadIdx.x] = 0;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(256) void k_count(QuantBuffers qb, const Tile *__re
         }
         __syncthreads();
     }
-    if (threadIdx.x < kMaxChildren) tilecnt[(size_t)blockIdx.x * kMaxChildren + threadIdx.x] = c[threadIdx.x];
+    if (threadIdx.x < kMaxChildren) tilecnt[(size_t)tix * kMaxChildren + threadIdx.x] = c[threadIdx.x];
 }
 __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ round_nodes, const int *__restrict__ node_tile0, NodeDev *nodes,
                                               const unsigned int *__restrict__ tilecnt, unsigned long long *tileoff) {
@@ -482,7 +488,8 @@ __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ round_nod
 // deterministic, but the roundings move with the tile boundaries) and splits the 14 partials once per run of tiles.
 template <bool W, bool COV, bool INV = false>
 __global__ __launch_bounds__(256, INV ? 4 : 5) void k_scatter(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
-                                                    const unsigned char *__restrict__ lut, const unsigned long long *__restrict__ tileoff) {
+                                                    const unsigned char *__restrict__ lut, const unsigned long long *__restrict__ tileoff,
+                                                    const int from_end) {
     constexpr int R = kTileP / 256;
     __shared__ unsigned long long off[R][4][kMaxChildren];
     __shared__ double sm[28 * 4];
@@ -493,7 +500,8 @@ __global__ __launch_bounds__(256, INV ? 4 : 5) void k_scatter(QuantBuffers qb, c
     // and the 14 per-thread partials are split onto the exact grids, reduced over the block and added atomically only
     // when the node changes or the block is done.
     const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int tfirst = (int)blockIdx.x * per, tlast = min(ntiles, tfirst + per);
+    const int bid = from_end ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
     constexpr int NP = INV ? 14 : 7;
     double pl[NP], pr[NP];
     if constexpr (COV) {
@@ -695,16 +703,16 @@ void launch_sum3(const double *planar, size_t N, BinK k, double *d_out6, hipStre
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s) {
+void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end) {
     if (!ntiles) return;
     KTIME("k_minmax", s, 24.0 * px);
-    hipLaunchKernelGGL(k_minmax, ntiles, 256, 0, s, qb, d_tiles, d_nodes);
+    hipLaunchKernelGGL(k_minmax, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0);
     HIP_CHECK(hipGetLastError());
 }
 
 template <bool W, bool GQ>
 static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, double *d_hist,
-                          unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s) {
+                          unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end) {
     constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
     size_t lds = (size_t)NQ * 2 * kBuckets * sizeof(double) + kBuckets * (sizeof(unsigned int) + sizeof(unsigned long long));
     static PerDeviceOnce attr_set;
@@ -713,7 +721,7 @@ static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntile
     // resident blocks per CU by LDS footprint (4 for the local quantiser's 29 KB, 1 for the global quantiser's 82+ KB);
     // each block walks its run of tiles and flushes once per node run
     const int g = std::min(ntiles, 256 * (GQ ? 1 : 4));
-    hipLaunchKernelGGL((k_hist<W, GQ>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount);
+    hipLaunchKernelGGL((k_hist<W, GQ>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount, from_end ? 1 : 0);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -802,12 +810,12 @@ void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, 
 }
 
 void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
-                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s) {
+                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end) {
     if (!ntiles) return;
-    if (qb.weighted) { if (gq) launch_hist_t<true, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s);
-                       else launch_hist_t<true, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s); }
-    else { if (gq) launch_hist_t<false, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s);
-           else launch_hist_t<false, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s); }
+    if (qb.weighted) { if (gq) launch_hist_t<true, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
+                       else launch_hist_t<true, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end); }
+    else { if (gq) launch_hist_t<false, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
+           else launch_hist_t<false, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end); }
 }
 
 void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int nround, const double *d_hist,
@@ -821,9 +829,10 @@ void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int n
 
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
-                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s, bool invariant) {
+                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s, bool invariant, bool from_end) {
+    const int fe = from_end ? 1 : 0;
     if (!nround) return;
-    if (nptiles) { KTIME("k_count", s, 2.0 * px); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt); }
+    if (nptiles) { KTIME("k_count", s, 2.0 * px); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt, fe); }
     // (a GPU holding none of the round's pixels still needs the children's -- empty -- segments: k_scan runs regardless)
     { KTIME("k_scan", s, 12.0 * kMaxChildren * nptiles); hipLaunchKernelGGL(k_scan, nround, 1024, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff); }
     if (nptiles) {
@@ -831,13 +840,13 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
         if (fuse_cov) {
             const int g = std::min(nptiles, 256 * (invariant ? 4 : 5));   // resident blocks per CU, each loops over its run of tiles
             if (invariant) {
-                if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
-                else hipLaunchKernelGGL((k_scatter<false, true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
-            } else if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
-            else hipLaunchKernelGGL((k_scatter<false, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
+                if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fe);
+                else hipLaunchKernelGGL((k_scatter<false, true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fe);
+            } else if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fe);
+            else hipLaunchKernelGGL((k_scatter<false, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fe);
         } else {
-            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
-            else hipLaunchKernelGGL((k_scatter<false, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff);
+            if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fe);
+            else hipLaunchKernelGGL((k_scatter<false, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fe);
         }
     }
     HIP_CHECK(hipGetLastError());
