@@ -389,7 +389,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 3),
                     "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"], 1),
-                    "time_share": round(r["total_ms"] / args.steps / max(1e-9, sum(v["ms_per_step"] for v in kernels.values())), 3)}
+                    "time_share": round(kernels.get(dom, {"ms_per_step": 0.0})["ms_per_step"] / max(1e-9, sum(v["ms_per_step"] for v in kernels.values())), 3)}
 
     # ---- extras of the default run, all outside the timed region ----
     ns_kernels = h2h = None

@@ -10,6 +10,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 tag, cfg = sys.argv[1], sys.argv[2]
@@ -24,7 +25,7 @@ def short(name):
     if base == "k_hist":
         return "k_hist_gq" if ", true>" in n else "k_hist_lq"
     if base == "k_scatter":
-        return "k_scatter_cov" if ", true>" in n else "k_scatter"
+        return "k_scatter_cov" if re.match(r"k_scatter<\w+, true", n) else "k_scatter"      # <W, COV(, INV)>
     if base in ("k_cov_children", "k_cov_nodes"):
         return "k_cov"
     if base in ("k_nn_map_lut", "k_nn_map_mid"):

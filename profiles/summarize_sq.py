@@ -6,6 +6,7 @@ import collections
 import csv
 import glob
 import os
+import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +22,7 @@ def short(name):
     if base == "k_hist":
         return "k_hist_gq" if ", true>" in n else "k_hist_lq"
     if base == "k_scatter":
-        return "k_scatter_cov" if ", true>" in n else "k_scatter"
+        return "k_scatter_cov" if re.match(r"k_scatter<\w+, true", n) else "k_scatter"      # <W, COV(, INV)>
     return base
 
 
