@@ -604,7 +604,10 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         NodeIn d = make_nodedev(hn[0], bnd);
         put_nodes(E, {0}, {d});
     }
-    launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, ntA0, N, E.nodes.p, s);
+    // every sweep over the pixels starts where the previous one stopped (see the split rounds below): the conversion wrote the
+    // image front to back, so the root's moments are taken back to front, the extrema front to back, ...
+    static const bool snake = !(getenv("PAMD_SWEEP_SNAKE") && atoi(getenv("PAMD_SWEEP_SNAKE")) == 0);
+    launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, ntA0, N, E.nodes.p, s, snake);
     std::vector<NodeOut> got;
     if (sh) shard_exchange_acc(E, shard_upload_ids(E, {0}), 1);
     get_nodes(E, {0}, got);
@@ -620,9 +623,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         put_nodes(E, {0}, {d});
     }
     const size_t hs = hist_slot_doubles();
-    launch_minmax(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s);
+    launch_minmax(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, false);
     if (sh) shard_exchange_keys(E, shard_upload_ids(E, {0}), 1);
-    launch_hist(qroot, true, E.tilesA.p, ntA0, N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s);
+    launch_hist(qroot, true, E.tilesA.p, ntA0, N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake);
     if (sh) { comm_sum_dev(E, E.hist.p, hs, 0); comm_sum_dev(E, E.hcount.p, kBuckets, 2); }
     const int gq_kmax = (int)std::min<size_t>(K, kGqMaxK);
     E.gq.reserve(1); E.h_gq.reserve(1);
@@ -700,7 +703,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     HIP_CHECK(hipMemcpyAsync(E.lut.p, E.h_bytes.p, kBuckets, hipMemcpyHostToDevice, s));
     launch_partition(qroot, E.tilesP.p, ntP0, N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, false, s);
     if (sh) { hipLaunchKernelGGL(k_shard_children_local, 1, 64, 0, s, E.nodes.p, E.round_nodes.p, 1); HIP_CHECK(hipGetLastError()); }
-    launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s);
+    launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, snake);
     if (sh) shard_exchange_acc(E, shard_upload_ids(E, base_ids), (int)base_ids.size());
     get_nodes(E, base_ids, got);
     for (size_t i = 0; i < base_ids.size(); i++) {
@@ -848,8 +851,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             }
             // the sweeps of a round alternate their direction through the pixels (the first one runs against the partition that
             // wrote them): each starts on what the previous one touched last.  PAMD_SWEEP_SNAKE=0: all forward
-            static const bool snake = !(getenv("PAMD_SWEEP_SNAKE") && atoi(getenv("PAMD_SWEEP_SNAKE")) == 0);
-            const bool rev = snake && (E.stats.lq_rounds % 2 == 0);
+            const bool rev = snake && (E.stats.lq_rounds % 2 == 1);     // (the base clusters' moments were taken back to front)
             launch_minmax(qlq, E.tilesA.p, ntA, rpx, E.nodes.p, s, rev);
             if (sh) shard_exchange_keys(E, d_ids, nr);
             launch_hist(qlq, false, E.tilesA.p, ntA, rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake && !rev);

@@ -113,9 +113,9 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
                       unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s,
                       bool invariant = false, bool from_end = false);
-void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s);
+void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end = false);
 void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
-                      NodeDev *d_nodes, hipStream_t s);
+                      NodeDev *d_nodes, hipStream_t s, bool from_end = false);
 
 size_t hist_slot_doubles();            // doubles per histogram slot
 

@@ -651,9 +651,9 @@ __device__ __forceinline__ void cov_accumulate(const double *px, const double *p
 
 // tiles cover the PARENT's range in the destination buffer; each child accumulates about its own mean
 template <bool W>
-__global__ __launch_bounds__(256) void k_cov_children(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes) {
+__global__ __launch_bounds__(256) void k_cov_children(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes, const int from_end) {
     __shared__ double sm[14 * 4];
-    const Tile t = tiles[blockIdx.x];
+    const Tile t = tiles[from_end ? gridDim.x - 1u - blockIdx.x : blockIdx.x];
     const NodeDev &nd = nodes[t.node];
     const double *px = qb.buf[1 - nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
     const size_t t_lo = t.start, t_hi = t.start + t.count;
@@ -674,9 +674,10 @@ __global__ __launch_bounds__(256) void k_cov_children(QuantBuffers qb, const Til
 
 // tiles cover the node's own segment (root: `planar` = the converted image itself)
 template <bool W>
-__global__ __launch_bounds__(256) void k_cov_nodes(QuantBuffers qb, const double *planar, const Tile *__restrict__ tiles, NodeDev *nodes) {
+__global__ __launch_bounds__(256) void k_cov_nodes(QuantBuffers qb, const double *planar, const Tile *__restrict__ tiles, NodeDev *nodes,
+                                                   const int from_end) {
     __shared__ double sm[14 * 4];
-    const Tile t = tiles[blockIdx.x];
+    const Tile t = tiles[from_end ? gridDim.x - 1u - blockIdx.x : blockIdx.x];
     NodeDev &nd = nodes[t.node];
     const double *px = planar ? planar : qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
     double a[14];
@@ -852,21 +853,21 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s) {
+void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end) {
     if (!ntiles) return;
     KTIME("k_cov", s, (qb.weighted ? 32.0 : 24.0) * px);
-    if (qb.weighted) hipLaunchKernelGGL(k_cov_children<true>, ntiles, 256, 0, s, qb, d_tiles, d_nodes);
-    else hipLaunchKernelGGL(k_cov_children<false>, ntiles, 256, 0, s, qb, d_tiles, d_nodes);
+    if (qb.weighted) hipLaunchKernelGGL(k_cov_children<true>, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0);
+    else hipLaunchKernelGGL(k_cov_children<false>, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0);
     HIP_CHECK(hipGetLastError());
 }
 
 void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
-                      NodeDev *d_nodes, hipStream_t s) {
+                      NodeDev *d_nodes, hipStream_t s, bool from_end) {
     if (!ntiles) return;
     KTIME("k_cov", s, ((qb.weighted && !planar_override) ? 32.0 : 24.0) * px);
     // the root PCA is unweighted even when weights exist (global.c:407)
-    if (qb.weighted && !planar_override) hipLaunchKernelGGL(k_cov_nodes<true>, ntiles, 256, 0, s, qb, planar_override, d_tiles, d_nodes);
-    else hipLaunchKernelGGL(k_cov_nodes<false>, ntiles, 256, 0, s, qb, planar_override, d_tiles, d_nodes);
+    if (qb.weighted && !planar_override) hipLaunchKernelGGL(k_cov_nodes<true>, ntiles, 256, 0, s, qb, planar_override, d_tiles, d_nodes, from_end ? 1 : 0);
+    else hipLaunchKernelGGL(k_cov_nodes<false>, ntiles, 256, 0, s, qb, planar_override, d_tiles, d_nodes, from_end ? 1 : 0);
     HIP_CHECK(hipGetLastError());
 }
 
