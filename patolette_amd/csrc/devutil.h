@@ -53,6 +53,23 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+// Sum over the wavefront by DPP moves (VALU only, no LDS round trips): the total lands in lane 63.  For exact addends.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(const double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(thi, tlo);
+}
+__device__ __forceinline__ double wave_sum_dpp63(double v) {
+    v = dpp_add_f64<0x111, 0xf>(v);          // row_shr:1
+    v = dpp_add_f64<0x112, 0xf>(v);          // row_shr:2
+    v = dpp_add_f64<0x114, 0xf>(v);          // row_shr:4
+    v = dpp_add_f64<0x118, 0xf>(v);          // row_shr:8  -> lane 15 of every row holds the row's sum
+    v = dpp_add_f64<0x142, 0xa>(v);          // row_bcast:15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xc>(v);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

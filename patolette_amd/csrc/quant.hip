@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__r
 // --------------------------------------------------------------------------------------------
 // bucket moments: sort.c:61-87 (bucket id) + local.c:118-134 (LQ) / cells.c:82-112 (GQ)
 // --------------------------------------------------------------------------------------------
+constexpr int kHistCombineMin = 12;    // lanes of a wavefront sharing a bucket from which their addends are summed before the LDS atomics
 template <bool W, bool GQ>
 __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
                                               double *hist, unsigned long long *hsize, unsigned int *hcount, const int from_end) {
@@ -184,28 +185,59 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
                 b = bq < (unsigned long long)(kBuckets - 1) ? (unsigned)bq : (unsigned)(kBuckets - 1);
             }
             qb.bkt[p] = (unsigned short)b;
-            atomicAdd(&cnt[b], 1u);
-            double v0, v1;
-#define HADD(q, val, K)                                         \
-    do {                                                        \
-        bin_split((val), (K), v0, v1);                          \
-        unsafeAtomicAdd(&h[((q) * 2 + 0) * kBuckets + b], v0);  \
-        unsafeAtomicAdd(&h[((q) * 2 + 1) * kBuckets + b], v1);  \
-    } while (0)
+            // the pixel's addends, both binned parts of every quantity
+            double pv[2 * NQ];
+#define HPART(q, val, K) bin_split((val), (K), pv[2 * (q)], pv[2 * (q) + 1])
             if constexpr (!GQ) {
-                HADD(0, x * w, klin); HADD(1, y * w, klin); HADD(2, z * w, klin);
-                if constexpr (W) {
-                    HADD(3, w, klin);
-                    atomicAdd(&siz[b], (unsigned long long)w);               // size_t += double truncates (local.c:133)
-                }
+                HPART(0, x * w, klin); HPART(1, y * w, klin); HPART(2, z * w, klin);
+                if constexpr (W) HPART(3, w, klin);
             } else {
-                HADD(0, x, klin); HADD(1, y, klin); HADD(2, z, klin);
-                HADD(3, (x * x + y * y) + z * z, kquad);
-                HADD(4, x * x, kquad); HADD(5, x * y, kquad); HADD(6, y * y, kquad);
-                HADD(7, x * z, kquad); HADD(8, y * z, kquad); HADD(9, z * z, kquad);
-                if constexpr (W) { HADD(10, x * w, klin); HADD(11, y * w, klin); HADD(12, z * w, klin); HADD(13, w, klin); }
+                HPART(0, x, klin); HPART(1, y, klin); HPART(2, z, klin);
+                HPART(3, (x * x + y * y) + z * z, kquad);
+                HPART(4, x * x, kquad); HPART(5, x * y, kquad); HPART(6, y * y, kquad);
+                HPART(7, x * z, kquad); HPART(8, y * z, kquad); HPART(9, z * z, kquad);
+                if constexpr (W) { HPART(10, x * w, klin); HPART(11, y * w, klin); HPART(12, z * w, klin); HPART(13, w, klin); }
             }
-#undef HADD
+#undef HPART
+            unsigned long long wi = 0ULL;
+            if constexpr (W && !GQ) wi = (unsigned long long)w;                  // size_t += double truncates (local.c:133)
+            // Neighbouring pixels of a flat or smooth region fall into the SAME bucket: 64 lanes adding to one LDS address
+            // serialise (a smooth 4096^2 image took 3.2x, a posterised one 5.4x as long as noise).  When the wavefront is complete
+            // and at least a third of it shares the first lane's bucket, that group's addends are summed over the wavefront first
+            // (exact: they lie on the grids) and added once; the other lanes add their own.
+            bool direct = true;
+            if (__ballot(true) == ~0ULL) {
+                // up to three groups: the bucket of the first lane still holding its addends, if enough lanes share it
+                unsigned long long left = ~0ULL;
+#pragma unroll 1
+                for (int g = 0; g < 3 && left != 0ULL; g++) {
+                    const int first = __builtin_ctzll(left);                       // wave-uniform
+                    const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)b, first);
+                    const bool mine = direct && b == b0;
+                    const unsigned long long m = __ballot(mine);
+                    if (__popcll(m) < kHistCombineMin) break;
+#pragma unroll
+                    for (int k2 = 0; k2 < 2 * NQ; k2++) {
+                        const double sum = wave_sum_dpp63(mine ? pv[k2] : 0.0);
+                        if ((threadIdx.x & 63) == 63) unsafeAtomicAdd(&h[k2 * kBuckets + b0], sum);
+                    }
+                    if constexpr (W && !GQ) {
+                        unsigned long long sw2 = mine ? wi : 0ULL;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) sw2 += __shfl_down(sw2, o, 64);
+                        if ((threadIdx.x & 63) == 0) atomicAdd(&siz[b0], sw2);
+                    }
+                    if ((threadIdx.x & 63) == 0) atomicAdd(&cnt[b0], (unsigned)__popcll(m));
+                    if (mine) direct = false;
+                    left &= ~m;
+                }
+            }
+            if (direct) {
+                atomicAdd(&cnt[b], 1u);
+#pragma unroll
+                for (int k2 = 0; k2 < 2 * NQ; k2++) unsafeAtomicAdd(&h[k2 * kBuckets + b], pv[k2]);
+                if constexpr (W && !GQ) atomicAdd(&siz[b], wi);
+            }
         };
         unsigned i = threadIdx.x;
         for (; i + 512 < t.count; i += 1024) {
