@@ -29,6 +29,10 @@ void kmeans_gather(const double *d_planar, size_t N, bool weighted, const int *d
 // the same for a GPU that holds pixels [begin, begin + n_local) of the image: foreign samples are written as zero bits
 void kmeans_gather_slice(const double *d_planar, size_t n_local, bool weighted, const int *d_perm, size_t nx, size_t begin,
                          KMeansWork &w, hipStream_t s);
-void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s);
+// expect_longest: samples the most populous centroid is expected to hold (0 = unknown).  The list-collecting update of the
+// few-samples path replays a centroid's chain at one sample per dependent add (3.3 ns), so one long cluster paces every
+// iteration (a colour covering 30 % of the image: 46 ms instead of 5); from 4096 expected samples on the iterations take the
+// sorted path, whose update sums long clusters block-parallel (km_chain_coop).
+void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s, size_t expect_longest = 0);
 
 }  // namespace pamd

@@ -1568,7 +1568,7 @@ void kmeans_gather_slice(const double *d_planar, size_t n_local, bool weighted, 
     HIP_CHECK(hipGetLastError());
 }
 
-void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s) {
+void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s, size_t expect_longest) {
     KmSamples ks{w.sx.p, w.sy.p, w.sz.p, w.sw.p};
     int nbits = 0;
     while ((1 << nbits) < k) nbits++;
@@ -1608,7 +1608,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     }
     // few samples: block-local sorts in the assignment kernel, one block per centroid collects its members (k_km_update_lists)
     const size_t direct_max = getenv("PAMD_KM_DIRECT_MAX") ? (size_t)atoll(getenv("PAMD_KM_DIRECT_MAX")) : ((size_t)1 << 19);
-    const bool use_direct = !use_lut && k <= 256 && nx <= direct_max && nx < ((size_t)1 << 32);
+    const size_t list_longest = getenv("PAMD_KM_LIST_LONGEST") ? (size_t)atoll(getenv("PAMD_KM_LIST_LONGEST")) : (size_t)4096;
+    const bool use_direct = !use_lut && k <= 256 && nx <= direct_max && nx < ((size_t)1 << 32) && expect_longest < list_longest;
     if (use_direct) {
         static PerDeviceOnce attr4;
         if (attr4.first()) {

@@ -561,7 +561,7 @@ static void gq_prepare(Engine &E, size_t N, bool weighted) {
 }
 
 static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const Bounds &bnd,
-                             std::vector<double> &centers, size_t &len, bool verbose = false) {
+                             std::vector<double> &centers, size_t &len, bool verbose = false, unsigned long long *max_members = nullptr) {
     hipStream_t s = E.stream;
     const size_t planes = weighted ? 4 : 3;
     const Shard *sh = E.shard;                                  // the image is dealt out over a group of GPUs: N is this GPU's part
@@ -886,6 +886,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     len = count;
     centers.assign(3 * len, 0.0);
     for (size_t i = 0; i < len; i++) for (int j = 0; j < 3; j++) centers[(size_t)j * len + i] = hn[result[i]].mean[j];   // create.c:11-33
+    if (max_members) { *max_members = 0; for (size_t i = 0; i < len; i++) *max_members = std::max(*max_members, hn[result[i]].gn); }
     E.stats.n_clusters = len;
     E.stats.ms_lq = now_ms() - t0;
     return 0;
@@ -894,8 +895,10 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
 // --------------------------------------------------------------------------------------------
 // KMeans refinement (refine.c:165-221); centres planar (k,3) f64 in/out
 // --------------------------------------------------------------------------------------------
+// largest_cluster: pixels of the most populous cluster the centres come from (0 = unknown): a dominant colour means one very long
+// centroid chain, and the iterations then take the sorted path with the block-parallel chain from the start (kmeans_iterate)
 static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double> &centers, size_t k, int niter, size_t max_samples,
-                          bool nonfinite) {
+                          bool nonfinite, unsigned long long largest_cluster = 0) {
     hipStream_t s = E.stream;
     if (k > (size_t)kKMeansMaxK) throw HipError("patolette_amd: KMeans refinement supports at most 4096 palette entries");
     std::vector<float> cent(3 * k);
@@ -907,6 +910,7 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
     // swallows the exception and the palette stays the initial centres
     const Shard *sh = E.shard;                                                     // sliced image: N is this GPU's part, the sample set is the whole image's
     const size_t Nt = sh ? sh->total : N;
+    auto expect_longest = [&](size_t nx_) { return (size_t)((double)largest_cluster / (double)(Nt ? Nt : 1) * (double)nx_); };
     bool ok = Nt >= k && !nonfinite;
     size_t nx = Nt;
     E.stats.kmeans_samples = 0;
@@ -943,7 +947,7 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
             } else {
                 HIP_CHECK(hipMemcpyAsync(E.km.cent.p, cent.data(), 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                kmeans_iterate(E.km, nx, (int)k, weighted, niter, s);
+                kmeans_iterate(E.km, nx, (int)k, weighted, niter, s, expect_longest(nx));
                 HIP_CHECK(hipMemcpyAsync(cent.data(), E.km.cent.p, 3 * k * sizeof(float), hipMemcpyDeviceToHost, s));
                 E.sync();
                 E.stats.kmeans_samples = nx;
@@ -957,7 +961,7 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
             E.h_cent.reserve(3 * k);                                               // pinned: no synchronisation before the iterations
             std::memcpy(E.h_cent.p, cent.data(), 3 * k * sizeof(float));
             HIP_CHECK(hipMemcpyAsync(E.km.cent.p, E.h_cent.p, 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
-            kmeans_iterate(E.km, nx, (int)k, weighted, niter, s);
+            kmeans_iterate(E.km, nx, (int)k, weighted, niter, s, expect_longest(nx));
             HIP_CHECK(hipMemcpyAsync(E.h_cent.p, E.km.cent.p, 3 * k * sizeof(float), hipMemcpyDeviceToHost, s));
             E.sync();
             std::memcpy(cent.data(), E.h_cent.p, 3 * k * sizeof(float));
@@ -1078,13 +1082,14 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     if (opt->verbose) printf("patolette ======== Palette generation \n");
     std::vector<double> pal;
     size_t len = 0;
-    if (quantize_clusters(E, N, K, weighted, bnd, pal, len, opt->verbose) != 0) throw HipError("internal quantization error");
+    unsigned long long largest_cluster = 0;
+    if (quantize_clusters(E, N, K, weighted, bnd, pal, len, opt->verbose, &largest_cluster) != 0) throw HipError("internal quantization error");
 
     // S4: optional KMeans refinement
     t0 = now_ms();
     if (opt->kmeans_niter > 0) {
         if (opt->verbose) printf("patolette ======== KMeans refinement\n");                // patolette.c:249-251
-        kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples, bnd.nonfinite);
+        kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples, bnd.nonfinite, largest_cluster);
     }
     E.stats.ms_kmeans = now_ms() - t0;
 

@@ -225,3 +225,21 @@ def test_release_workspace_and_thread_engines(gpu, native, ob):
     box.append(p.quantize(w, h, colors, K, dither=False, tile_size=0, kmeans_niter=2))
     for r in box:
         assert r[0] and np.array_equal(r[1], first[1]) and np.array_equal(r[2], first[2])
+
+
+@pytest.mark.parametrize("frac", [0.08, 0.5])
+def test_dominant_colour_takes_the_sorted_kmeans_path(gpu, native, ob, frac):
+    """A colour that covers a good part of the image means ONE very long centroid chain.  The refinement then leaves the
+    list-collecting update of the few-samples path (one sample per dependent add) for the sorted path with the block-parallel
+    chain -- predicted from the size of the largest cluster the centres come from -- and must give what the oracle gives."""
+    w, h, K = 640, 400, 64
+    n = w * h
+    rng = np.random.default_rng(23)
+    rows = rng.random((n, 3))
+    k = int(frac * n)
+    rows[rng.permutation(n)[:k]] = np.array([0.12, 0.3, 0.65]) + 0.003 * rng.standard_normal((k, 3))
+    flat = np.ascontiguousarray(np.clip(rows, 0, 1).T).reshape(-1)
+    got, want = run_both(native, ob, w, h, flat, None, K, kmeans_niter=6)
+    assert_same(got, want, tol=1e-6)
+    st = native.last_stats()
+    assert st["kmeans_samples"] == n                       # 256 000 pixels <= 64 x 4096: every pixel is a sample
