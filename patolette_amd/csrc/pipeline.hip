@@ -719,7 +719,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     // ---------------- local quantiser (local.c:318-404) ----------------
     std::vector<int> result(base_ids);                          // frontier in the reference's order
     std::vector<int> leaves(base_ids);                          // candidate-tree nodes with moments but no split yet
-    const double spec_beta = 1.0 / 64;
+    static const double spec_beta = getenv("PAMD_SPEC_BETA") ? atof(getenv("PAMD_SPEC_BETA")) : 0.25;   // swept 1/256 .. 1 on six kinds of content: 1/4 evaluates least (noise 514 -> 319 splits, lq -8 %)
     size_t count = result.size();
     E.stats.split_evals = 0; E.stats.split_px = 0; E.stats.lq_rounds = 0;
     auto known = [&](const HNode &h) { return h.nosplit || h.gn <= 1 || h.split_done; };

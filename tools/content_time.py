@@ -20,7 +20,10 @@ try:
     imgs["scene, 8-bit"] = np.round(imgs["scene (tests.util)"] * 255) / 255
 except Exception as ex:                                      # noqa: BLE001
     print("no scene generator:", ex)
+only = sys.argv[1].split(";") if len(sys.argv) > 1 else None
 for name, colors in imgs.items():
+    if only and name not in only:
+        continue
     p.quantize(n, n, colors, 256, dither=False, tile_size=0)
     p.profile(True)
     ok = p.quantize(n, n, colors, 256, dither=False, tile_size=0)[0]
