@@ -816,6 +816,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             const int nr = (int)todo.size();
             size_t rpx = 0;
             for (int id : todo) rpx += hn[id].n;
+            static const bool lq_trace = getenv("PAMD_LQ_TRACE") != nullptr;       // one line per split round on stderr
+            if (lq_trace) fprintf(stderr, "patolette_amd: split round %zu: %d nodes, %zu pixels (%.2f of the image), %zu of %zu colours committed\n",
+                                  E.stats.lq_rounds + 1, nr, rpx, (double)rpx / (double)(N ? N : 1), count, K);
             // one packet, one copy: node records, ids, tile prefixes of both tilings, children ids
             std::vector<int> tA0(nr + 1), tP0(nr + 1), cids;
             tA0[0] = 0; tP0[0] = 0;
