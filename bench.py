@@ -215,11 +215,28 @@ def main():
                          "separately as throughput_concurrent, never as `value` (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, RCCL), exactly as the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` does; rank 0 prints the line.
+        import socket
+        import subprocess
+        from patolette_amd import _native
+        have = _native.lib().patolette_amd_device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but %d HIP device(s) visible" % (args.gpus, have))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
 
     dist = None
     torch = None
@@ -231,6 +248,9 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:          # n_gpus in the line = the ranks RCCL actually saw
+            raise SystemExit("bench.py: RCCL group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        world = dist.get_world_size()
 
     import numpy as np
     from patolette_amd import _native

@@ -80,7 +80,7 @@ def _check_weights(weights, count, npx):
     return out
 
 
-def _quantize_block_to_device(width, height, get, idx, palette_size, weights, device, opts_kw):
+def _quantize_block_to_device(width, height, get, idx, palette_size, weights, device, opts_kw, errors):
     """This rank's block through patolette_amd_batch_dmap: host images in, maps left in HBM in one torch tensor.
     Returns (codes int64 (n,1), palettes (n,K,3) f64, maps tensor (n, N) on `device`)."""
     import torch
@@ -97,36 +97,57 @@ def _quantize_block_to_device(width, height, get, idx, palette_size, weights, de
                                        int(opts_kw.get("kmeans_niter", 32)), int(opts_kw.get("kmeans_max_samples", 512 ** 2)), False)
     tile_size = float(opts_kw.get("tile_size", 512))
     torch.cuda.current_stream(device).synchronize()               # the library runs on its own streams
-    for g0 in range(0, n, 6):                                     # groups of six bound the host memory held at once
-        grp = list(range(g0, min(g0 + 6, n)))
-        imgs = [np.asarray(get(idx[j])) for j in grp]
-        if all(im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] in (3, 4) for im in imgs):
-            fmt = int(imgs[0].shape[2])
-            if any(im.shape != (height, width, fmt) for im in imgs):
+    def prepare(im):
+        """(fmt, array) of one image as patolette_amd_batch_dmap takes it; ValueError with the binding's message if malformed."""
+        im = np.asarray(im)
+        if im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] in (3, 4):
+            if im.shape[:2] != (height, width):
                 raise ValueError("images must be (height, width, 3|4) uint8 arrays of one shape")
-            datas = [np.ascontiguousarray(im) for im in imgs]
-        else:
-            planar = all(im.ndim == 2 and im.dtype == np.float64 and im.flags.f_contiguous and not im.flags.c_contiguous for im in imgs)
-            fmt = 0 if planar else 1
-            datas = imgs if planar else [np.ascontiguousarray(im, dtype=np.float64) for im in imgs]
-            for d in datas:
-                if d.ndim != 2 or d.shape[1] != 3:
-                    raise ValueError(bad_channel_count.format(d.shape[1] if d.ndim == 2 else "?"))
-                if d.shape[0] != npx:
-                    raise ValueError(color_mismatch)
-        cnt = len(grp)
-        ws = None if weights is None else [weights[idx[j]] for j in grp]
-        gp = [np.zeros((palette_size, 3), dtype=np.float64, order="F") for _ in grp]
+            return int(im.shape[2]), np.ascontiguousarray(im)
+        planar = im.ndim == 2 and im.dtype == np.float64 and im.flags.f_contiguous and not im.flags.c_contiguous
+        d = im if planar else np.ascontiguousarray(im, dtype=np.float64)
+        if d.ndim != 2 or d.shape[1] != 3:
+            raise ValueError(bad_channel_count.format(d.shape[1] if d.ndim == 2 else "?"))
+        if d.shape[0] != npx:
+            raise ValueError(color_mismatch)
+        return (0 if planar else 1), d
+
+    def run(js, fmt, datas):
+        cnt = len(js)
+        ws = None if weights is None else [weights[idx[j]] for j in js]
+        gp = [np.zeros((palette_size, 3), dtype=np.float64, order="F") for _ in js]
         gc = (C.c_int * cnt)()
         PV, PD = C.c_void_p * cnt, _native.dp * cnt
         L.patolette_amd_batch_dmap(cnt, width, height, PV(*[d.ctypes.data_as(C.c_void_p) for d in datas]), fmt,
                                    None if ws is None else PD(*[w.ctypes.data_as(_native.dp) if w is not None else _native.dp() for w in ws]),
                                    tile_size, palette_size, C.byref(opts), PD(*[p.ctypes.data_as(_native.dp) for p in gp]),
-                                   None if palette_only else C.c_void_p(maps_t[g0].data_ptr()), me, gc)
-        for j, p, c in zip(grp, gp, gc):
+                                   None if palette_only else C.c_void_p(maps_t[js[0]].data_ptr()), me, gc)
+        for j, p, c in zip(js, gp, gc):
             codes[j, 0] = c
             if c == 0:
                 pals[j] = p
+
+    for g0 in range(0, n, 6):                                     # groups of six bound the host memory held at once
+        # A malformed image (or a failing loader) must not raise here: the other ranks are on their way to the gathers and
+        # would wait for this one for ever.  It gets exit code -1 (its message goes to `errors`), the rest of the block runs.
+        ready = []
+        for j in range(g0, min(g0 + 6, n)):
+            try:
+                ready.append((j,) + prepare(get(idx[j])))
+            except Exception as e:                                # noqa: BLE001 -- whatever the loader or the checks raise
+                errors[idx[j]] = "%s: %s" % (type(e).__name__, e)
+        # maximal runs of consecutive images of one format go through one call (their maps are consecutive rows of maps_t)
+        k = 0
+        while k < len(ready):
+            m = k + 1
+            while m < len(ready) and ready[m][0] == ready[m - 1][0] + 1 and ready[m][1] == ready[k][1]:
+                m += 1
+            try:
+                run([r[0] for r in ready[k:m]], ready[k][1], [r[2] for r in ready[k:m]])
+            except Exception as e:                                # noqa: BLE001
+                for r in ready[k:m]:
+                    errors[idx[r[0]]] = "%s: %s" % (type(e).__name__, e)
+            k = m
     return codes, pals, maps_t
 
 
@@ -161,11 +182,12 @@ def quantize_batch_sharded(width, height, images, palette_size, dist=None, quant
             if m:
                 messages[c] = m.decode("UTF-8")
 
+    errors = {}                                                   # image number -> text of what it raised on THIS rank
     if quantize_fn is None and device is not None:
         # RCCL: bind this rank's engine to its GPU, leave the maps in HBM, gather from there
         if L.patolette_amd_set_device(device.index) != 0:
             raise RuntimeError("patolette_amd.dist: cannot bind to GPU %d" % device.index)
-        codes, pals, maps = _quantize_block_to_device(width, height, get, idx, palette_size, weights, device, kwargs)
+        codes, pals, maps = _quantize_block_to_device(width, height, get, idx, palette_size, weights, device, kwargs, errors)
     else:
         codes = np.full((n, 1), -1, dtype=np.int64)
         pals = np.full((n, palette_size, 3), np.nan)
@@ -177,38 +199,61 @@ def quantize_batch_sharded(width, height, images, palette_size, dist=None, quant
                 pals[j] = np.asarray(r[1], dtype=np.float64)
                 if have_map and r[2] is not None:
                     maps[j] = np.asarray(r[2]).reshape(-1).astype(mdt)
+            elif code is None and len(r) > 3 and r[3] and r[3] != MESSAGES[-1]:
+                errors[idx[j]] = r[3]
+
+        def fail(j, e):
+            # Nothing an image (or its loader) raises may leave this rank before the gathers: the others would wait for ever.
+            # Saliency stage: shape (-5) / singular covariance (-6); anything else is the reference's "internal error".
+            code = -6 if isinstance(e, np.linalg.LinAlgError) else (-5 if isinstance(e, ValueError) else -1)
+            errors[idx[j]] = str(e) if code != -1 else "%s: %s" % (type(e).__name__, e)
+            put(j, (False, None, None, str(e)), code)
 
         if quantize_fn is None:
             from . import quantize_batch, quantize_u8_batch
+
+            def run_group(js):
+                group = [get(idx[j]) for j in js]
+                ws = None if weights is None else [weights[idx[j]] for j in js]
+                if all(getattr(im, "dtype", None) == np.uint8 and getattr(im, "ndim", 0) == 3 for im in group):
+                    # 8-bit images as decoded, (H, W, 3|4): 3 bytes per pixel over PCIe instead of 24
+                    if any(im.shape[:2] != (height, width) for im in group):
+                        raise ValueError("images must be (height, width, 3|4) uint8 arrays of one shape")
+                    kw = {k: v for k, v in kwargs.items() if k != "verbose"}
+                    return [(r[0], r[4], r[2], r[5]) for r in quantize_u8_batch(group, palette_size, weights=ws, want_quantized=False, **kw)]
+                return quantize_batch(width, height, group, palette_size, weights=ws, **kwargs)
+
             for g0 in range(0, n, 6):                             # groups of six bound the host memory held at once
                 grp = list(range(g0, min(g0 + 6, n)))
-                group = [get(idx[j]) for j in grp]
-                ws = None if weights is None else [weights[idx[j]] for j in grp]
                 try:
-                    if all(getattr(im, "dtype", None) == np.uint8 and getattr(im, "ndim", 0) == 3 for im in group):
-                        # 8-bit images as decoded, (H, W, 3|4): 3 bytes per pixel over PCIe instead of 24
-                        kw = {k: v for k, v in kwargs.items() if k != "verbose"}
-                        res = [(r[0], r[4], r[2], r[5]) for r in quantize_u8_batch(group, palette_size, weights=ws, want_quantized=False, **kw)]
-                    else:
-                        res = quantize_batch(width, height, group, palette_size, weights=ws, **kwargs)
-                except (ValueError, np.linalg.LinAlgError) as e:  # saliency stage: shape (-5) / singular covariance (-6)
-                    code = -6 if isinstance(e, np.linalg.LinAlgError) else -5
-                    messages[code] = str(e)
-                    res = [(False, None, None, str(e))] * len(grp)
+                    for j, r in zip(grp, run_group(grp)):
+                        put(j, r)
+                except Exception:                                 # noqa: BLE001 -- find the culprit: one image at a time
                     for j in grp:
-                        put(j, res[0], code)
-                    continue
-                for j, r in zip(grp, res):
-                    put(j, r)
+                        try:
+                            put(j, run_group([j])[0])
+                        except Exception as e:                    # noqa: BLE001
+                            fail(j, e)
         else:
             for j, i in enumerate(idx):
-                w = None if weights is None else weights[i]
-                put(j, quantize_fn(width, height, get(i), palette_size, weights=w, **kwargs))
+                try:
+                    w = None if weights is None else weights[i]
+                    put(j, quantize_fn(width, height, get(i), palette_size, weights=w, **kwargs))
+                except Exception as e:                            # noqa: BLE001
+                    fail(j, e)
+
+    # what a failing image raised travels with its exit code (fixed 240-byte rows), so the root reports the real reason
+    texts = np.zeros((n, 240), dtype=np.uint8)
+    for j, i in enumerate(idx):
+        if i in errors:
+            raw = errors[i].encode("UTF-8", "replace")[:240]
+            texts[j, :len(raw)] = np.frombuffer(raw, dtype=np.uint8)
 
     if dist is None:
-        g_code, g_pal, g_map = [codes], [pals], [maps.cpu().numpy() if hasattr(maps, "cpu") else maps]
+        g_code, g_pal, g_map, g_txt = [codes], [pals], [maps.cpu().numpy() if hasattr(maps, "cpu") else maps], [texts]
     else:
         g_code = gather_to_root(codes, dist, device=device)
+        g_txt = gather_to_root(texts, dist, device=device)
         g_pal = gather_to_root(pals, dist, device=device)
         g_map = gather_to_root(maps, dist, device=device) if have_map else None
         if rank != 0:
@@ -219,6 +264,8 @@ def quantize_batch_sharded(width, height, images, palette_size, dist=None, quant
             code = int(g_code[r][j, 0])
             msg = messages.get(code, MESSAGES[-1])
             if code != 0:
+                why = bytes(g_txt[r][j]).rstrip(b"\0").decode("UTF-8", "replace")
+                msg = why if why and code in (-5, -6) else (msg + " (" + why + ")" if why else msg)
                 out.append((False, None, None, msg))
             else:
                 m = None

@@ -31,6 +31,19 @@ def main():
     n = w * h
     images = [ob.image(n, 40 + i).reshape(3, n).T.copy() for i in range(count)]
     res = pdist.quantize_batch_sharded(w, h, images, K, dist=dist, quantize_fn=oracle_quantize, dither=False, kmeans_niter=0)
+    # a failing image must not strand the other rank in the gathers: image 1 (rank 0's block) is malformed, the loader of
+    # image 4 (rank 1's block) raises; both come back as failures with the reason, the rest as usual
+    def loader(i):
+        if i == 4:
+            raise OSError("cannot decode image 4")
+        return images[i][:, :2] if i == 1 else images[i]
+
+    def checked_quantize(width, height, colors, palette_size, **kw):
+        if np.asarray(colors).shape != (width * height, 3):
+            raise ValueError("bad shape %s" % (np.asarray(colors).shape,))
+        return oracle_quantize(width, height, colors, palette_size, **kw)
+    res_bad = pdist.quantize_batch_sharded(w, h, loader, K, dist=dist, quantize_fn=checked_quantize, count=count, dither=False,
+                                           kmeans_niter=0)
     # timing protocol of bench.py: barrier, then max-over-ranks of a per-rank scalar
     import torch
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
@@ -76,6 +89,9 @@ def main():
         assert len(res) == count
         single = [oracle_quantize(w, h, im, K, dither=False, kmeans_niter=0) for im in images]
         ok = all(r[0] and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2]) for r, s in zip(res, single))
+        ok = ok and [r[0] for r in res_bad] == [True, False, True, True, False]
+        ok = ok and "bad shape" in res_bad[1][3] and "cannot decode image 4" in res_bad[4][3]
+        ok = ok and all(np.array_equal(res_bad[i][1], single[i][1]) and np.array_equal(res_bad[i][2], single[i][2]) for i in (0, 2, 3))
         shards = [pdist.shard(count, r, world) for r in range(world)]
         with open(out_path, "w") as f:
             f.write("OK" if ok and split_ok and shards == [(0, 3), (3, 2)] else "MISMATCH")

@@ -46,6 +46,12 @@ def main():
     # a failing image must not hang the collective: a flat image has a singular border covariance (exit code -6)
     bad = [small[0], np.full((96, 128, 3), 7, dtype=np.uint8)]
     resb = pdist.quantize_batch_sharded(128, 96, bad, 24, dist=dist, dither=False, kmeans_niter=0)
+    # ... nor may a malformed one (two channels; wrong size) or a loader that raises: they fail before the library is called
+    def loader(i):
+        if i == 2:
+            raise OSError("cannot decode image 2")
+        return [small[0], small[1][:, :, :2], None, small[2][:50]][i]
+    resm = pdist.quantize_batch_sharded(128, 96, loader, 24, dist=dist, count=4, dither=False, kmeans_niter=0)
     ok = True
     notes = []
     if rank == 0:
@@ -63,10 +69,15 @@ def main():
         okb = resb[0][0] and (not resb[1][0]) and resb[1][1] is None and "singular" in resb[1][3].lower()
         notes.append("failure tuple %s: %s" % ("ok" if okb else "WRONG", resb[1][3]))
         ok = ok and okb
+        one = p.quantize_u8(small[0], 24, dither=False, kmeans_niter=0)
+        okm = [r[0] for r in resm] == [True, False, False, False] and "cannot decode image 2" in resm[2][3] and \
+            np.array_equal(resm[0][1], one[4]) and np.array_equal(resm[0][2], one[2].reshape(-1))
+        notes.append("malformed images %s: %s" % ("ok" if okm else "WRONG", [r[3] for r in resm]))
+        ok = ok and okm
         with open(out_path, "w") as f:
             f.write(("OK\n" if ok else "MISMATCH\n") + "\n".join(notes))
     else:
-        assert res is None and res8 is None and resb is None
+        assert res is None and res8 is None and resb is None and resm is None
     dist.barrier()
     dist.destroy_process_group()
 
