@@ -175,9 +175,16 @@ def host_to_host(L, native, cfg, reps=3):
     finally:
         L.patolette_amd_free(d)
     wts = None
-    if weighted is True:
-        from oracle import binding as ob            # the synthetic weights generator only (inputs, not results)
-        wts = ob.weights(n, 55)
+    if weighted is True:                            # the library's own generator (SURVEY.md 8(d) weights), brought to the host
+        dw = L.patolette_amd_malloc(n * 8)
+        if not dw:
+            return None
+        wts = np.empty(n)
+        try:
+            assert L.patolette_amd_fill_weights(dw, n, 55) == 0
+            assert L.patolette_amd_memcpy_d2h(wts.ctypes.data_as(C.c_void_p), dw, wts.nbytes) == 0
+        finally:
+            L.patolette_amd_free(dw)
     opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
     pal = np.zeros((K, 3), dtype=np.float64, order="F")
     pmap = np.zeros(n, dtype=np.uintp)

@@ -488,6 +488,7 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
     const double lo0 = g.lo[0], lo1 = g.lo[1], lo2 = g.lo[2], in0 = g.inv[0], in1 = g.inv[1], in2 = g.inv[2];
     const unsigned long long ltmask = (1ULL << lane) - 1ULL;
     int qn = 0;                                                                   // wave-uniform
+    const bool out_even = (reinterpret_cast<size_t>(out) & 1) == 0;               // packed two-byte stores need an even address
     for (; base < n; base += step) {
         double x[P], y[P], z[P];
 #pragma unroll
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
             ovbits |= ov ? (1u << p) : 0u;
         }
         // results: parked pixels get a 0 for now, the drain writes theirs later (same wavefront, program order)
-        if (left == (unsigned)tile && sizeof(OutT) == 1) {
+        if (left == (unsigned)tile && sizeof(OutT) == 1 && out_even) {               // (an odd `out`: image i of a batch with odd N)
 #pragma unroll
             for (int gq = 0; gq < P / 2; gq++)
                 reinterpret_cast<unsigned short *>(ob)[64 * gq + lane] = (unsigned short)((bests[2 * gq] & 0xffu) | (bests[2 * gq + 1] << 8));
@@ -563,6 +564,9 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
                 }
                 qn += take; done += take;
                 if (qn == kMidQueue || (lasttile && done == btot)) {
+                    // a parked pixel's provisional result was stored above by ANOTHER lane of this wavefront: the fence orders
+                    // the two stores (wavefront scope: no instruction, the wave's stores to one address already leave in order)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     if (lane < qn) {
                         const double px = qx[lane], py = qy[lane], pz = qz[lane];
                         const size_t cell = nn_cell(px, py, pz, G, lo0, lo1, lo2, in0, in1, in2);

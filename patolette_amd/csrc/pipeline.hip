@@ -218,7 +218,8 @@ struct Engine {
     int device = -1;
     hipStream_t stream = nullptr;
     const Shard *shard = nullptr;    // set for the duration of a sliced call
-    bool invariant = getenv("PAMD_INVARIANT_SUMS") && atoi(getenv("PAMD_INVARIANT_SUMS")) != 0;   // tiling-invariant children moments (always on while `shard` is set)
+    bool invariant = false;          // tiling-invariant children moments (always on while `shard` is set); a property of the CALLING
+                                     // THREAD (tl_invariant), copied in whenever an engine starts serving a thread or a batch
     DevBuf<unsigned char> commbuf;
     PinBuf<unsigned char> h_comm;
     DevBuf<int> shard_ids;
@@ -281,19 +282,28 @@ struct Engine {
 namespace {
 std::mutex g_pool_mu;
 std::vector<Engine *> g_pool;
-Engine *pool_acquire(int device) {               // device < 0: any
+// patolette_amd_set_invariant_sums: the caller's setting lives with the calling thread, not with a pooled engine (an engine
+// outlives the thread it served and is handed to others).  -1 = not set: the environment's default.
+thread_local int tl_invariant = -1;
+bool invariant_default() {
+    static const bool env = getenv("PAMD_INVARIANT_SUMS") && atoi(getenv("PAMD_INVARIANT_SUMS")) != 0;
+    return tl_invariant < 0 ? env : tl_invariant != 0;
+}
+Engine *pool_acquire(int device, bool invariant) {   // device < 0: the current device is unknown -> only an engine bound to no GPU yet
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         for (size_t i = 0; i < g_pool.size(); i++)
-            if (device < 0 || g_pool[i]->device == device || g_pool[i]->device < 0) {
+            if (g_pool[i]->device == device || g_pool[i]->device < 0) {
                 Engine *e = g_pool[i];
                 g_pool.erase(g_pool.begin() + i);
                 if (e->device < 0) e->device = device;
+                e->invariant = invariant;
                 return e;
             }
     }
     Engine *e = new Engine;
     e->device = device;
+    e->invariant = invariant;
     return e;
 }
 void pool_release(Engine *e) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool.push_back(e); }
@@ -309,7 +319,7 @@ static Engine &engine() {
     if (!h.e) {
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-        h.e = pool_acquire(dev);
+        h.e = pool_acquire(dev, invariant_default());
     }
     return *h.e;
 }
@@ -1394,15 +1404,19 @@ static const char *kMessages[8] = {                                        // pa
         return ret_fail;                                                     \
     }
 
+static int comm_ok(const patolette_amd__Comm *comm) {
+    return comm && comm->allreduce_sum && comm->size >= 1 && comm->rank >= 0 && comm->rank < comm->size;
+}
 static int slice_args_ok(size_t total_pixels, size_t slice_begin, size_t slice_pixels, const void *slice_data,
-                         const patolette__QuantizationOptions *options, const patolette_amd__Comm *comm, const void *slice_map) {
-    return comm && comm->allreduce_sum && comm->size >= 1 && comm->rank >= 0 && comm->rank < comm->size && slice_pixels > 0 &&
-           slice_begin <= total_pixels && slice_pixels <= total_pixels - slice_begin && slice_data &&
+                         const patolette__QuantizationOptions *options, const void *slice_map) {
+    return slice_pixels > 0 && slice_begin <= total_pixels && slice_pixels <= total_pixels - slice_begin && slice_data &&
            (options->palette_only || slice_map);
 }
 // runs `body` on the calling thread's engine with the slice description attached
+// args_ok: this rank's arguments passed slice_args_ok.  A rank that returned early on bad arguments would leave its peers
+// waiting in the first collective for ever, so the verdicts are summed over the group first and every rank fails together.
 template <typename F>
-static void slice_entry(size_t total_pixels, size_t slice_begin, const patolette_amd__Comm *comm, int *exit_code, F body) {
+static void slice_entry(size_t total_pixels, size_t slice_begin, const patolette_amd__Comm *comm, bool args_ok, int *exit_code, F body) {
     Shard sh;
     sh.total = total_pixels; sh.begin = slice_begin; sh.comm = *comm;
     Engine *Ep = nullptr;
@@ -1411,6 +1425,10 @@ static void slice_entry(size_t total_pixels, size_t slice_begin, const patolette
         Ep = &E;
         E.init();
         E.shard = &sh;
+        int bad = args_ok ? 0 : 1;
+        comm_sum_host(E, &bad, 1, 2);
+        if (bad) throw HipError(args_ok ? "patolette_amd_slice: another rank of the group passed unusable arguments"
+                                        : "patolette_amd_slice: unusable arguments (empty slice, slice outside the image, missing buffer)");
         body(E);
         E.shard = nullptr;
         *exit_code = 0;
@@ -1485,8 +1503,9 @@ void patolette_amd_slice(size_t total_pixels, size_t slice_begin, size_t slice_p
                          const patolette_amd__Comm *comm, double *palette, size_t *slice_map, int *exit_code) {
     *exit_code = validate(total_pixels, 1, palette_size);
     if (*exit_code != 0) return;
-    if (!slice_args_ok(total_pixels, slice_begin, slice_pixels, slice_data, options, comm, slice_map)) { *exit_code = -1; return; }
-    slice_entry(total_pixels, slice_begin, comm, exit_code, [&](Engine &E) {
+    if (!comm_ok(comm)) { *exit_code = -1; return; }              // (validate() above is the same on every rank)
+    slice_entry(total_pixels, slice_begin, comm, slice_args_ok(total_pixels, slice_begin, slice_pixels, slice_data, options, slice_map),
+                exit_code, [&](Engine &E) {
         run_host(E, slice_pixels, 1, slice_data, slice_weights, 0.0, palette_size, options, palette, slice_map);
     });
 }
@@ -1497,8 +1516,9 @@ void patolette_amd_slice_device(size_t total_pixels, size_t slice_begin, size_t 
                                 int *exit_code) {
     *exit_code = validate(total_pixels, 1, palette_size);
     if (*exit_code != 0) return;
-    if (!slice_args_ok(total_pixels, slice_begin, slice_pixels, d_slice_data, options, comm, d_slice_map)) { *exit_code = -1; return; }
-    slice_entry(total_pixels, slice_begin, comm, exit_code, [&](Engine &E) {
+    if (!comm_ok(comm)) { *exit_code = -1; return; }
+    slice_entry(total_pixels, slice_begin, comm, slice_args_ok(total_pixels, slice_begin, slice_pixels, d_slice_data, options, d_slice_map),
+                exit_code, [&](Engine &E) {
         std::vector<double> pal(3 * palette_size);
         run_device(E, slice_pixels, 1, Pixels{d_slice_data, nullptr, 3}, d_slice_weights, palette_size, options, pal.data(), d_slice_map,
                    map_elem_bytes);
@@ -1507,9 +1527,10 @@ void patolette_amd_slice_device(size_t total_pixels, size_t slice_begin, size_t 
 }
 
 int patolette_amd_set_invariant_sums(int on) {
-    Engine &E = engine();
-    const int before = E.invariant ? 1 : 0;
-    E.invariant = on != 0;
+    const int before = invariant_default() ? 1 : 0;
+    tl_invariant = on != 0 ? 1 : 0;
+    EngineHolder &h = holder();
+    if (h.e) h.e->invariant = on != 0;                // the engine already serving this thread; later ones copy tl_invariant
     return before;
 }
 
@@ -1563,7 +1584,7 @@ int patolette_amd_set_device(int ordinal) {
     if (hipSetDevice(ordinal) != hipSuccess) return -1;
     EngineHolder &h = holder();
     if (h.e && h.e->stream && h.e->device != ordinal) { pool_release(h.e); h.e = nullptr; }   // bound to another GPU: swap engines
-    if (!h.e) h.e = pool_acquire(ordinal);
+    if (!h.e) h.e = pool_acquire(ordinal, invariant_default());
     h.e->device = ordinal;
     return 0;
 }
@@ -1574,7 +1595,10 @@ void patolette_amd_release_workspace(void) {
     std::vector<Engine *> victims;
     if (h.e) { victims.push_back(h.e); h.e = nullptr; }
     { std::lock_guard<std::mutex> lk(g_pool_mu); victims.insert(victims.end(), g_pool.begin(), g_pool.end()); g_pool.clear(); }
+    int cur = -1;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;      // ~Engine selects the engine's GPU: put the caller's back
     for (Engine *e : victims) delete e;
+    if (have_cur) (void)hipSetDevice(cur);
 }
 const char *patolette_amd_last_error(void) { return engine().last_error.c_str(); }
 void *patolette_amd_malloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; return p; }
@@ -1674,11 +1698,12 @@ static void batch_run(size_t count, size_t width, size_t height, const patolette
         }
     }
     std::atomic<size_t> next{0};
+    const bool invariant = invariant_default();
     auto work = [&]() {
         Engine *E = nullptr;
         try {
             (void)hipSetDevice(device);
-            E = pool_acquire(device);
+            E = pool_acquire(device, invariant);                 // the CALLER's setting (this may be a helper thread)
             E->init();
         } catch (const std::exception &ex) {
             fprintf(stderr, "patolette: %s\n", ex.what());

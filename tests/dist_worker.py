@@ -50,9 +50,9 @@ def main():
     dist.barrier()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert float(t.item()) == float(world)
-    # within-image sharding (patolette_amd/split.py): each rank holds half of one node's pixels; the all-reduced moment table and
+    # within-image sharding (tests/split_model.py): each rank holds half of one node's pixels; the all-reduced moment table and
     # the cut must equal, bit for bit, what the whole node gives in one process
-    from patolette_amd import split as psplit
+    from tests import split_model as psplit
     rng = np.random.default_rng(77)
     npx = 30001
     c = rng.random((npx, 3))

@@ -85,6 +85,14 @@ class Cells:
         q = self.w1[:, b] - self.w1[:, a]
         return self.w2[b] - self.w2[a] - ((q[0] ** 2 + q[1] ** 2) + q[2] ** 2) / float(self.w0[b] - self.w0[a])
 
+    def distortion_to(self, a, b):
+        """distortion(a[i], b) for an array of lower ends: the expression of cells.c:141-182 element-wise."""
+        q = self.w1[:, b][:, None] - self.w1[:, a]
+        n = (self.w0[b] - self.w0[a]).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = self.w2[b] - self.w2[a] - ((q[0] ** 2 + q[1] ** 2) + q[2] ** 2) / n
+        return np.where(self.w0[a] == self.w0[b], 0.0, d)
+
     def vcov(self, a, b):                                         # cells.c:184-259
         m = np.zeros((3, 3))
         if self.w0[a] != self.w0[b]:
@@ -157,13 +165,14 @@ def principal_quantizer(K, cells):
             break
         E_ = E.copy()
         for n in range(k + 1, N + 1):
-            cut, e = n - 1, E_[n - 1]
-            for t in range(n - 2, k - 2, -1):                     # t = n-2 down to k-1
-                c = E_[t] + cells.distortion(t, n)
-                if c < e:
-                    cut, e = t, c
-            L[(k, n)] = cut
-            E[n] = e
+            # global.c:252-272: cut = n-1, e = E_[n-1]; then t = n-2 down to k-1: `if (c < e)` takes it.  A strict '<' scanned
+            # downwards keeps the FIRST minimum of (E_[n-1], c(n-2), c(n-3), ...), which is what argmin returns; the candidates
+            # are evaluated element-wise with the same expression as Cells.distortion (no reassociation).
+            ts = np.arange(n - 2, k - 2, -1)
+            cand = np.concatenate(([E_[n - 1]], E_[ts] + cells.distortion_to(ts, n)))
+            j = int(np.argmin(cand))
+            L[(k, n)] = n - 1 if j == 0 else int(ts[j - 1])
+            E[n] = cand[j]
         result = chain(k)
     return result
 
@@ -222,22 +231,26 @@ def split_cluster(c, w, idx, extended=False):
     if ww is None:
         sizes = np.bincount(bmap, minlength=BUCKETS).astype(np.uint64)
     else:
-        for b, x in zip(bmap, ww):
-            sizes[b] = np.uint64(float(sizes[b]) + x)
+        order = np.argsort(bmap, kind="stable")                  # per bucket, members in index order
+        bs, xs = bmap[order], ww[order]
+        starts = np.flatnonzero(np.r_[True, bs[1:] != bs[:-1]])
+        for a, e in zip(starts, np.r_[starts[1:], len(bs)]):
+            acc = 0
+            for x in xs[a:e].tolist():
+                acc = int(float(acc) + x)                         # size_t += double: converted back to an integer every step
+            sizes[bs[a]] = np.uint64(acc)
     sizes = np.cumsum(sizes)
+    # local.c:147-170, all 512 cuts at once (element-wise: the same operations in the same order per cut):
+    # objective[i] += (sl != 0 ? csl*csl/sl : 0) + (sr != 0 ? csr*csr/sr : 0), channel after channel
     obj = np.zeros(BUCKETS, dtype=ft)
-    for i in range(BUCKETS):
-        for j in range(3):
-            csl = sums[j, i]
-            csr = sums[j, BUCKETS - 1] - csl
-            sl = ft(sizes[i])
-            sr = ft(sizes[BUCKETS - 1]) - sl
-            v = ft(0)
-            if sl != 0:
-                v += (csl * csl) / sl
-            if sr != 0:
-                v += (csr * csr) / sr
-            obj[i] += v
+    sl = sizes.astype(ft)
+    sr = ft(sizes[BUCKETS - 1]) - sl
+    for j in range(3):
+        csl = sums[j]
+        csr = sums[j, BUCKETS - 1] - csl
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = np.where(sl != 0, (csl * csl) / sl, ft(0)) + np.where(sr != 0, (csr * csr) / sr, ft(0))
+        obj = obj + v
     split = int(np.argmax(obj))                                   # vector.c:26-46 maxloc: strict '>' upwards = first maximum
     left = idx[bmap <= split]
     right = idx[bmap > split]
@@ -261,9 +274,11 @@ def lq_quantize(c, w, clusters, K):
         if ch is None:
             return 0.0
         return D(result[i]) - (D(ch[0]) + D(ch[1]))
+    # local.c:277-307 recomputes every benefit at every step from cached distortions: the values of untouched entries do
+    # not change, so they are kept and only the two entries a step rewrites are evaluated again
+    ben = [benefit(j) for j in range(len(result))]
     for i in range(len(clusters), K):
-        ben = np.array([benefit(j) for j in range(i)])
-        best = int(np.argmax(ben))
+        best = int(np.argmax(np.array(ben)))                      # first maximum
         if ben[best] < DELTA:
             break
         left, right = children[best]
@@ -272,6 +287,8 @@ def lq_quantize(c, w, clusters, K):
         result[best] = right
         children[i] = split_cluster(c, w, left)
         children[best] = split_cluster(c, w, right)
+        ben.append(benefit(i))
+        ben[best] = benefit(best)
     return result
 
 
@@ -366,4 +383,51 @@ def dither(img, width, height, pal):
         out[y * width + x] = idx
         q[:-1] = q[1:]
         q[15] = p - pal[idx]
+    return out
+
+
+# ---- patolette() (lib/src/patolette.c:157-343): stage sequencing and colour-space routing ------------------------------
+def patolette(width, height, colors, weights, K, dither, palette_only, color_space, kmeans_niter, kmeans_max_samples, conv, kmeans):
+    """The orchestrator read from patolette.c:157-343, over this file's GQ / LQ / NN map / dither.  `conv(name, (n,3))` and
+    `kmeans(colors, weights, centers, niter, max_samples)` are the two stages reference builds DO pin in this image (the
+    colour code, `oracle/_ref/libref_color.so`; faiss, `libref_faiss.so`): the caller passes them in.  Returns
+    (palette (K,3) with -1 rows for unset entries, map or None)."""
+    SRGB, LUV, ICTCP = 0, 1, 2
+    c = np.array(colors, dtype=np.float64, copy=True)            # Matrix2D_init copies (patolette.c:187-191)
+    if color_space == LUV:                                        # :201-207
+        c = conv("srgb_to_cieluv", c)
+    elif color_space == ICTCP:
+        c = conv("srgb_to_ictcp", c)
+    q = quantize_clusters(c, weights, K)                          # :213-245 GQ then LQ
+    if q is None:
+        return None
+    centers, member, _ = q
+    pal = kmeans(c, weights, centers, kmeans_niter, kmeans_max_samples) if kmeans_niter > 0 else centers   # :247-264
+    pmap = None
+    if not palette_only:                                          # :266 -- palette_only skips the map AND the back-conversion
+        if dither:                                                # :267-299
+            to_rec = {LUV: "cieluv_to_rec2020", ICTCP: "ictcp_to_rec2020", SRGB: "srgb_to_rec2020"}[color_space]
+            c = conv(to_rec, c)
+            pal = conv(to_rec, pal)
+            pmap = dither_map(c, width, height, pal)
+            pal = conv("rec2020_to_srgb", pal)
+        else:                                                     # :300-324
+            if color_space == LUV:                                # "pretty ugly": Luv -> Rec2020 -> sRGB -> ICtCp, pixels and palette
+                for name in ("cieluv_to_rec2020", "rec2020_to_srgb", "srgb_to_ictcp"):
+                    c = conv(name, c)
+                    pal = conv(name, pal)
+            pmap = nn_map(c, pal)
+            # :322-323 unconditionally: in the sRGB colour space the palette (sRGB values) goes through the ICtCp -> Rec2020 ->
+            # sRGB conversions all the same
+            pal = conv("ictcp_to_rec2020", pal)
+            pal = conv("rec2020_to_srgb", pal)
+    out = np.full((K, 3), -1.0)                                   # :327-336
+    out[:len(pal)] = pal
+    return out, pmap
+
+
+def dither_map(img, width, height, pal):
+    out = dither(img, width, height, pal)
+    if max(width, height) <= 1:
+        return None                                               # riemersma.c:452-456: a 1x1 image is never visited
     return out

@@ -1,5 +1,5 @@
 """N > 1 paths on CPU: world_size-2 gloo run of the batch sharding + final gather, and the exchange protocol of the
-within-image sharding (patolette_amd/split.py)."""
+within-image sharding (tests/split_model.py)."""
 import os
 import subprocess
 import sys
@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from patolette_amd import dist as pdist
-from patolette_amd import split as psplit
+from tests import split_model as psplit
 from tests.util import ROOT
 
 

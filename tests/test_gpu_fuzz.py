@@ -41,7 +41,7 @@ def _case(rng):
 def test_random_configurations_match_the_oracle(gpu, ob, seed):
     import patolette_amd as p
     rng = np.random.default_rng(seed)
-    exact = reordered = degenerate = 0
+    exact = reordered = degenerate = dither_stage = 0
     for case in range(60):
         w, h, kind, colors, wts, o = _case(rng)
         ok, pal_g, map_g, _ = p.quantize(w, h, colors, o["K"], dither=o["dither"], color_space=o["cs"], tile_size=0,
@@ -60,6 +60,26 @@ def test_random_configurations_match_the_oracle(gpu, ob, seed):
             degenerate += 1
             if not o["dither"]:
                 assert rdiff <= 1e-9, desc
+            else:
+                # The palettes may differ by the reference's tie noise (above), but the dither stage is then still checked
+                # against the oracle's: the oracle's Riemersma walk over the same pixels with the palette the HIP path's
+                # mapping stage used (Rec2020, patolette.c:268-299) must give the HIP path's map, bit for bit.
+                import ctypes as C
+                K = o["K"]
+                mp = np.zeros((K, 3), order="F")
+                rows = gpu.patolette_amd_last_map_palette(mp.ctypes.data_as(C.POINTER(C.c_double)), K)
+                assert 1 <= rows <= K, desc
+                flat = ob.planar(colors)
+                if o["cs"] == 1:
+                    rec = ob.convert("cieluv_to_rec2020", ob.convert("srgb_to_cieluv", flat))
+                elif o["cs"] == 2:
+                    rec = ob.convert("ictcp_to_rec2020", ob.convert("srgb_to_ictcp", flat))
+                else:
+                    rec = ob.convert("srgb_to_rec2020", flat)
+                map_s = ob.dither(rec, w, h, np.ascontiguousarray(mp[:rows]))
+                if max(w, h) > 1:                                # the 1x1 walk visits nothing (riemersma.c:452-456)
+                    assert np.array_equal(map_g, map_s), desc
+                dither_stage += 1
             continue
         rows_g = sorted(map(tuple, np.round(pal_g[pal_g[:, 0] >= 0], 9).tolist()))
         rows_o = sorted(map(tuple, np.round(pal_o[pal_o[:, 0] >= 0], 9).tolist()))

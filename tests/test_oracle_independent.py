@@ -95,3 +95,75 @@ def test_dither_matches_independent_reading(ob, w, h, k, seed):
     want = ir.dither(img, w, h, pal)
     got = ob.dither(flat, w, h, pal).astype(np.int64)
     assert np.array_equal(got, want)
+
+
+# ---- K = 256: the configuration every BASELINE config uses (254 greedy commits, deep candidate trees) ----------------
+@pytest.mark.parametrize("kind,n,weighted,seed", [("ictcp", 65536, False, 31), ("luv", 70000, True, 32), ("blobs", 65536, True, 33),
+                                                  ("modes", 66000, False, 34)])
+def test_gq_lq_at_256_colours_matches_independent_reading(ob, kind, n, weighted, seed):
+    """As above at K = 256 on >= 65 536 colours: every one of the ~254 greedy commits (palette ORDER), the membership of every
+    colour and the centres."""
+    K = 256
+    c = dataset(kind, n, 300 + seed, ob)
+    w = (1.0 + 3.0 * np.random.default_rng(seed).random(n) ** 3) if weighted else None
+    centers, member, nbase = ir.quantize_clusters(c, w, K)
+    got = ob.quantize_clusters(np.ascontiguousarray(c.T).reshape(-1), w, n, K)
+    assert got["rc"] == 0 and got["n_base"] == nbase and got["n_clusters"] == len(centers) == K
+    assert np.array_equal(got["member"].astype(np.int64), member)
+    assert np.allclose(got["centers"][:K], centers, rtol=0, atol=1e-12 * max(1.0, np.abs(centers).max()))
+
+
+# ---- the orchestrator: stage sequencing and colour-space routing of lib/src/patolette.c:157-343 ----------------------
+def _pinned_stages(ob):
+    """The two stages reference builds pin in this image (colour code: libref_color.so; KMeans: libref_faiss.so), through the
+    oracle's entry points that tests/test_oracle_pinning.py holds to those builds bit for bit."""
+    def conv(name, a):
+        n = a.shape[0]
+        return ob.convert(name, np.ascontiguousarray(a.T).reshape(-1)).reshape(3, n).T.copy()
+
+    def kmeans(c, w, centers, niter, max_samples):
+        return ob.kmeans_refine(np.ascontiguousarray(c.T).reshape(-1), w, c.shape[0], np.ascontiguousarray(centers), niter, max_samples)
+    return conv, kmeans
+
+
+@pytest.mark.parametrize("niter", [0, 3])
+@pytest.mark.parametrize("palette_only", [False, True])
+@pytest.mark.parametrize("dither", [False, True])
+@pytest.mark.parametrize("color_space", [0, 1, 2])
+def test_orchestrator_routing_matches_independent_reading(ob, color_space, dither, palette_only, niter):
+    """All three colour spaces x dither / NN map x palette_only x KMeans on/off: the CIELuv -> Rec2020 -> sRGB -> ICtCp detour of
+    the NN map, the ICtCp back-conversion the sRGB palette goes through all the same (patolette.c:322-323), palette_only
+    returning the palette in the quantisation space, the -1 rows."""
+    w_, h_, K = 37, 29, 24
+    n = w_ * h_
+    seed = 500 + 7 * color_space + 3 * int(dither) + int(palette_only) + 11 * niter
+    flat = ob.image(n, seed)
+    colors = flat.reshape(3, n).T.copy()
+    weights = (1.0 + 2.0 * np.random.default_rng(seed).random(n)) if (seed % 2) else None
+    conv, kmeans = _pinned_stages(ob)
+    want = ir.patolette(w_, h_, colors, weights, K, dither, palette_only, color_space, niter, 512 ** 2, conv, kmeans)
+    assert want is not None
+    ec, pal, pmap = ob.patolette(w_, h_, flat, weights, K, dither=dither, palette_only=palette_only, color_space=color_space,
+                                 kmeans_niter=niter, kmeans_max_samples=512 ** 2)
+    assert ec == 0
+    assert np.allclose(pal, want[0], rtol=0, atol=1e-12 * max(1.0, np.abs(want[0]).max()))
+    if palette_only:
+        assert pmap is None and want[1] is None
+    else:
+        assert np.array_equal(pmap.astype(np.int64), want[1])
+
+
+def test_orchestrator_more_colours_than_pixels_and_unset_rows(ob):
+    """K > pixel count: the clusters run out, the unset palette rows are -1 (patolette.c:327-336)."""
+    w_, h_, K = 5, 4, 40
+    n = w_ * h_
+    flat = ob.image(n, 77)
+    conv, kmeans = _pinned_stages(ob)
+    want = ir.patolette(w_, h_, flat.reshape(3, n).T.copy(), None, K, False, False, 2, 0, 512 ** 2, conv, kmeans)
+    ec, pal, pmap = ob.patolette(w_, h_, flat, None, K, dither=False, color_space=2, kmeans_niter=0)
+    assert ec == 0 and np.array_equal(pal == -1.0, want[0] == -1.0) and (pal == -1.0).any()
+    # the last splits are of two-colour clusters: rank-1 covariance, the eigenvector SIGN -- which child is "left" -- is rounding
+    # noise that differs between LAPACK builds (DESIGN.md section 2), so two palette rows may trade places: same rows, same image
+    from tests.util import match_rows_up_to_permutation
+    assert match_rows_up_to_permutation(pal, want[0], 1e-12) is not None
+    assert np.array_equal(pal[pmap], want[0][want[1]])
