@@ -320,6 +320,16 @@ def main():
         if not args.no_profile and i == args.warmup - 1:
             _native.profile(True)
         run.step(i)
+        if dist is not None:
+            # a warm-up step is a whole step: its maps are gathered too (the first gather sets up RCCL's channels and buffers)
+            part = warm_t[:S]
+            gl = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
+            dist.gather(part, gl, dst=0)
+            pw_t = torch.from_numpy(pals[i * S:(i + 1) * S]).to("cuda")
+            gp = [torch.empty_like(pw_t) for _ in range(world)] if rank == 0 else None
+            dist.gather(pw_t, gp, dst=0)
+            torch.cuda.synchronize()
+            del gl, gp
     if not args.no_profile and args.warmup > 0:
         L.patolette_amd_synchronize()
         pw = _native.profile_results()

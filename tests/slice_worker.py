@@ -29,7 +29,7 @@ def smooth(w, h):
     return np.stack([r, g, b], axis=-1).reshape(-1, 3)
 
 
-def oracle_verdict(pal_g, map_g, pal_o, map_o, degenerate):
+def oracle_verdict(pal_g, map_g, pal_o, map_o, degenerate, colors=None):
     """The rules of tests/test_gpu_fuzz.py: generic content agrees exactly (palette 1e-9, map bit for bit); a cluster with a
     rank-deficient covariance may swap two palette rows (same set, same image); content with a handful of distinct colours
     must reconstruct the same image."""
@@ -39,7 +39,15 @@ def oracle_verdict(pal_g, map_g, pal_o, map_o, degenerate):
         return "same"
     rdiff = float(np.max(np.abs(pal_g[map_g] - pal_o[map_o])))
     if degenerate:
-        return "same image" if rdiff <= 1e-9 else "DIFFERS (image, %.3g)" % rdiff
+        # A handful of distinct colours: the reference's cut decisions are exact ties decided by the rounding noise of its
+        # sequential sums -- it may keep EMPTY clusters, whose KMeans treatment (Clustering.cpp:216-263)
+        # then perturbs a populated centroid by 1/1024.  The HIP path's sums are exact; what can be demanded is that its image
+        # is the input itself (to f32 rounding when KMeans ran) and lies within that perturbation of the reference's.
+        if rdiff <= 1e-9:
+            return "same image"
+        exact = colors is not None and float(np.max(np.abs(pal_g[map_g] - colors))) <= 2e-6
+        return "reproduces the input exactly; the reference is within its empty-cluster perturbation (%.3g)" % rdiff \
+            if exact and rdiff <= 2.0 / 1024 else "DIFFERS (image, %.3g)" % rdiff
     rows_g = sorted(map(tuple, np.round(pal_g[pal_g[:, 0] >= 0], 9).tolist()))
     rows_o = sorted(map(tuple, np.round(pal_o[pal_o[:, 0] >= 0], 9).tolist()))
     return "same set, same image" if rows_g == rows_o and rdiff <= 1e-9 else "DIFFERS (palette max %.3g, image %.3g)" % (
@@ -113,7 +121,7 @@ def main():
         for tag, got in (("invariant", one), ("default", fast)):
             v = "FAILED"
             if got[0] and ec == 0:
-                v = oracle_verdict(got[1], got[2], pal_o, map_o, degenerate="degenerate" in name or "constant" in name)
+                v = oracle_verdict(got[1], got[2], pal_o, map_o, degenerate="degenerate" in name or "constant" in name, colors=colors)
             verdicts.append("%s sums vs oracle: %s" % (tag, v))
             ok = ok and not v.startswith("DIFFERS") and v != "FAILED"
         notes.append("%s: %s (rows %d, slice %d+%d; default sums %s the invariant ones; %s)"

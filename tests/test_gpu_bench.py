@@ -26,9 +26,9 @@ def _bench(*flags, timeout=900):
 
 @pytest.mark.gpu
 def test_rccl_path_on_one_rank_measures_what_the_plain_path_measures(gpu):
-    r0, plain = _bench("--gpus", "1", "--steps", "6", "--warmup", "2")
+    r0, plain = _bench("--gpus", "1", "--steps", "12", "--warmup", "3")
     assert r0.returncode == 0 and plain is not None, r0.stdout[-2000:] + r0.stderr[-2000:]
-    r1, dist = _bench("--gpus", "1", "--force-dist", "--steps", "6", "--warmup", "2")
+    r1, dist = _bench("--gpus", "1", "--force-dist", "--steps", "12", "--warmup", "3")
     assert r1.returncode == 0 and dist is not None, r1.stdout[-2000:] + r1.stderr[-2000:]
     assert plain["n_gpus"] == 1 and dist["n_gpus"] == 1
     assert "RCCL gather" in dist["config"]["final_gather"] and plain["config"]["final_gather"].startswith("none")
