@@ -76,6 +76,17 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes through DPP row shifts and row broadcasts (a __shfl_up loop is six LDS round trips)
+__device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8  -> inclusive within each row of 16
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // Block-wide sum of NV doubles per thread (exact addends -> any order); result valid in thread 0.
 // smem must hold NV * (blockDim.x / 64) doubles.
 template <int NV>

@@ -1359,16 +1359,6 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
 constexpr int kKmDirectCap = 4096;                                     // listed member records between two chain replays (64 KB of LDS)
 constexpr int kKmSortBlock = 1024;                                     // samples sorted together by one block of k_km_assign_sort
 
-// inclusive prefix sum over the 64 lanes through DPP row shifts and row broadcasts (a __shfl_up loop is six LDS round trips)
-__device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8  -> inclusive within each row of 16
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1 and 3
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2 and 3
-    return v;
-}
 // inclusive prefix over the threads of a block of up to 1024 (wsum: 16 words of LDS); *total = the block's sum
 __device__ __forceinline__ unsigned block_scan_incl_u32(const unsigned v, unsigned *wsum, unsigned *total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);

@@ -548,7 +548,7 @@ static void leaf_bound(HNode &h) {
 static void gq_prepare(Engine &E, size_t N, bool weighted) {
     hipStream_t s = E.stream;
     const size_t planes = weighted ? 4 : 3;
-    E.bufA.reserve(planes * N); E.bufB.reserve(planes * N); E.bkt.reserve(N);
+    E.bufA.reserve(planes * N + 64); E.bufB.reserve(planes * N + 64); E.bkt.reserve(N);   // + the slack k_scatter_bin's pixel-less lanes store to
     std::vector<HNode> hn(1);
     hn[0].begin = 0; hn[0].n = N;
     const std::vector<int> round = {0};

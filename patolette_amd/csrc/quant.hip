@@ -16,6 +16,8 @@
 // and the results are bit-reproducible for any launch geometry.
 #include "quant.h"
 
+#include <type_traits>
+
 namespace pamd {
 
 // --------------------------------------------------------------------------------------------
@@ -658,6 +660,176 @@ __global__ __launch_bounds__(256, INV ? 4 : 5) void k_scatter(QuantBuffers qb, c
     }
 }
 
+// The binary splits of the local quantiser (every sweep of k_scatter<., true, .> above), software-pipelined.  That kernel
+// makes one memory round trip after another -- eight bucket loads, then eight times (three pixel loads, wait, three stores),
+// the stores counted in the same in-order vmcnt as the loads -- and spends 81 % of its wavefront time parked with ~30 KB in
+// flight per CU, which is what 4.4 TB/s needs at ~2 us of latency and no more.  Here a wavefront issues ALL of a tile's
+// pixel loads (24, 32 with weights) first, then the NEXT tile's bucket loads; the offsets are worked out while the pixels
+// are on their way, and the next tile's ranks at the end of the trip, behind this tile's stores.  Nothing is waited for out
+// of issue order (gfx9's vmcnt retires loads and stores in the order they were issued: a wait for a late load is a wait
+// for everything before it), and what a trip hands to the next are ALU results (ranks, scalar offsets), never a load's
+// destination: a register copy of one, moved by the allocator behind the next trip's loads, would wait for this trip's stores.
+// Same pixels per thread, same order of the per-thread sums, same flush: bit-identical moments and layout.
+template <bool W, bool INV>
+__global__ __launch_bounds__(256, (W || INV) ? 2 : 3) void k_scatter_bin(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
+                                                                        const NodeDev *__restrict__ nodes_ro,
+                                                                        const unsigned long long *__restrict__ tileoff, const int from_end) {
+    constexpr int R = kTileP / 256;
+    static_assert(R * 4 == 32, "one 32-lane group per child");
+    __shared__ unsigned int wcnt[2][2][R * 4];               // [tile parity][child][r * 4 + wavefront]: members per (round, wavefront)
+    __shared__ double sm[28 * 4];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned long long ltmask = (1ULL << lane) - 1ULL;
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int bid = from_end ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
+    if (tfirst >= tlast) return;
+    constexpr int NP = INV ? 14 : 7;
+    double pl[NP], pr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) { pl[i] = 0; pr[i] = 0; }
+
+    // bucket ids of a tile, one per round (clamped inside the tile: no lane is switched off, nothing branches), and where each
+    // child's part of the tile starts (lane l asks for child l >> 5)
+    auto fetch_buckets = [&](const Tile &tt, const int ti, unsigned (&b)[R], unsigned long long &toff) {
+        const unsigned last = tt.count - 1u;
+#pragma unroll
+        for (int r = 0; r < R; r++) b[r] = qb.bkt[tt.start + min((unsigned)(r * 256) + threadIdx.x, last)];
+        toff = tileoff[(size_t)ti * kMaxChildren + (lane >> 5)];
+    };
+    // ranks: child of each pixel (k_cut's table is bucket > split), position among the wavefront's pixels of that child;
+    // the members per (round, wavefront) go to wcnt[par]
+    auto classify = [&](const Tile &tt, const unsigned (&b)[R], const int split, const int par, unsigned (&cr)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool valid = (unsigned)(r * 256) + threadIdx.x < tt.count;
+            const bool right = (int)b[r] > split;
+            const unsigned long long mR = __ballot(valid && right), mL = __ballot(valid && !right);
+            const unsigned rk = (unsigned)__popcll((right ? mR : mL) & ltmask);
+            cr[r] = (valid ? (right ? 1u : 0u) : 2u) | (rk << 8);
+            if (lane == 0) { wcnt[par][0][r * 4 + wid] = (unsigned)__popcll(mL); wcnt[par][1][r * 4 + wid] = (unsigned)__popcll(mR); }
+        }
+    };
+    auto lane64 = [](const unsigned long long v, const int l) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32) |
+               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    };
+    Tile t = tiles[tfirst];
+    unsigned cr[R];                                          // child (low byte, 2 = no pixel) | rank << 8, of the current tile
+    unsigned long long baseL, baseR;                         // where the children's parts of the current tile start (wave-uniform)
+    {
+        unsigned b0[R];
+        unsigned long long toff;
+        fetch_buckets(t, tfirst, b0, toff);
+        classify(t, b0, nodes_ro[t.node].split, 0, cr);
+        baseL = lane64(toff, 0); baseR = lane64(toff, 32);
+    }
+    for (int ti = tfirst; ti < tlast; ti++) {
+        const int par = (ti - tfirst) & 1;
+        const NodeDev &nd = nodes_ro[t.node];
+        const int child0 = nd.child0;
+        const double *sx = qb.buf[nd.buf], *sy = sx + qb.N, *sz = sy + qb.N, *sw = sz + qb.N;
+        double *dx = qb.buf[1 - nd.buf], *dy = dx + qb.N, *dz = dy + qb.N, *dw = dz + qb.N;
+        // 1. every pixel of the tile this thread moves: 3 (4) loads per round, all in flight at once
+        double x[R], y[R], z[R], w[R];
+        {
+            const unsigned last = t.count - 1u;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const size_t src = t.start + min((unsigned)(r * 256) + threadIdx.x, last);
+                x[r] = sx[src]; y[r] = sy[src]; z[r] = sz[src];
+                w[r] = 1.0;
+                if constexpr (W) w[r] = sw[src];
+            }
+        }
+        // 2. behind them, the next tile's buckets and offsets (straight-line: after the last tile the same tile is fetched
+        //    once more, so that the waits below count exactly)
+        const bool more = ti + 1 < tlast;                    // block-uniform
+        const int tnx = more ? ti + 1 : ti;
+        const Tile tn = tiles[tnx];
+        unsigned bkn[R];
+        unsigned long long toffn;
+        fetch_buckets(tn, tnx, bkn, toffn);
+        // 3. offsets: every wavefront scans the 2 x 32 counts itself, lane = child * 32 + (round * 4 + wavefront)
+        __syncthreads();                                     // the only barrier of a tile: wcnt[par] is complete
+        const unsigned c = wcnt[par][lane >> 5][lane & 31];
+        const unsigned incl = wave_scan_incl_u32(c);
+        const unsigned tot0 = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
+        const unsigned excl = incl - c - (lane >= 32 ? tot0 : 0u);
+        // the children's means (k_cut wrote them before this launch)
+        const NodeDev &c0 = nodes_ro[child0], &c1 = nodes_ro[child0 + 1];
+        const double m0L = c0.mean[0], m1L = c0.mean[1], m2L = c0.mean[2], m0R = c1.mean[0], m1R = c1.mean[1], m2R = c1.mean[2];
+        BinK kinv{0.0, 0.0};
+        if constexpr (INV) kinv = nd.kquad;
+        // 4. stores + the children's centred moments (pca.c:62-101 / cluster.c:111-152), the pixels in the order they always had.
+        // A lane without a pixel (the last tile of a node) is not switched off: it stores to the slack behind the planes and
+        // adds with a zero factor, so nothing branches around the stores and the waits count every one of them (a skipped
+        // branch makes the compiler wait as if the stores behind it had never been issued: the late rounds would then wait
+        // for EARLIER STORES to land)
+        const size_t slack = (size_t)(W ? 4 : 3) * qb.N + (size_t)lane;                  // 64 doubles behind the last plane (gq_prepare)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned eL = (unsigned)__builtin_amdgcn_readlane((int)excl, r * 4 + wid);
+            const unsigned eR = (unsigned)__builtin_amdgcn_readlane((int)excl, 32 + r * 4 + wid);
+            const unsigned ch = cr[r] & 255u;
+            const bool right = ch == 1u, none = ch == 2u;
+            const size_t dst = (right ? baseR + eR : baseL + eL) + (cr[r] >> 8);
+            dx[none ? slack : dst] = x[r]; dy[none ? slack - qb.N : dst] = y[r]; dz[none ? slack - 2 * qb.N : dst] = z[r];
+            if constexpr (W) dw[none ? slack - 3 * qb.N : dst] = w[r];
+            const double rf = right ? 1.0 : 0.0, lf = ch == 0u ? 1.0 : 0.0;          // q * {0,1} exact, x + (+-0) = x; no pixel: both 0
+            const double ex = x[r] - (right ? m0R : m0L), ey = y[r] - (right ? m1R : m1L), ez = z[r] - (right ? m2R : m2L);
+            const double wx = w[r] * ex, wy = w[r] * ey, wz = w[r] * ez;
+            const double q[7] = {wx * ex, wy * ex, wz * ex, wy * ey, wz * ey, wz * ez, ((ex * ex + ey * ey) + ez * ez) * w[r]};
+            if constexpr (INV) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    double v0, v1;
+                    bin_split(q[i], kinv, v0, v1);
+                    pl[2 * i] = __builtin_fma(v0, lf, pl[2 * i]); pl[2 * i + 1] = __builtin_fma(v1, lf, pl[2 * i + 1]);
+                    pr[2 * i] = __builtin_fma(v0, rf, pr[2 * i]); pr[2 * i + 1] = __builtin_fma(v1, rf, pr[2 * i + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 7; i++) { pl[i] = __builtin_fma(q[i], lf, pl[i]); pr[i] = __builtin_fma(q[i], rf, pr[i]); }
+            }
+        }
+        const bool flush = !more || tn.node != t.node;                                  // block-uniform
+        if (flush) {
+            const BinK kq = nd.kquad;
+            double a[28];
+            if constexpr (INV) {
+#pragma unroll
+                for (int i = 0; i < 14; i++) { a[i] = pl[i]; a[14 + i] = pr[i]; pl[i] = 0; pr[i] = 0; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    bin_split(pl[i], kq, a[2 * i], a[2 * i + 1]);
+                    bin_split(pr[i], kq, a[14 + 2 * i], a[14 + 2 * i + 1]);
+                    pl[i] = 0; pr[i] = 0;
+                }
+            }
+            block_sum<28>(a, sm);
+            if (threadIdx.x == 0) {
+                for (int side = 0; side < 2; side++) {
+                    NodeDev &chn = nodes[child0 + side];
+                    for (int i = 0; i < 7; i++) {
+                        if (a[14 * side + 2 * i] != 0.0) unsafeAtomicAdd(&chn.acc[blockIdx.x & (kSlots - 1)][i][0], a[14 * side + 2 * i]);
+                        if (a[14 * side + 2 * i + 1] != 0.0) unsafeAtomicAdd(&chn.acc[blockIdx.x & (kSlots - 1)][i][1], a[14 * side + 2 * i + 1]);
+                    }
+                }
+            }
+        }
+        // 5. the next tile's ranks and offsets, from the loads of step 2 (they sit BEFORE this tile's stores in the queue).
+        // wcnt[par ^ 1]: the trip after the next writes wcnt[par] again only behind the next trip's barrier, which every
+        // wavefront reaches after its reads of wcnt[par] above
+        if (more) {
+            classify(tn, bkn, nodes_ro[tn.node].split, par ^ 1, cr);
+            baseL = lane64(toffn, 0); baseR = lane64(toffn, 32);
+        }
+        t = tn;
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // centred second moments + distortion: pca.c:62-101 (vcov, product order (w*c_j)*c_k, lower
 // triangle) and cluster.c:111-152 (distortion = sum ((dx^2+dy^2)+dz^2)*w)
@@ -871,6 +1043,17 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
     if (nptiles) {
         KTIME(fuse_cov ? "k_scatter_cov" : "k_scatter", s, (qb.weighted ? 66.0 : 50.0) * px);
         if (fuse_cov) {
+            static const bool v1 = getenv("PAMD_SCATTER_V1") && atoi(getenv("PAMD_SCATTER_V1")) != 0;   // the round-trip-per-round kernel (A/B)
+            if (!v1) {
+                const int gb = std::min(nptiles, 256 * ((invariant || qb.weighted) ? 2 : 3));
+                if (invariant) {
+                    if (qb.weighted) hipLaunchKernelGGL((k_scatter_bin<true, true>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe);
+                    else hipLaunchKernelGGL((k_scatter_bin<false, true>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe);
+                } else if (qb.weighted) hipLaunchKernelGGL((k_scatter_bin<true, false>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe);
+                else hipLaunchKernelGGL((k_scatter_bin<false, false>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe);
+                HIP_CHECK(hipGetLastError());
+                return;
+            }
             const int g = std::min(nptiles, 256 * (invariant ? 4 : 5));   // resident blocks per CU, each loops over its run of tiles
             if (invariant) {
                 if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, true, true>), g, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fe);
