@@ -635,7 +635,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     const size_t hs = hist_slot_doubles();
     launch_minmax(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, false);
     if (sh) shard_exchange_keys(E, shard_upload_ids(E, {0}), 1);
-    launch_hist(qroot, true, E.tilesA.p, ntA0, N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake);
+    launch_hist(qroot, true, E.tilesA.p, ntA0, N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake, Nt >= ((size_t)1 << 18));
     if (sh) { comm_sum_dev(E, E.hist.p, hs, 0); comm_sum_dev(E, E.hcount.p, kBuckets, 2); }
     const int gq_kmax = (int)std::min<size_t>(K, kGqMaxK);
     E.gq.reserve(1); E.h_gq.reserve(1);

@@ -105,8 +105,11 @@ void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, 
 // from_end (every sweep launcher): the blocks take the tiles from the end of the list.  The sweeps of a split round alternate,
 // so that each starts on the lines the previous one touched last
 void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end = false);
+// fixed_point (global quantiser only): block-local sums as 64-bit integers (k_hist_fix); a property of the IMAGE (its total
+// pixel count), so that every GPU sharing an image takes the same path
 void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
-                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end = false);
+                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end = false,
+                 bool fixed_point = false);
 void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int nround, const double *d_hist,
                 const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s);
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,

@@ -274,6 +274,178 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
     }
 }
 
+// ---- the same histogram with block-local sums in 64-bit fixed point: used for the global quantiser's sweep over images of
+// 2^18 pixels and more (launch_hist).  Smaller nodes keep the two-part f64 sums above, which hold 2B >= 66 bits below the bound
+// there: on flat or posterised content the cell distortion w2 - |w1|^2 / w0 (cells.c:141-182) is a difference of equal numbers
+// and must come out below 1e-16 (global.c:115), which 45 bits cannot deliver.  The local quantiser's histogram (3-4 quantities)
+// gained 5 % from it -- it is not bound by its seven LDS atomics -- and stays as it is.
+// Block-local accumulation in 64-bit FIXED POINT: one LDS atomic per quantity and pixel instead of two f64 ones (seven LDS
+// atomics per pixel made k_hist_lq stall half of its time, twenty-one k_hist_gq).  An addend v (|v| < 2^E, the node's bound)
+// is rounded to the nearest multiple of the quantum 2^(E-F), F = min(45, 2B) -- F <= 2B keeps it on the node's fine grid
+// (devutil.h), so the rounding is a property of the pixel alone, whatever block sees it -- and added as an integer: exact
+// in any order.  A block flushes at least every 2^17 pixels, so |sum| < 2^(F+17) <= 2^62.  The flush turns the integer into
+// the two grid parts of the global table (hi a multiple of 2^(E-B), lo the rest; both exact in f64) and adds them with the
+// f64 atomics as before: the table's two parts depend on how the pixels were grouped, their SUM -- all any reader forms --
+// does not.  45 bits below the bound (54 before at 16 M pixels): the sum of a 4096^2 image's addends is still ~10x closer
+// to the exact sum than the reference's sequential f64 sum.
+struct FixK { double magic; int s; double ghi, glo; };      // magic = 1.5 * 2^(52+E-F); s = F - B; ghi = 2^(E-B), glo = 2^(E-F)
+__device__ __forceinline__ FixK make_fixk(const BinK k) {
+    const int e0 = (int)((__double_as_longlong(k.M0) >> 52) & 0x7ff) - 1023 - 52;      // E - B
+    const int e1 = (int)((__double_as_longlong(k.M1) >> 52) & 0x7ff) - 1023 - 52;      // E - 2B
+    const int B = e0 - e1, E = e0 + B;
+    const int F = 2 * B < 45 ? 2 * B : 45;
+    FixK f;
+    f.magic = ldexp(1.5, 52 + E - F); f.s = F - B; f.ghi = ldexp(1.0, e0); f.glo = ldexp(1.0, E - F);
+    return f;
+}
+__device__ __forceinline__ long long fix_quant(const double v, const double magic) {     // v / quantum, rounded to nearest even
+    return __double_as_longlong(v + magic) - __double_as_longlong(magic);                 // same binade: the mantissas subtract
+}
+template <bool W, bool GQ>
+__global__ __launch_bounds__(512) void k_hist_fix(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
+                                              double *hist, unsigned long long *hsize, unsigned int *hcount, const int from_end) {
+    constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
+    constexpr int NQS = GQ ? kNQ_GQ : kNQ_LQ;            // slot stride in quantities
+    extern __shared__ unsigned long long lds64[];
+    unsigned long long *h = lds64;                         // [NQ][512] fixed-point sums (two's complement)
+    unsigned long long *siz = h + NQ * kBuckets;           // 64-bit: weights may be large (local.c:133 sums in size_t)
+    unsigned int *cnt = (unsigned int *)(siz + kBuckets);
+    for (int i = threadIdx.x; i < NQ * kBuckets; i += blockDim.x) h[i] = 0ULL;
+    for (int i = threadIdx.x; i < kBuckets; i += blockDim.x) { cnt[i] = 0u; siz[i] = 0ULL; }
+    __syncthreads();
+
+    // a block walks consecutive tiles (the tiles of one node are consecutive) and flushes its LDS histogram to HBM
+    // only when the node changes: far fewer global f64 atomics than one flush per tile
+    // from_end: the blocks take their runs of tiles from the end of the list -- each sweep of a split round starts where the
+    // previous one stopped, on the lines that are still in the caches (k_minmax)
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int bid = from_end ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
+    int since_flush = 0;                                    // tiles accumulated in LDS (kTileA = 2^13 pixels each)
+    for (int ti = tfirst; ti < tlast; ti++) {
+        const Tile t = tiles[ti];
+        NodeDev &nd = nodes[t.node];
+        const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
+        double mn, mx;
+        node_minmax(nd, mn, mx);
+        const bool degenerate = (mx - mn < kDelta);
+        const double sc = 1 / (mx - mn);
+        const FixK flin = make_fixk(nd.klin), fquad = make_fixk(nd.kquad);
+        const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
+        const unsigned long long gslot0 = nd.gslot0;
+        if (threadIdx.x == 0) nd.degenerate = degenerate ? 1 : 0;
+
+        // two pixels per trip: both sets of loads are issued before either is consumed
+        auto one = [&](const size_t p, const double x, const double y, const double z, const double w) {
+            unsigned b;
+            if (degenerate) {
+                b = (unsigned)((p - nd.begin + gslot0) % kBuckets);   // the node-wide slot (sort.c:61-79)
+            } else {
+                double ratio = (project(x, y, z, a0, a1, a2) - mn) * sc;
+                unsigned long long bq = (unsigned long long)((double)kBuckets * ratio);
+                b = bq < (unsigned long long)(kBuckets - 1) ? (unsigned)bq : (unsigned)(kBuckets - 1);
+            }
+            qb.bkt[p] = (unsigned short)b;
+            // the pixel's addends: value and the magic constant of its grid
+            double pv[NQ], pm[NQ];
+#define HPART(q, val, K) pv[q] = (val); pm[q] = (K).magic
+            if constexpr (!GQ) {
+                HPART(0, x * w, flin); HPART(1, y * w, flin); HPART(2, z * w, flin);
+                if constexpr (W) { HPART(3, w, flin); }
+            } else {
+                HPART(0, x, flin); HPART(1, y, flin); HPART(2, z, flin);
+                HPART(3, (x * x + y * y) + z * z, fquad);
+                HPART(4, x * x, fquad); HPART(5, x * y, fquad); HPART(6, y * y, fquad);
+                HPART(7, x * z, fquad); HPART(8, y * z, fquad); HPART(9, z * z, fquad);
+                if constexpr (W) { HPART(10, x * w, flin); HPART(11, y * w, flin); HPART(12, z * w, flin); HPART(13, w, flin); }
+            }
+#undef HPART
+            unsigned long long wi = 0ULL;
+            if constexpr (W && !GQ) wi = (unsigned long long)w;                  // size_t += double truncates (local.c:133)
+            // Neighbouring pixels of a flat or smooth region fall into the SAME bucket: 64 lanes adding to one LDS address
+            // serialise (a smooth 4096^2 image took 3.2x, a posterised one 5.4x as long as noise).  When the wavefront is complete
+            // and at least a third of it shares the first lane's bucket, that group's addends are summed over the wavefront first
+            // (exact: the quantised values are multiples of the quantum, 64 of them stay below 2^51 quanta) and added once; the
+            // other lanes add their own.
+            bool direct = true;
+            if (__ballot(true) == ~0ULL) {
+                // up to three groups: the bucket of the first lane still holding its addends, if enough lanes share it
+                unsigned long long left = ~0ULL;
+#pragma unroll 1
+                for (int g = 0; g < 3 && left != 0ULL; g++) {
+                    const int first = __builtin_ctzll(left);                       // wave-uniform
+                    const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)b, first);
+                    const bool mine = direct && b == b0;
+                    const unsigned long long m = __ballot(mine);
+                    if (__popcll(m) < kHistCombineMin) break;
+#pragma unroll
+                    for (int k2 = 0; k2 < NQ; k2++) {
+                        const double vq = (pv[k2] + pm[k2]) - pm[k2];              // the addend on its quantum
+                        const double sum = wave_sum_dpp63(mine ? vq : 0.0);
+                        if ((threadIdx.x & 63) == 63) atomicAdd(&h[k2 * kBuckets + b0], (unsigned long long)fix_quant(sum, pm[k2]));
+                    }
+                    if constexpr (W && !GQ) {
+                        unsigned long long sw2 = mine ? wi : 0ULL;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) sw2 += __shfl_down(sw2, o, 64);
+                        if ((threadIdx.x & 63) == 0) atomicAdd(&siz[b0], sw2);
+                    }
+                    if ((threadIdx.x & 63) == 0) atomicAdd(&cnt[b0], (unsigned)__popcll(m));
+                    if (mine) direct = false;
+                    left &= ~m;
+                }
+            }
+            if (direct) {
+                atomicAdd(&cnt[b], 1u);
+#pragma unroll
+                for (int k2 = 0; k2 < NQ; k2++) atomicAdd(&h[k2 * kBuckets + b], (unsigned long long)fix_quant(pv[k2], pm[k2]));
+                if constexpr (W && !GQ) atomicAdd(&siz[b], wi);
+            }
+        };
+        unsigned i = threadIdx.x;
+        for (; i + 512 < t.count; i += 1024) {
+            const size_t p0 = t.start + i, p1 = p0 + 512;
+            const double x0 = px[p0], y0 = py[p0], z0 = pz[p0], x1 = px[p1], y1 = py[p1], z1 = pz[p1];
+            double w0 = 1.0, w1 = 1.0;
+            if constexpr (W) { w0 = pw[p0]; w1 = pw[p1]; }
+            one(p0, x0, y0, z0, w0);
+            one(p1, x1, y1, z1, w1);
+        }
+        for (; i < t.count; i += 512) {
+            const size_t p = t.start + i;
+            double w = 1.0;
+            if constexpr (W) w = pw[p];
+            one(p, px[p], py[p], pz[p], w);
+        }
+        since_flush++;
+        const bool flush = (ti + 1 == tlast) || tiles[ti + 1].node != t.node || since_flush >= 16;   // block-uniform
+        if (!flush) continue;
+        since_flush = 0;
+        __syncthreads();
+        const size_t slot = (size_t)nd.slot;
+        double *gh = hist + slot * (size_t)(NQS * 2 * kBuckets);
+        for (int i2 = threadIdx.x; i2 < NQ * kBuckets; i2 += blockDim.x) {
+            const long long S = (long long)h[i2];
+            if (S != 0) {
+                const int q = i2 / kBuckets, bb = i2 % kBuckets;
+                const bool quad = GQ && q >= 3 && q <= 9;
+                const FixK &f = quad ? fquad : flin;
+                // S quanta = Sh * 2^s + Sl: hi = Sh on the coarse grid, lo = Sl on the quantum (|Sh| < 2^51: B + log2(pixels) <= 51)
+                const long long Sh = (S + (1LL << (f.s - 1))) >> f.s, Sl = S - (Sh << f.s);
+                if (Sh != 0) unsafeAtomicAdd(&gh[(q * 2 + 0) * kBuckets + bb], (double)Sh * f.ghi);
+                if (Sl != 0) unsafeAtomicAdd(&gh[(q * 2 + 1) * kBuckets + bb], (double)Sl * f.glo);
+                h[i2] = 0ULL;
+            }
+        }
+        for (int b = threadIdx.x; b < kBuckets; b += blockDim.x) {
+            unsigned c = cnt[b];
+            if (c) { atomicAdd(&hcount[slot * kBuckets + b], c); cnt[b] = 0u; }
+            if constexpr (W && !GQ) { const unsigned long long s2 = siz[b]; if (s2) { atomicAdd(&hsize[slot * kBuckets + b], s2); siz[b] = 0ULL; } }
+        }
+        __syncthreads();
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // optimal cut: local.c:136-176 (prefix, objective, first arg-max) + the children's records
 // --------------------------------------------------------------------------------------------
@@ -915,6 +1087,19 @@ void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size
     HIP_CHECK(hipGetLastError());
 }
 
+template <bool W>
+static void launch_hist_fix(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, double *d_hist,
+                            unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end) {
+    constexpr int NQ = W ? 14 : 10;
+    const size_t lds = (size_t)NQ * kBuckets * sizeof(unsigned long long) + kBuckets * (sizeof(unsigned int) + sizeof(unsigned long long));
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) HIP_CHECK(hipFuncSetAttribute((const void *)k_hist_fix<W, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KTIME("k_hist_gq", s, (W ? 34.0 : 26.0) * px);
+    const int g = std::min(ntiles, 256 * (W ? 2 : 3));       // resident blocks per CU by LDS footprint (46 / 63 KB)
+    hipLaunchKernelGGL((k_hist_fix<W, true>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount, from_end ? 1 : 0);
+    HIP_CHECK(hipGetLastError());
+}
+
 template <bool W, bool GQ>
 static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, double *d_hist,
                           unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end) {
@@ -1015,8 +1200,13 @@ void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, 
 }
 
 void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
-                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end) {
+                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end, bool fixed_point) {
     if (!ntiles) return;
+    if (gq && fixed_point) {
+        if (qb.weighted) launch_hist_fix<true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
+        else launch_hist_fix<false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
+        return;
+    }
     if (qb.weighted) { if (gq) launch_hist_t<true, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
                        else launch_hist_t<true, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end); }
     else { if (gq) launch_hist_t<false, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
