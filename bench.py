@@ -158,6 +158,69 @@ def north_star_kernels(L, native):
     return out
 
 
+def content_times(L, native, cfg):
+    """The timed region runs on uniform noise (what BASELINE.json asks for) -- the best case of the LDS histograms and of the
+    centroid chains.  Here the SAME configuration once each on content a photograph is closer to, device-resident like `value`,
+    outside the timed region and never part of `value`: a smooth synthetic scene with saturated blobs and mild noise, the same
+    scene posterised to eight levels per channel (a handful of distinct colours: 64 lanes adding to one histogram bucket), and
+    noise with one colour covering 30 % of the image (one very long centroid chain)."""
+    import numpy as np
+    width, height, K, cs, niter, max_samples, dither, weighted, _ = cfg
+    n = width * height
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
+    planes = [0.5 + 0.4 * np.sin(xx / (0.15 * width + 3.0) + 4.0), 0.5 + 0.4 * np.cos(yy / (0.12 * height + 3.0)),
+              0.35 + 0.25 * np.sin((xx + yy) / (0.2 * (width + height) + 3.0))]
+    for _ in range(3):
+        cy, cx = rng.uniform(0.25, 0.75) * height, rng.uniform(0.25, 0.75) * width
+        ry, rx = rng.uniform(0.05, 0.18) * height + 1, rng.uniform(0.05, 0.18) * width + 1
+        inside = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
+        for pl, v in zip(planes, rng.uniform(0.0, 1.0, size=3)):
+            pl[inside] = v
+    del yy, xx
+    scene = np.empty(3 * n)
+    for j, pl in enumerate(planes):
+        scene[j * n:(j + 1) * n] = np.clip(pl.reshape(-1).astype(np.float64) + rng.normal(0.0, 0.02, n), 0.0, 1.0)
+    del planes
+    d = L.patolette_amd_malloc(3 * n * 8)
+    dmap = L.patolette_amd_malloc(n)
+    if not d or not dmap:
+        return None
+    opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+    pal = np.zeros((K, 3), dtype=np.float64, order="F")
+    code = C.c_int(0)
+    out = {"note": "same configuration and entry point as `value`, other image content; median of 3 after one warm-up; never part of `value`"}
+
+    def run(host, name):
+        assert L.patolette_amd_memcpy_h2d(d, host.ctypes.data_as(C.c_void_p), host.nbytes) == 0
+        times = []
+        for i in range(4):
+            L.patolette_amd_synchronize()
+            t0 = time.perf_counter()
+            L.patolette_amd_device(width, height, d, None, K, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+            L.patolette_amd_synchronize()
+            if code.value != 0:
+                return
+            if i:
+                times.append(time.perf_counter() - t0)
+        st = native.last_stats()
+        out[name] = {"ms": round(1e3 * sorted(times)[1], 3), "ms_lq": round(st["ms_lq"], 3), "ms_kmeans": round(st["ms_kmeans"], 3),
+                     "split_evals": st["split_evals"]}
+    try:
+        run(scene, "scene")
+        run(np.round(scene * 7.0) / 7.0, "posterised")
+        del scene
+        noise = rng.random(3 * n)
+        m = int(0.3 * n)
+        for j, v in enumerate((0.1, 0.2, 0.7)):
+            noise[j * n:j * n + m] = v + 0.004 * rng.standard_normal(m)
+        run(np.clip(noise, 0.0, 1.0), "dominant30")
+    finally:
+        L.patolette_amd_free(d)
+        L.patolette_amd_free(dmap)
+    return out
+
+
 def host_to_host(L, native, cfg, reps=3):
     """SURVEY.md 8(d) metric (ii): the same workload through the reference's own entry point `patolette()` -- host f64
     image in (pageable numpy memory), size_t map and f64 palette out, PCIe copies included.  Reported next to, never as,
@@ -416,22 +479,26 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["total_ms"])
         r = prof[dom]
         achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         if os.path.exists(tpath):       # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
             tj = json.load(open(tpath))
             if dom in tj.get("kernels", {}):
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                # counters cannot be read inside this process: the figure is the one kept from the PMC passes, and says so
+                traffic_source = "profiles/traffic_%s.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run" % (
+                    args.config, tj.get("collected", "collection date not recorded"))
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 3),
                     "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"], 1),
                     "time_share": round(kernels.get(dom, {"ms_per_step": 0.0})["ms_per_step"] / max(1e-9, sum(v["ms_per_step"] for v in kernels.values())), 3)}
 
     # ---- extras of the default run, all outside the timed region ----
-    ns_kernels = h2h = None
+    ns_kernels = h2h = content = None
     if not args.no_extras and world == 1 and args.config == "c3":
         h2h = host_to_host(L, _native, cfg)
+        content = content_times(L, _native, cfg)
         ns_kernels = north_star_kernels(L, _native)
 
     # ---- CPU baseline: the oracle (plain-C restatement of the reference path) on this host, same workload ----
@@ -485,7 +552,7 @@ def main():
                                                       "per-kernel table from one extra untimed step" % (dom_name, EVENT_SAMPLE)
                                                       if dom_name else "all kernels")),
                    "final_gather": ("RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region" if dist is not None else "none (1 GPU)")},
-        "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "throughput_concurrent": conc,
+        "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "content": content, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

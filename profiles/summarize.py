@@ -24,6 +24,10 @@ def short(name):
     base = n.split("<")[0]
     if base == "k_hist":
         return "k_hist_gq" if ", true>" in n else "k_hist_lq"
+    if base == "k_hist_fix":
+        return "k_hist_gq"
+    if base == "k_scatter_bin":
+        return "k_scatter_cov"
     if base == "k_scatter":
         return "k_scatter_cov" if re.match(r"k_scatter<\w+, true", n) else "k_scatter"      # <W, COV(, INV)>
     if base in ("k_cov_children", "k_cov_nodes"):
@@ -74,7 +78,8 @@ if "k_convert" in kern:
     npx = bench["config"]["width"] * bench["config"]["height"]
     cal = {"kernel": "k_convert", "known_read_bytes": 24 * npx, "FETCH_SIZE_bytes": kern["k_convert"]["FETCH_SIZE_KiB_per_launch"] * 1024,
            "known_write_bytes": 24 * npx, "WRITE_SIZE_bytes": kern["k_convert"]["WRITE_SIZE_KiB_per_launch"] * 1024}
-json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --config %s --steps 2 --warmup 1 --no-cpu-baseline --no-profile --extra-streams 0" % cfg,
+import datetime
+json.dump({"collected": os.environ.get("PAMD_PROFILE_STAMP", datetime.date.today().isoformat()), "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --config %s --steps 2 --warmup 1 --no-cpu-baseline --no-profile --extra-streams 0" % cfg,
            "correction": "hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B read requests at 64 B)", "calibration": cal, "kernels": kern},
           open(os.path.join(root, "profiles", "traffic_%s.json" % cfg), "w"), indent=1)
 for f in ("bench_%s.json" % cfg, "bench_%s_traced.json" % cfg):

@@ -21,6 +21,10 @@ def short(name):
     base = n.split("<")[0]
     if base == "k_hist":
         return "k_hist_gq" if ", true>" in n else "k_hist_lq"
+    if base == "k_hist_fix":
+        return "k_hist_gq"
+    if base == "k_scatter_bin":
+        return "k_scatter_cov"
     if base == "k_scatter":
         return "k_scatter_cov" if re.match(r"k_scatter<\w+, true", n) else "k_scatter"      # <W, COV(, INV)>
     return base
