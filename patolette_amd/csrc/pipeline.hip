@@ -82,6 +82,7 @@ __global__ void k_put_nodes(NodeDev *table, const NodeIn *stage, const int *ids,
     for (int j = 0; j < 3; j++) { d.axis[j] = in.axis[j]; d.mean[j] = in.mean[j]; }
     d.sw = in.sw; d.klin = in.klin; d.kquad = in.kquad;
     node_reset_outputs(d);
+    d.split = in.split;
 }
 __global__ void k_get_nodes(const NodeDev *table, NodeOut *stage, const int *ids, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,7 +431,7 @@ static void build_tiles(const std::vector<int> &round, const std::vector<HNode> 
 static NodeIn make_nodedev(const HNode &h, const Bounds &b) {
     NodeIn d;
     std::memset(&d, 0, sizeof d);
-    d.begin = h.begin; d.n = h.n; d.gn = h.gn; d.buf = h.buf; d.slot = -1; d.child0 = -1; d.nchild = 0;
+    d.begin = h.begin; d.n = h.n; d.gn = h.gn; d.buf = h.buf; d.slot = -1; d.child0 = -1; d.nchild = 0; d.split = -1;
     for (int j = 0; j < 3; j++) d.mean[j] = h.mean[j];
     d.sw = h.sw;
     int P = 1;
@@ -675,6 +676,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         while (j < kbase - 1 && !((size_t)(b + 1) <= cuts[j + 1])) j++;
         lut[b] = (unsigned char)j;
     }
+    // Two base clusters (what noise and most photographs give): the partition is a binary split like the local quantiser's, so
+    // it takes the same pipelined kernel and the children's centred moments ride along instead of costing a sweep of their own
+    const bool gq_binary = kbase == 2;
     std::vector<int> base_ids;
     {
         unsigned long long pos = 0;
@@ -703,6 +707,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         NodeIn d = make_nodedev(hn[0], bnd);
         for (int j = 0; j < 3; j++) d.axis[j] = axis[j];
         d.slot = 0; d.child0 = base_ids[0]; d.nchild = kbase;
+        if (gq_binary) d.split = (int)cuts[1] - 1;               // bucket b is in cluster 0 iff b + 1 <= cuts[1] (global.c:328-335)
         std::vector<int> ids = {0};
         std::vector<NodeIn> recs = {d};
         for (int id : base_ids) { ids.push_back(id); NodeIn c = make_nodedev(hn[id], bnd); c.klin = d.klin; c.kquad = d.kquad; recs.push_back(c); }
@@ -711,9 +716,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     E.h_bytes.reserve(kBuckets);                                // pinned: no synchronisation before the partition
     std::memcpy(E.h_bytes.p, lut.data(), kBuckets);
     HIP_CHECK(hipMemcpyAsync(E.lut.p, E.h_bytes.p, kBuckets, hipMemcpyHostToDevice, s));
-    launch_partition(qroot, E.tilesP.p, ntP0, N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, false, s);
+    launch_partition(qroot, E.tilesP.p, ntP0, N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, gq_binary, s, inv_sums);
     if (sh) { hipLaunchKernelGGL(k_shard_children_local, 1, 64, 0, s, E.nodes.p, E.round_nodes.p, 1); HIP_CHECK(hipGetLastError()); }
-    launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, snake);
+    if (!gq_binary) launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, snake);
     if (sh) shard_exchange_acc(E, shard_upload_ids(E, base_ids), (int)base_ids.size());
     get_nodes(E, base_ids, got);
     for (size_t i = 0; i < base_ids.size(); i++) {

@@ -23,6 +23,7 @@ constexpr int kSlots = 16;             // accumulator copies per node: same-addr
 struct NodeIn {
     unsigned long long begin, n, gn;   // gn: members over ALL GPUs of a within-image shard group (= n on one GPU)
     int buf, slot, child0, nchild;
+    int split;                         // >= 0: the children are "bucket <= split" / "bucket > split" (two base clusters out of the global quantiser)
     double axis[3], mean[3], sw;
     BinK klin, kquad;
 };
