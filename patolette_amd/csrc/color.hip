@@ -19,12 +19,16 @@ namespace pamd {
 // sumk.M0 != 0: also accumulate the column sums of the output (order-independent binned parts; the bound behind sumk
 // is a property of the colour space, so it is known before the pass)
 template <int WHICH, class SRC>
-__global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ dst, size_t n, ConvertStats *stats, BinK sumk) {
+__global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ dst, size_t n, ConvertStats *stats, BinK sumk, BinK momk) {
     // per-plane min / max of the OUTPUT (bounds for the binned accumulators downstream)
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     double acc[6] = {0, 0, 0, 0, 0, 0};
     bool bad = false;                                      // (float)value would be NaN or Inf: at or beyond FLT_MAX + half an ulp
     const bool do_sum = stats != nullptr && sumk.M0 != 0.0;
+    // momk.M0 != 0: the raw second moments of the output too (xx, yx, zx, yy, zy, zz) -- with the column sums they give the root's
+    // centred covariance without another sweep (pipeline.hip quantize_clusters)
+    const bool do_mom = do_sum && momk.M0 != 0.0;
+    double acc2[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr bool kLut = std::is_same<SRC, SrcU8>::value && (WHICH == PAMD_SRGB_TO_ICTCP || WHICH == PAMD_SRGB_TO_CIELUV);
     __shared__ double glut[kLut ? 256 : 1];                // companding of the 256 possible 8-bit values (sRGB.c:70-89)
     pow_tables_to_lds();
@@ -41,6 +45,10 @@ __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ d
         if (do_sum) {
 #pragma unroll
             for (int p = 0; p < 3; p++) bin_add(c[p], sumk, acc[2 * p], acc[2 * p + 1]);
+        }
+        if (do_mom) {
+            bin_add(c[0] * c[0], momk, acc2[0], acc2[1]); bin_add(c[1] * c[0], momk, acc2[2], acc2[3]); bin_add(c[2] * c[0], momk, acc2[4], acc2[5]);
+            bin_add(c[1] * c[1], momk, acc2[6], acc2[7]); bin_add(c[2] * c[1], momk, acc2[8], acc2[9]); bin_add(c[2] * c[2], momk, acc2[10], acc2[11]);
         }
     };
     // the pow chains are VALU work (nine pow per pixel for ICtCp) during which nothing was in flight: the NEXT pixel's
@@ -64,6 +72,15 @@ __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ d
             const int slot = blockIdx.x & (kStatSlots - 1);
 #pragma unroll
             for (int q = 0; q < 6; q++) unsafeAtomicAdd(&stats->sum[slot][q >> 1][q & 1], acc[q]);
+        }
+    }
+    if (do_mom) {                                          // block-uniform
+        __shared__ double smom[12 * 4];
+        block_sum<12>(acc2, smom);
+        if (threadIdx.x == 0) {
+            const int slot = blockIdx.x & (kStatSlots - 1);
+#pragma unroll
+            for (int q = 0; q < 12; q++) unsafeAtomicAdd(&stats->mom[slot][q >> 1][q & 1], acc2[q]);
         }
     }
     if (stats) {
@@ -102,6 +119,7 @@ __global__ __launch_bounds__(256) void k_weight_stats(const double *__restrict__
 __global__ void k_init_stats(ConvertStats *s) {
     if (threadIdx.x < kStatSlots) {
         for (int p = 0; p < 3; p++) { s->minkey[threadIdx.x][p] = ~0ULL; s->maxkey[threadIdx.x][p] = 0ULL; s->sum[threadIdx.x][p][0] = 0.0; s->sum[threadIdx.x][p][1] = 0.0; }
+        for (int q = 0; q < 6; q++) { s->mom[threadIdx.x][q][0] = 0.0; s->mom[threadIdx.x][q][1] = 0.0; }
         s->wmaxkey[threadIdx.x] = f64_key(0.0);
     }
     if (threadIdx.x == 0) s->nonfinite_f32 = 0u;
@@ -123,49 +141,49 @@ static int stream_grid(size_t n) {
     return (int)b;
 }
 
-void launch_convert(int which, const double *src_p, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk) {
+void launch_convert(int which, const double *src_p, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk, BinK momk) {
     if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
     int g = stream_grid(n);
     KTIME("k_convert", s, 48.0 * n);
     const SrcF64 src{src_p, n};
     switch (which) {
-        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_ICTCP_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_REC2020_TO_SRGB: hipLaunchKernelGGL((k_convert<PAMD_REC2020_TO_SRGB, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_CIELUV_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk); break;
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_ICTCP_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_REC2020_TO_SRGB: hipLaunchKernelGGL((k_convert<PAMD_REC2020_TO_SRGB, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_CIELUV_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
         default: throw HipError("patolette_amd: unknown conversion");
     }
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk) {
+void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk, BinK momk) {
     if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
     int g = stream_grid(n);
     KTIME("k_convert", s, 48.0 * n);
     const SrcF64Rows src{rows};
     switch (which) {
-        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk); break;
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
         default: throw HipError("patolette_amd: unknown conversion");
     }
     HIP_CHECK(hipGetLastError());
 }
 
 void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
-                       hipStream_t s, BinK sumk) {
+                       hipStream_t s, BinK sumk, BinK momk) {
     if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
     int g = stream_grid(n);
     KTIME("k_convert_u8", s, (24.0 + channels) * n);
     const SrcU8 src{pixels, channels};
     switch (which) {
-        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk); break;
-        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk); break;
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
         default: throw HipError("patolette_amd: unknown conversion");
     }
     HIP_CHECK(hipGetLastError());

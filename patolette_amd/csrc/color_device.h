@@ -15,6 +15,7 @@ constexpr int kStatSlots = 32;       // same-address atomics serialise in L2: bl
 struct ConvertStats {                // filled by k_convert / k_weight_stats (ordered-key min/max per slot)
     unsigned long long minkey[kStatSlots][3], maxkey[kStatSlots][3], wmaxkey[kStatSlots];
     double sum[kStatSlots][3][2];    // binned column sums of the converted image (the root mean of the global quantiser)
+    double mom[kStatSlots][6][2];    // binned raw second moments xx, yx, zx, yy, zy, zz (the root covariance)
     unsigned int nonfinite_f32;      // some converted value is NaN / Inf once cast to float (faiss Clustering.cpp:295-304 scans for that)
 };
 

@@ -26,11 +26,12 @@
 namespace pamd {
 
 // launchers defined in color.hip
-void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk = BinK{0.0, 0.0});
+void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk = BinK{0.0, 0.0},
+                    BinK momk = BinK{0.0, 0.0});
 void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s,
-                         BinK sumk = BinK{0.0, 0.0});
+                         BinK sumk = BinK{0.0, 0.0}, BinK momk = BinK{0.0, 0.0});
 void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
-                       hipStream_t s, BinK sumk = BinK{0.0, 0.0});
+                       hipStream_t s, BinK sumk = BinK{0.0, 0.0}, BinK momk = BinK{0.0, 0.0});
 void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned char *pal_u8, int k, unsigned char *out,
                         hipStream_t s);
 void launch_weight_stats(const double *w, size_t n, ConvertStats *stats, hipStream_t s);
@@ -201,6 +202,8 @@ __global__ void k_shard_children_local(NodeDev *table, const int *round_nodes, i
 struct Bounds {
     double cmax, range, wmax; int e_lin, e_quad; double lo[3], hi[3];
     bool have_sum = false; double sum[3] = {0, 0, 0};        // column sums of the converted image, when the conversion took them
+    bool have_mom = false;                                   // ... and the raw second moments with them: both as exact (hi, lo) pairs
+    double sum2[3][2] = {{0, 0}, {0, 0}, {0, 0}}, mom2[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
     bool nonfinite = false;                                  // a converted value is NaN / Inf as f32 (KMeans then leaves the centres alone)
 };
 
@@ -611,18 +614,31 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     QuantBuffers qlq{{E.bufB.p, E.bufA.p}, E.bkt.p, N, weighted};
     std::vector<int> round = {0};
     const int ntA0 = (int)ceil_div(N, (size_t)kTileA), ntP0 = (int)ceil_div(N, (size_t)kTileP);   // the root's tilings (gq_prepare)
-    {
-        NodeIn d = make_nodedev(hn[0], bnd);
-        put_nodes(E, {0}, {d});
-    }
     // every sweep over the pixels starts where the previous one stopped (see the split rounds below): the conversion wrote the
     // image front to back, so the root's moments are taken back to front, the extrema front to back, ...
     static const bool snake = !(getenv("PAMD_SWEEP_SNAKE") && atoi(getenv("PAMD_SWEEP_SNAKE")) == 0);
-    launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, ntA0, N, E.nodes.p, s, snake);
     std::vector<NodeOut> got;
-    if (sh) shard_exchange_acc(E, shard_upload_ids(E, {0}), 1);
-    get_nodes(E, {0}, got);
-    absorb_moments(hn[0], got[0]);
+    const bool mom_path = bnd.have_mom && !sh;                  // one sweep less: the directions of the following ones flip
+    if (mom_path) {
+        // The conversion pass took the column sums S1 and the raw second moments S2 as exact pairs: the centred sums
+        // S2_jk - S1_j S1_k / n (pca.c:62-101 about the mean, matrix2D.c:200-233) follow in extended precision -- the
+        // difference keeps ~60 of its 64 bits, then ONE rounding to double -- instead of a sweep over the image and a round trip.
+        const long double nn = (long double)Nt;
+        long double s1[3], c6[6];
+        for (int j = 0; j < 3; j++) s1[j] = (long double)bnd.sum2[j][0] + (long double)bnd.sum2[j][1];
+        static const int ja[6] = {0, 1, 2, 1, 2, 2}, jb[6] = {0, 0, 0, 1, 1, 2};       // xx, yx, zx, yy, zy, zz
+        for (int q = 0; q < 6; q++)
+            c6[q] = ((long double)bnd.mom2[q][0] + (long double)bnd.mom2[q][1]) - s1[ja[q]] * s1[jb[q]] / nn;
+        for (int q = 0; q < 6; q++) hn[0].cov6[q] = (double)c6[q];
+        hn[0].dist = (double)(c6[0] + c6[3] + c6[5]);
+    } else {
+        NodeIn d = make_nodedev(hn[0], bnd);
+        put_nodes(E, {0}, {d});
+        launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, ntA0, N, E.nodes.p, s, snake);
+        if (sh) shard_exchange_acc(E, shard_upload_ids(E, {0}), 1);
+        get_nodes(E, {0}, got);
+        absorb_moments(hn[0], got[0]);
+    }
     double axis[3];
     if (!node_axis(hn[0], axis)) return -1;
 
@@ -634,9 +650,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
         put_nodes(E, {0}, {d});
     }
     const size_t hs = hist_slot_doubles();
-    launch_minmax(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, false);
+    launch_minmax(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, snake && mom_path);
     if (sh) shard_exchange_keys(E, shard_upload_ids(E, {0}), 1);
-    launch_hist(qroot, true, E.tilesA.p, ntA0, N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake, Nt >= ((size_t)1 << 18));
+    launch_hist(qroot, true, E.tilesA.p, ntA0, N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake && !mom_path, Nt >= ((size_t)1 << 18));
     if (sh) { comm_sum_dev(E, E.hist.p, hs, 0); comm_sum_dev(E, E.hcount.p, kBuckets, 2); }
     const int gq_kmax = (int)std::min<size_t>(K, kGqMaxK);
     E.gq.reserve(1); E.h_gq.reserve(1);
@@ -716,9 +732,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     E.h_bytes.reserve(kBuckets);                                // pinned: no synchronisation before the partition
     std::memcpy(E.h_bytes.p, lut.data(), kBuckets);
     HIP_CHECK(hipMemcpyAsync(E.lut.p, E.h_bytes.p, kBuckets, hipMemcpyHostToDevice, s));
-    launch_partition(qroot, E.tilesP.p, ntP0, N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, gq_binary, s, inv_sums);
+    launch_partition(qroot, E.tilesP.p, ntP0, N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, gq_binary, s, inv_sums, snake && mom_path);
     if (sh) { hipLaunchKernelGGL(k_shard_children_local, 1, 64, 0, s, E.nodes.p, E.round_nodes.p, 1); HIP_CHECK(hipGetLastError()); }
-    if (!gq_binary) launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, snake);
+    if (!gq_binary) launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, snake && !mom_path);
     if (sh) shard_exchange_acc(E, shard_upload_ids(E, base_ids), (int)base_ids.size());
     get_nodes(E, base_ids, got);
     for (size_t i = 0; i < base_ids.size(); i++) {
@@ -1042,7 +1058,9 @@ static Bounds read_bounds(Engine &E, bool weighted, const std::function<void()> 
     const double quad = 3.0 * b.wmax * std::max(std::max(b.range, b.cmax), 1e-300) * std::max(std::max(b.range, b.cmax), 1e-300);
     b.e_lin = exp_bound(lin);
     b.e_quad = exp_bound(std::max(quad, 1e-300));
-    for (int p = 0; p < 3; p++) b.sum[p] = parts[p][0] + parts[p][1];
+    for (int p = 0; p < 3; p++) { b.sum[p] = parts[p][0] + parts[p][1]; b.sum2[p][0] = parts[p][0]; b.sum2[p][1] = parts[p][1]; }
+    for (int q = 0; q < 6; q++)
+        for (int t = 0; t < kStatSlots; t++) { b.mom2[q][0] += cs.mom[t][q][0]; b.mom2[q][1] += cs.mom[t][q][1]; }   // exact: parts on the grids
     b.nonfinite = nonfinite != 0ULL;
     return b;
 }
@@ -1075,7 +1093,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     else if (opt->color_space == patolette__ICtCp) which = PAMD_SRGB_TO_ICTCP;
     // the root mean of the global quantiser (matrix2D.c:229) rides along with the conversion where the colour space bounds
     // the values a priori: |I| <= 1, |Ct|, |Cp| <= 0.5 (2^1); L <= 100, |u|, |v| < 256 (2^8).  sRGB passes user data through.
-    BinK sumk{0.0, 0.0};
+    BinK sumk{0.0, 0.0}, momk{0.0, 0.0};
     if (E.shard && opt->dither && !opt->palette_only)
         throw HipError("patolette_amd: dithering is one serial chain over the whole image; it is not available per slice");
     {
@@ -1083,10 +1101,16 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
         int rootP = 1; while ((1ULL << rootP) < (Nt > 1 ? Nt : 2)) rootP++;
         if (which == PAMD_SRGB_TO_ICTCP) sumk = make_bink(1, rootP);
         else if (which == PAMD_SRGB_TO_CIELUV) sumk = make_bink(8, rootP);
+        // one GPU: the raw second moments ride along too (products < 1, resp. < 2^16), and the root's covariance needs no sweep
+        static const bool mom_on = !(getenv("PAMD_ROOT_MOMENTS") && atoi(getenv("PAMD_ROOT_MOMENTS")) == 0);
+        if (!E.shard && mom_on) {
+            if (which == PAMD_SRGB_TO_ICTCP) momk = make_bink(1, rootP);
+            else if (which == PAMD_SRGB_TO_CIELUV) momk = make_bink(16, rootP);
+        }
     }
-    if (px.u8) launch_convert_u8(which, px.u8, px.channels, E.cvt.p, N, E.cstats.p, s, sumk);
-    else if (px.rows) launch_convert_rows(which, px.f64, E.cvt.p, N, E.cstats.p, s, sumk);
-    else launch_convert(which, px.f64, E.cvt.p, N, E.cstats.p, s, sumk);
+    if (px.u8) launch_convert_u8(which, px.u8, px.channels, E.cvt.p, N, E.cstats.p, s, sumk, momk);
+    else if (px.rows) launch_convert_rows(which, px.f64, E.cvt.p, N, E.cstats.p, s, sumk, momk);
+    else launch_convert(which, px.f64, E.cvt.p, N, E.cstats.p, s, sumk, momk);
     if (weighted) {
         HIP_CHECK(hipMemcpyAsync(E.cvt.p + 3 * N, d_weights, N * sizeof(double), hipMemcpyDeviceToDevice, s));
         launch_weight_stats(d_weights, N, E.cstats.p, s);
@@ -1094,6 +1118,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     // the quantiser's size-only preparations go behind the statistics' download: they run while the host derives the bounds
     Bounds bnd = read_bounds(E, weighted, [&] { gq_prepare(E, N, weighted); });
     bnd.have_sum = sumk.M0 != 0.0;
+    bnd.have_mom = momk.M0 != 0.0;
     E.stats.ms_convert = now_ms() - t0;
 
     // S2 + S3: global + local quantiser (progress lines as patolette.c:209-229 prints them when verbose)
