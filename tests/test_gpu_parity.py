@@ -527,3 +527,21 @@ def test_photograph_like_image_end_to_end(gpu, ob, rows, cols, K, cs, dither, ni
     assert ok and ec == 0
     assert np.allclose(pal, pal_o, rtol=0, atol=1e-9)
     assert np.array_equal(pmap, pmap_o)
+
+
+@pytest.mark.parametrize("rows,cols,K,cs,kind", [(1200, 1600, 256, 1, "noise"), (1024, 1536, 200, 2, "scene")])
+def test_large_weighted_image_end_to_end(gpu, ob, rows, cols, K, cs, kind):
+    """1.6-1.9 Mpx with weights: the sizes from which the global quantiser's histogram sums in fixed point (2^18 pixels) and the
+    partition kernels walk many tiles per block, weighted variants -- palette and map against the oracle, the map bit for bit."""
+    import patolette_amd as p
+    from tests.util import scene
+    n = rows * cols
+    colors = ob.unplanar(ob.image(n, 23), n) if kind == "noise" else scene(rows, cols, 29).reshape(-1, 3)
+    wts = ob.weights(n, 23)
+    ok, pal, pmap, _ = p.quantize(cols, rows, colors, K, dither=False, color_space=cs, tile_size=0, kmeans_niter=2,
+                                  kmeans_max_samples=512 ** 2, weights=wts)
+    ec, pal_o, pmap_o = ob.patolette(cols, rows, ob.planar(colors), wts, K, dither=False, color_space=cs, kmeans_niter=2,
+                                     kmeans_max_samples=512 ** 2)
+    assert ok and ec == 0
+    assert np.allclose(pal, pal_o, rtol=0, atol=1e-9)
+    assert np.array_equal(pmap, pmap_o)
