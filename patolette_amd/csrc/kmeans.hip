@@ -1270,6 +1270,85 @@ __device__ __forceinline__ float km_chain_coop(const float4 *__restrict__ sorted
     return acc;
 }
 
+// The same per-block step over n samples that already sit in LDS, one array per component, zero-padded to a multiple of 1024
+// (k_km_update_lists: the pieces of a long member list): exact integer sum of a block of 1024 while the accumulator keeps
+// its binade, the block replayed in order otherwise.
+template <bool W>
+__device__ __forceinline__ float km_coop_lds(const float *mine, const float *wts, const unsigned n, const bool wx, float acc, const int lane) {
+    constexpr unsigned BS = 1024;
+    for (unsigned pos = 0; pos < n; pos += BS) {
+        const unsigned bend = pos + BS < n ? pos + BS : n;
+        const float *blk = mine + pos, *wblk = wts + pos;
+        bool done = false;
+        const float aa = fabsf(acc);
+        if (aa >= 1e-30f && aa < 1e30f) {
+            int ex;
+            (void)frexpf(aa, &ex);                                 // aa in [2^(ex-1), 2^ex)
+            const double sgn = acc < 0.f ? -1.0 : 1.0;
+            const double scale = ldexp(sgn, 24 - ex);              // +-1/u with u = 2^(ex-1-23)
+            const double M0 = (double)aa * fabs(scale);            // integer in [2^23, 2^24)
+            double tot = 0.0, mag = 0.0, dev = 0.0;                // sum r, sum |r|, max |t - r|
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                          // 16 samples per lane; any split of the block will do
+                const float4 xv = *reinterpret_cast<const float4 *>(blk + q * 256 + lane * 4);
+                float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (wx) wv = *reinterpret_cast<const float4 *>(wblk + q * 256 + lane * 4);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ws[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double x = (double)xs[e] * (double)ws[e];   // exact product (x itself for w = 1)
+                    const double t = x * scale;
+                    const double r = rint(t);
+                    dev = fmax(dev, fabs(t - r));
+                    tot += r; mag += fabs(r);
+                }
+            }
+            tot = wave_sum_dpp(tot); mag = wave_sum_dpp(mag);
+            const double pp = 0.5 * (tot + mag), nn = 0.5 * (tot - mag);
+            if (!__any(dev >= 0.5) && M0 + nn >= 8388609.0 && M0 + pp <= 16777215.0) {
+                acc = (float)(ldexp(M0 + tot, ex - 24) * sgn);
+                done = true;
+            }
+        }
+        if (!done) {                                               // in order, straight from the shared arrays
+            for (unsigned base = pos; base < bend; base += 64) {
+                const int cnt = (int)(bend - base < 64 ? bend - base : 64);
+                const float4 *s4 = reinterpret_cast<const float4 *>(mine + base), *w4 = reinterpret_cast<const float4 *>(wts + base);
+                if (cnt == 64) {
+                    float4 xv[16], wv[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) { xv[q] = s4[q]; if (wx) wv[q] = w4[q]; }
+                    if (wx) {
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            acc = __builtin_fmaf(xv[q].x, wv[q].x, acc); acc = __builtin_fmaf(xv[q].y, wv[q].y, acc);
+                            acc = __builtin_fmaf(xv[q].z, wv[q].z, acc); acc = __builtin_fmaf(xv[q].w, wv[q].w, acc);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; q++) { acc += xv[q].x; acc += xv[q].y; acc += xv[q].z; acc += xv[q].w; }
+                    }
+                } else {
+                    for (int q = 0; 4 * q < cnt; q++) {
+                        const float4 x = s4[q];
+                        float4 w = make_float4(0, 0, 0, 0);
+                        if (wx) w = w4[q];
+                        const float xs[4] = {x.x, x.y, x.z, x.w}, ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (4 * q + e < cnt) {
+                                if (wx) acc = __builtin_fmaf(xs[e], ws[e], acc);
+                                else acc += xs[e];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return acc;
+}
+
 // Tail of a centroid's update block: res[0..3] = the four chain results; scales the centroid, publishes it, and the LAST block
 // to arrive handles empty clusters and writes (y, |y|^2) for the next assignment.  All 256 threads of the block call it.
 template <bool W>
@@ -1466,17 +1545,31 @@ __global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restric
                                                         unsigned long long nx, int k, float *cent, float *hassign, float4 *c4,
                                                         unsigned int *ticket, DevMT *mt) {
     __shared__ float4 stage[4][2][64];
-    extern __shared__ float4 members[];                                    // [kKmDirectCap] member records (x, y, z, w), in sample order
+    extern __shared__ __attribute__((aligned(16))) float members[];       // [4][kKmDirectCap]: the listed members in sample order, one array per component
     __shared__ float res[4];
     __shared__ int s_last;
     __shared__ unsigned int wsum[16];
+    __shared__ unsigned int n_long, long_src[256], long_lo[256], long_nb[256];   // the long runs of the current pass
     const int kidx = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float *const mx = members, *const my = members + kKmDirectCap, *const mz = members + 2 * kKmDirectCap, *const mw = members + 3 * kKmDirectCap;
+    unsigned int *const srcidx = reinterpret_cast<unsigned int *>(members + 4 * kKmDirectCap);   // [kKmDirectCap]: where a long run's records come from
     float acc = 0.f;
     size_t total = 0;
     unsigned fill = 0;                                                    // block-uniform
-    auto replay = [&]() {                                                 // the chains over members[0, fill), continuing `acc`
+    bool long_list = false;                                               // a full piece has gone by: this centroid holds thousands of samples
+    auto replay = [&]() {                                                 // the chains over the fill listed members, continuing `acc`
         const unsigned n = fill;
-        auto rec = [&](const size_t i) { return members[i]; };
+        if (n == (unsigned)kKmDirectCap || long_list) {
+            // Long lists (a dominant colour: tens of thousands of members where noise gives ~1000) take the block-parallel exact
+            // form of the chain, 1024 members at a time (km_chain_coop's step): ~0.7 us per block instead of 4.2 in sequence
+            const unsigned padded = (n + 1023u) & ~1023u;
+            for (unsigned i = n + threadIdx.x; i < padded; i += 256) { mx[i] = 0.f; my[i] = 0.f; mz[i] = 0.f; mw[i] = 0.f; }
+            __syncthreads();
+            if ((W || wid < 3) && n) acc = km_coop_lds<W>(members + (size_t)wid * kKmDirectCap, mw, n, W && wid < 3, acc, lane);
+            long_list = true;
+            return;
+        }
+        auto rec = [&](const size_t i) { return make_float4(mx[i], my[i], mz[i], mw[i]); };
         if (wid == 0) acc = km_chain_over<W, 0>(rec, n, stage[0], lane, acc);
         else if (wid == 1) acc = km_chain_over<W, 1>(rec, n, stage[1], lane, acc);
         else if (wid == 2) acc = km_chain_over<W, 2>(rec, n, stage[2], lane, acc);
@@ -1489,17 +1582,48 @@ __global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restric
         if (b < nblocks) { o0 = offs[b * 257 + kidx]; nb = (unsigned)offs[b * 257 + kidx + 1] - o0; }
         unsigned chunk_total = 0;
         const unsigned excl = block_scan_incl_u32(nb, wsum, &chunk_total) - nb;
+        // A run of more than kLongRun records (a dominant colour: hundreds of a block's 1024 samples in one centroid) is not
+        // copied by its own thread, four records at a time while the others idle, but by the whole block, 256 records at a time
+        constexpr unsigned kLongRun = 32;
+        const bool is_long = nb > kLongRun;
+        if (threadIdx.x == 0) n_long = 0u;
+        __syncthreads();
+        if (is_long) { const unsigned e = atomicAdd(&n_long, 1u); long_src[e] = (unsigned)(b * kKmSortBlock) + o0; long_lo[e] = excl; long_nb[e] = nb; }
+        __syncthreads();
+        const unsigned nl = n_long;
         unsigned done = 0;
         while (done < chunk_total) {                                      // block-uniform; one trip unless the list fills up
             const unsigned take = min((unsigned)kKmDirectCap - fill, chunk_total - done);
-            const unsigned lo = max(excl, done), hi = min(excl + nb, done + take);
-            const float4 *src = sorted_rec + b * kKmSortBlock + o0;      // this block of samples' members: one contiguous run
-            for (unsigned q = lo; q < hi; q += 4) {                       // four independent 16-byte loads per trip
-                float4 r4[4];
+            if (!is_long) {
+                const unsigned lo = max(excl, done), hi = min(excl + nb, done + take);
+                const float4 *src = sorted_rec + b * kKmSortBlock + o0;  // this block of samples' members: one contiguous run
+                for (unsigned q = lo; q < hi; q += 4) {                   // four independent 16-byte loads per trip
+                    float4 r4[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) r4[u] = q + u < hi ? src[q + u - excl] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < 4; u++) r4[u] = q + u < hi ? src[q + u - excl] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (q + u < hi) members[fill + q + u - done] = r4[u];
+                    for (int u = 0; u < 4; u++) if (q + u < hi) { const unsigned i = fill + q + u - done; mx[i] = r4[u].x; my[i] = r4[u].y; mz[i] = r4[u].z; mw[i] = r4[u].w; }
+                }
+            }
+            if (nl) {                                                     // block-uniform
+                // the long runs' records: first WHERE each comes from (LDS only), then all of them in one flat sweep with eight
+                // independent loads per thread in flight -- run by run, every run would cost a memory round trip of its own
+                for (unsigned i = threadIdx.x; i < take; i += 256) srcidx[fill + i] = ~0u;
+                __syncthreads();
+                for (unsigned e = 0; e < nl; e++) {
+                    const unsigned ex0 = long_lo[e], lo = max(ex0, done), hi = min(ex0 + long_nb[e], done + take);
+                    for (unsigned q = lo + threadIdx.x; q < hi; q += 256) srcidx[fill + q - done] = long_src[e] + (q - ex0);
+                }
+                __syncthreads();
+                for (unsigned i0 = threadIdx.x; i0 < take; i0 += 256 * 8) {
+                    unsigned ix[8]; float4 r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const unsigned i = i0 + 256u * u; ix[u] = i < take ? srcidx[fill + i] : ~0u; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r[u] = ix[u] != ~0u ? sorted_rec[ix[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (ix[u] != ~0u) { const unsigned i = fill + i0 + 256u * u; mx[i] = r[u].x; my[i] = r[u].y; mz[i] = r[u].z; mw[i] = r[u].w; }
+                }
             }
             fill += take; done += take;
             __syncthreads();
@@ -1598,13 +1722,16 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     }
     // few samples: block-local sorts in the assignment kernel, one block per centroid collects its members (k_km_update_lists)
     const size_t direct_max = getenv("PAMD_KM_DIRECT_MAX") ? (size_t)atoll(getenv("PAMD_KM_DIRECT_MAX")) : ((size_t)1 << 19);
-    const size_t list_longest = getenv("PAMD_KM_LIST_LONGEST") ? (size_t)atoll(getenv("PAMD_KM_LIST_LONGEST")) : (size_t)4096;
+    // (a cluster of up to 16 384 samples: its list is summed block-parallel in pieces of 4096 by k_km_update_lists -- a scene with a
+    // few flat regions refines in 2.3 ms instead of 3.2; beyond that the global sort + k_km_update's long-chain form wins: a colour
+    // covering 10 % / 30 % of the image 4.5 / 6.9 ms against 8.2 / 18.7, measured with the threshold swept over 4096 .. 131 072)
+    const size_t list_longest = getenv("PAMD_KM_LIST_LONGEST") ? (size_t)atoll(getenv("PAMD_KM_LIST_LONGEST")) : (size_t)16384;
     const bool use_direct = !use_lut && k <= 256 && nx <= direct_max && nx < ((size_t)1 << 32) && expect_longest < list_longest;
     if (use_direct) {
         static PerDeviceOnce attr4;
         if (attr4.first()) {
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 16));
-            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 16));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 20));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 20));
         }
     }
     static const bool mid_enabled = !(getenv("PAMD_KM_MID") && atoi(getenv("PAMD_KM_MID")) == 0);
@@ -1622,9 +1749,9 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             }
             {
                 KTIME("k_km_update", s, 16.0 * nx);
-                if (weighted) hipLaunchKernelGGL(k_km_update_lists<true>, k, 256, kKmDirectCap * 16, s, (const float4 *)w.sorted.p, (const unsigned short *)offs,
+                if (weighted) hipLaunchKernelGGL(k_km_update_lists<true>, k, 256, kKmDirectCap * 20, s, (const float4 *)w.sorted.p, (const unsigned short *)offs,
                                                  (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
-                else hipLaunchKernelGGL(k_km_update_lists<false>, k, 256, kKmDirectCap * 16, s, (const float4 *)w.sorted.p, (const unsigned short *)offs,
+                else hipLaunchKernelGGL(k_km_update_lists<false>, k, 256, kKmDirectCap * 20, s, (const float4 *)w.sorted.p, (const unsigned short *)offs,
                                         (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
             }
             continue;

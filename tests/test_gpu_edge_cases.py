@@ -227,11 +227,14 @@ def test_release_workspace_and_thread_engines(gpu, native, ob):
         assert r[0] and np.array_equal(r[1], first[1]) and np.array_equal(r[2], first[2])
 
 
-@pytest.mark.parametrize("frac", [0.08, 0.5])
-def test_dominant_colour_takes_the_sorted_kmeans_path(gpu, native, ob, frac):
-    """A colour that covers a good part of the image means ONE very long centroid chain.  The refinement then leaves the
-    list-collecting update of the few-samples path (one sample per dependent add) for the sorted path with the block-parallel
-    chain -- predicted from the size of the largest cluster the centres come from -- and must give what the oracle gives."""
+@pytest.mark.parametrize("frac,force_lists", [(0.04, False), (0.08, False), (0.5, False), (0.3, True)])
+def test_dominant_colour_long_centroid_chains(gpu, native, ob, monkeypatch, frac, force_lists):
+    """A colour that covers a good part of the image means ONE very long centroid chain.  Up to 16 384 samples in one cluster
+    (4 % of this image: 10 240) the list-collecting update sums such a list in pieces of 4096 with the block-parallel exact
+    form of the chain; beyond that the refinement takes the sorted path (predicted from the size of the largest cluster the
+    centres come from).  Either way it must give what the oracle's sequential sums give."""
+    if force_lists:                                            # 77 000 members through the list path: 19 pieces, long runs copied block-wide
+        monkeypatch.setenv("PAMD_KM_LIST_LONGEST", "100000000")
     w, h, K = 640, 400, 64
     n = w * h
     rng = np.random.default_rng(23)
