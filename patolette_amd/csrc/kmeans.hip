@@ -650,14 +650,19 @@ __device__ __forceinline__ double km_min_key(const double a, const double b) {
 // Returns the winner's address; `doubt` is set when some OTHER index reaches the smallest s or the smallest s is negative
 // (the reference clamps: ties at 0) -- then the caller runs the exact procedure; on real data a handful per million.
 // The order of the four and repeated entries (padding) do not matter.
-__device__ __forceinline__ double km_eval4(const float x0, const float x1, const float x2, const char *lb, const unsigned (&ad)[4], bool &doubt) {
+// `lb` + ad[t] are LDS byte addresses (not generic pointers: a pointer built from the kernel's extern LDS array costs one add of a
+// link-time constant per access; the callers keep the centroid records at a known address).
+typedef float KmVec4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const KmVec4 LdsF4;
+typedef __attribute__((address_space(3))) const unsigned int LdsU32;
+__device__ __forceinline__ double km_eval4(const float x0, const float x1, const float x2, const unsigned lb, const unsigned (&ad)[4], bool &doubt) {
     const float m0 = -2 * x0, m1 = -2 * x1, m2 = -2 * x2;
     const float xn = __builtin_fmaf(x2, x2, __builtin_fmaf(x0, x0, x1 * x1));
     int sb[4];
     double key[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const float4 y = *reinterpret_cast<const float4 *>(lb + ad[t]);
+        const KmVec4 y = *(LdsF4 *)(lb + ad[t]);
         float d = m0 * y.x;
         d = __builtin_fmaf(m1, y.y, d);
         d = __builtin_fmaf(m2, y.z, d);
@@ -677,7 +682,8 @@ __device__ __forceinline__ double km_eval4(const float x0, const float x1, const
 
 // Parked samples of k_km_assign_mid, a (nearly) full wavefront at a time: the 64^3 records hold up to fifteen candidates, but
 // the cell of a sample is an eighth of the crowded one and four suffice for most -- the evaluation above on the first four
-// entries (records are padded with their last); longer lists and doubtful samples take the exact procedure.  Called from ONE
+// entries (records are padded with their last), then on the rest; doubtful samples and cells of more than fifteen take the
+// exact procedure (a few per million: one straggler used to drag most drains through it).  Called from ONE
 // place (the code is long; several inlined copies cost more in instruction fetch than the drains themselves).
 struct KmDrainGrid { float lo[3], inv64[3]; int sane; };
 __device__ __forceinline__ void km_mid_drain(const int n, const uint4 *q, const float4 *lc4, unsigned int *cnt, unsigned char *assign_chunk,
@@ -694,22 +700,26 @@ __device__ __forceinline__ void km_mid_drain(const int n, const uint4 *q, const 
         rec = reinterpret_cast<const uint4 *>(lut)[dg.sane ? ((iz << 12) | (iy << 6) | ix) : 0u];
         const unsigned ad[4] = {(rec.x >> 4) & 0xff0u, (rec.x >> 12) & 0xff0u, (rec.x >> 20) & 0xff0u, (rec.y << 4) & 0xff0u};
         bool doubt;
-        double kw = km_eval4(a0, a1, a2, (const char *)lc4, ad, doubt);
+        double kw = km_eval4(a0, a1, a2, 0u, ad, doubt);
         const unsigned cnt = rec.x & 0xffu;
-        if (__any(cnt > 4u && cnt <= 8u)) {
-            // entries five to eight the same way; the two groups combine like two candidates: the smaller key wins, equal s
-            // at different addresses is a doubt (a record's padding repeats its LAST entry, so for cnt <= 4 group B is all
-            // one entry of group A and changes nothing)
-            if (cnt > 4u) {
-                const unsigned ad2[4] = {(rec.y >> 4) & 0xff0u, (rec.y >> 12) & 0xff0u, (rec.y >> 20) & 0xff0u, (rec.z << 4) & 0xff0u};
-                bool doubt2;
-                const double k2 = km_eval4(a0, a1, a2, (const char *)lc4, ad2, doubt2);
-                doubt = doubt || doubt2 || (__double2hiint(k2) == __double2hiint(kw) && __double2loint(k2) != __double2loint(kw));
-                kw = km_min_key(kw, k2);
+        // entries five to fifteen the same way, four at a time, while some lane holds that many; groups combine like
+        // candidates: the smaller key wins, equal s at different addresses is a doubt (a record's padding repeats its LAST
+        // entry, so a group beyond the record's count is all one entry of an earlier group and changes nothing)
+        auto group = [&](const unsigned wa, const unsigned wb) {
+            const unsigned adg[4] = {(wa >> 4) & 0xff0u, (wa >> 12) & 0xff0u, (wa >> 20) & 0xff0u, (wb << 4) & 0xff0u};
+            bool doubt2;
+            const double k2 = km_eval4(a0, a1, a2, 0u, adg, doubt2);
+            doubt = doubt || doubt2 || (__double2hiint(k2) == __double2hiint(kw) && __double2loint(k2) != __double2loint(kw));
+            kw = km_min_key(kw, k2);
+        };
+        if (__any(cnt > 4u && cnt <= 15u)) {
+            if (cnt > 4u) group(rec.y, rec.z);
+            if (__any(cnt > 8u && cnt <= 15u)) {
+                if (cnt > 8u) { group(rec.z, rec.w); group(rec.w, rec.w >> 24); }
             }
         }
         a = (int)((unsigned)__double2loint(kw) >> 4);
-        exact = doubt || cnt > 8u || !dg.sane;
+        exact = doubt || cnt > 15u || !dg.sane;                                   // 255: the cell keeps more than fifteen
     }
     if (__any(exact)) {
         if (exact) {
@@ -738,6 +748,10 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
     unsigned int *cnt = lds_u + 4 * 256 + (size_t)wid * 256;                      // this wavefront's counters
     unsigned int *T = lds_u + 4 * 256 + 16 * 256;                                 // [ncell]
     uint4 *q = (uint4 *)(T + ncell) + wid * kKmQueue;                             // this wavefront's parked samples
+    // the hot loop addresses LDS by number: the centroid records at byte 0, the table at byte kTableAt (this kernel has no
+    // static LDS, so the extern array starts at 0; anything else is a build that must not run)
+    constexpr unsigned kTableAt = (4 * 256 + 16 * 256) * 4;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned int *)lds_u != 0u) __builtin_trap();
     for (int i = threadIdx.x; i < ncell / 4; i += 1024) ((uint4 *)T)[i] = ((const uint4 *)mid)[i];
     for (int j = threadIdx.x; j < 256; j += 1024) lc4[j] = j < k ? c4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = lane; j < 256; j += 64) cnt[j] = 0u;
@@ -753,16 +767,19 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
     for (int a = 0; a < 3; a++) {
         const double r = (double)g.hi[a] - (double)g.lo[a];
         flo[a] = g.lo[a];
-        finv[a] = r > 0 ? (float)(32.0 * (1.0 - 0x1.0p-18) / r) : 0.f;
+        finv[a] = r > 0 ? (float)(32.0 * (1.0 - 0x1.0p-18) / r) : 0.f;                // (zeroed below when the range is not sane)
         finv64[a] = r > 0 ? (float)(64.0 * (1.0 - 0x1.0p-18) / r) : 0.f;
         sane = sane && fabsf(g.lo[a]) < 1e18f && fabsf(g.hi[a]) < 1e18f && (r == 0 || r > 1e-30);
     }
+    // not sane: every sample parks, and its table entry is never used -- a factor 0 sends (x - lo) * 0 = 0 or NaN to cell 0
+    // (v_cvt_u32_f32 of NaN is 0) without a select per sample
+#pragma unroll
+    for (int a = 0; a < 3; a++) finv[a] = sane ? finv[a] : 0.f;
     KmDrainGrid dg;
 #pragma unroll
     for (int a = 0; a < 3; a++) { dg.lo[a] = flo[a]; dg.inv64[a] = finv64[a]; }
     dg.sane = sane ? 1 : 0;
-    const unsigned long long ltmask = (1ULL << lane) - 1ULL;
-    const char *lb = (const char *)lc4;
+    constexpr unsigned lb = 0u;
     for (int chunk = blockIdx.x * 16 + wid; chunk < nchunks; chunk += gridDim.x * 16) {
         const size_t lo = (size_t)chunk * chunk_len;
         const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
@@ -771,9 +788,10 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
         // the samples of trip n+1 are requested before trip n is evaluated (a wavefront owns its chunk: nothing else hides
         // the memory latency at four wavefronts per SIMD)
         float n0[P], n1[P], n2[P];
-        auto fetch = [&](const size_t base) {
-            const unsigned left = (unsigned)min((size_t)(64 * P), hi - base);    // wave-uniform base + 32-bit lane offsets
-            const float *bx = s.x + base, *by = s.y + base, *bz = s.z + base;
+        const unsigned len = (unsigned)(hi > lo ? hi - lo : 0);                   // 32-bit positions inside the chunk: scalar compares
+        auto fetch = [&](const unsigned rel) {
+            const unsigned left = min(64u * P, len - rel);                        // wave-uniform base + 32-bit lane offsets
+            const float *bx = s.x + lo + rel, *by = s.y + lo + rel, *bz = s.z + lo + rel;
             if (left == 64u * P) {                                               // chunks start at multiples of 64 samples: 16-byte aligned
 #pragma unroll
                 for (int gq = 0; gq < PG; gq++) {
@@ -788,39 +806,50 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
                 for (int p = 0; p < P; p++) {
                     const unsigned j = min(256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3), left - 1u);
                     n0[p] = bx[j]; n1[p] = by[j]; n2[p] = bz[j];
-                }
+                    asm volatile("" ::: "memory");                               // keeps the two branches apart (merged, the 16-byte loads
+                }                                                                 // above become twelve 4-byte ones)
             }
         };
-        if (lo < hi) fetch(lo);
-        for (size_t base = lo; base < hi; base += 64 * P) {
+        if (len) fetch(0u);
+        // the first trip's samples are waited for HERE: left pending into the loop they make the compiler's wait-count
+        // bookkeeping (merged over both ways into the loop) wait for the NEXT trip's loads at the top of every trip
+#pragma unroll
+        for (int p = 0; p < P; p++) asm volatile("" :: "v"(n0[p]), "v"(n1[p]), "v"(n2[p]));
+        for (unsigned rel = 0; rel < len; rel += 64 * P) {
             float x0[P], x1[P], x2[P];
             bool v[P];
-            const unsigned left = (unsigned)min((size_t)(64 * P), hi - base);
-            unsigned char *ba = assign + base;
+            const unsigned left = min(64u * P, len - rel);
+            unsigned char *ba = assign + lo + rel;
 #pragma unroll
             for (int p = 0; p < P; p++) { x0[p] = n0[p]; x1[p] = n1[p]; x2[p] = n2[p]; v[p] = 256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3) < left; }
             unsigned packed[PG];
 #pragma unroll
             for (int gq = 0; gq < PG; gq++) packed[gq] = 0u;
-            if (base + 64 * P < hi) fetch(base + 64 * P);
+            fetch(rel + 64 * P < len ? rel + 64 * P : 0u);                       // after the last trip: the first again, unused (an
+                                                                                  // unconditional fetch keeps the registers of the two trips apart)
             unsigned e[P];
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const unsigned ix = __float2uint_rz((x0[p] - flo[0]) * finv[0]), iy = __float2uint_rz((x1[p] - flo[1]) * finv[1]),
                                iz = __float2uint_rz((x2[p] - flo[2]) * finv[2]);
-                e[p] = *reinterpret_cast<const unsigned int *>(reinterpret_cast<const char *>(T) + (sane ? ((iz << 12) | (iy << 7) | (ix << 2)) : 0u));
+                e[p] = *(LdsU32 *)(kTableAt + ((iz << 12) | (iy << 7) | (ix << 2)));
             }
             unsigned ovbits = 0;
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 // the (up to) four candidates of the cell (k % 8 == 0: no scalar leftovers in the reference's procedure)
-                const unsigned ad[4] = {(e[p] << 4) & 0xff0u, (e[p] >> 4) & 0xff0u, (e[p] >> 12) & 0xff0u, (e[p] >> 20) & 0xff0u};
+                const unsigned ad[4] = {(e[p] & 0xffu) << 4, (e[p] >> 4) & 0xff0u, (e[p] >> 12) & 0xff0u, (e[p] >> 20) & 0xff0u};
                 bool doubt;
                 const unsigned cur_i = (unsigned)__double2loint(km_eval4(x0[p], x1[p], x2[p], lb, ad, doubt)) >> 4;
                 const bool park = (doubt || e[p] == kKmMidOverflow || !sane) && v[p];
                 ovbits |= park ? (1u << p) : 0u;
                 if (v[p] && !park) { packed[p >> 2] |= cur_i << (8 * (p & 3)); atomicAdd(&cnt[cur_i], 1u); }
             }
+            // the next trip's samples are waited for BEFORE this trip's store goes out (they were requested ~400 instructions
+            // ago): loads and stores retire through one in-order counter, so a wait placed after the store -- where the
+            // values are first needed -- would also wait for the store, once per trip
+#pragma unroll
+            for (int p = 0; p < P; p++) asm volatile("" :: "v"(n0[p]), "v"(n1[p]), "v"(n2[p]));
             if (left == 64u * P) {                                                // parked samples: 0 for now, the drain writes theirs
 #pragma unroll
                 for (int gq = 0; gq < PG; gq++) reinterpret_cast<unsigned int *>(ba)[64 * gq + lane] = packed[gq];
@@ -828,25 +857,29 @@ __global__ __launch_bounds__(1024) void k_km_assign_mid(KmSamples s, size_t nx, 
 #pragma unroll
                 for (int p = 0; p < P; p++) if (v[p]) ba[256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3)] = (unsigned char)(packed[p >> 2] >> (8 * (p & 3)));
             }
-            const bool lasttrip = base + 64 * P >= hi;
+            const bool lasttrip = rel + 64 * P >= len;
             if (__ballot(ovbits != 0u) || lasttrip) {
                 // park: the samples of this trip are numbered slot-major (all of slot 0, then slot 1, ...); as many as fit go
                 // into the queue, a full queue is drained, and so on -- one loop around ONE drain site
                 unsigned long long m[P];
-                int off[P + 1];
+                int off[P + 1], rank[P];
                 off[0] = 0;
 #pragma unroll
-                for (int p = 0; p < P; p++) { m[p] = __ballot((ovbits >> p) & 1u); off[p + 1] = off[p] + (int)__popcll(m[p]); }
+                for (int p = 0; p < P; p++) {
+                    m[p] = __ballot((ovbits >> p) & 1u);
+                    off[p + 1] = off[p] + (int)__popcll(m[p]);
+                    rank[p] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[p] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[p], 0u));
+                }
                 const int btot = off[P];
                 int done = 0;
                 do {                                                              // wave-uniform
                     const int take = min(kKmQueue - qn, btot - done);
 #pragma unroll
                     for (int p = 0; p < P; p++) {
-                        const int gr = off[p] + (int)__popcll(m[p] & ltmask) - done;
+                        const int gr = off[p] + rank[p] - done;
                         if (((ovbits >> p) & 1u) && gr >= 0 && gr < take)
                             q[qn + gr] = make_uint4(__float_as_uint(x0[p]), __float_as_uint(x1[p]), __float_as_uint(x2[p]),
-                                                    (unsigned)(base - lo) + 256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3));
+                                                    rel + 256u * (unsigned)(p >> 2) + (unsigned)lane * 4u + (unsigned)(p & 3));
                     }
                     qn += take; done += take;
                     if (qn == kKmQueue || (lasttrip && done == btot)) { drain(qn); qn = 0; }
