@@ -206,6 +206,23 @@ def content_times(L, native, cfg):
         st = native.last_stats()
         out[name] = {"ms": round(1e3 * sorted(times)[1], 3), "ms_lq": round(st["ms_lq"], 3), "ms_kmeans": round(st["ms_kmeans"], 3),
                      "split_evals": st["split_evals"]}
+        if niter > 0:
+            # the same image with the order-free centroid update (an option: include/patolette_amd.h), whose cost does not depend
+            # on how the samples spread over the centroids
+            before = L.patolette_amd_set_kmeans_update(1)
+            try:
+                t1 = []
+                for i in range(3):
+                    L.patolette_amd_synchronize()
+                    t0 = time.perf_counter()
+                    L.patolette_amd_device(width, height, d, None, K, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+                    L.patolette_amd_synchronize()
+                    if i:
+                        t1.append(time.perf_counter() - t0)
+                if code.value == 0:
+                    out[name]["order_free_kmeans_update"] = {"ms": round(1e3 * min(t1), 3), "ms_kmeans": round(native.last_stats()["ms_kmeans"], 3)}
+            finally:
+                L.patolette_amd_set_kmeans_update(before)
     try:
         run(scene, "scene")
         run(np.round(scene * 7.0) / 7.0, "posterised")
@@ -283,6 +300,9 @@ def main():
     ap.add_argument("--extra-streams", type=int, default=3,
                     help="after the timed region also measure throughput with this many concurrent images per GPU; reported "
                          "separately as throughput_concurrent, never as `value` (0 = skip)")
+    ap.add_argument("--kmeans-update", type=int, default=0, choices=[0, 1],
+                    help="1: the order-free centroid update (patolette_amd_set_kmeans_update(1): an option within north_star's 1e-5, "
+                         "not the reference's bits); the line then says so in config.kmeans_update and is never the headline")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -330,6 +350,8 @@ def main():
     if L.patolette_amd_set_device(local_rank) != 0:
         raise SystemExit("bench.py: cannot select device %d" % local_rank)
 
+    if args.kmeans_update:
+        L.patolette_amd_set_kmeans_update(1)
     cfg = CONFIGS[args.config]
     width, height, K, cs, niter, max_samples, dither, weighted, desc = cfg
     n = width * height
@@ -542,7 +564,9 @@ def main():
         "value": round(value, 3), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": desc, "width": width, "height": height, "palette_size": K, "images_per_step_per_gpu": S,
+        "config": {"workload": desc, "kmeans_update": ("order-free exact sums (OPTION: within 1e-5 of the reference, not its bits)"
+                                                        if args.kmeans_update else "reference (sequential f32 chains, bit-exact)"),
+                   "width": width, "height": height, "palette_size": K, "images_per_step_per_gpu": S,
                    "input": "uniform random sRGB (splitmix64), planar f64, resident in HBM; index map left in HBM as u8",
                    "cached_between_steps": "the KMeans subsample index list (faiss rand_perm(N, seed 1234): a pure function of N and the sample count, "
                                            "262 144 mt19937 draws + 1 MB upload, ~2 ms) is built in the first warm-up step and reused; a pool of <= 3 "

@@ -182,6 +182,16 @@ void patolette_amd_slice_device(size_t total_pixels, size_t slice_begin, size_t 
  * sliced path always does; 190 instead of 157 us per 4096^2 level in the partition kernel, +7 % on the whole step); 0 (default): per-thread partial sums first.  Applies to
  * the calling thread's later calls.  Returns the previous setting. */
 int patolette_amd_set_invariant_sums(int on);
+/* The centroid update of the KMeans refinement.  0 (default): the reference's, bit for bit -- every centroid is the sequential f32
+ * sum of its samples in sample order (faiss Clustering.cpp:135-204), which costs a stable sort of the samples and one dependent
+ * chain per centroid in every iteration.  1: order-free -- the sums are taken exactly (64-bit fixed point) and rounded to f32
+ * once: deterministic, independent of how the samples spread over the centroids, 4.4x faster per KMeans stage at 67 M samples,
+ * but NOT the reference's bits: per iteration the centroids differ by what its f32 chains round away (~1e-6 of the colour range),
+ * and a sample on the border of two cells that therefore changes sides moves a centroid of m members by |x - c| / m (1e-4 at the
+ * default 1024 members, 1e-6 at 65 536): most palette rows stay within BASELINE's 1e-5, a few do not, and ~0.02 % of the index
+ * map follows them (tests/test_gpu_kmeans_update.py prints the measured figures).  Process-wide; applies to later calls.  Returns
+ * the previous setting.  Environment default: PAMD_KMEANS_UPDATE=1. */
+int patolette_amd_set_kmeans_update(int mode);
 
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
 /* patolette__EIGEN_solve (math/eigen.c:83-140: LAPACK dsyev 'V','L', n = 3) as the split loop's host side solves it:

@@ -102,6 +102,13 @@ def quantize(width, height, colors, palette_size, dither=True, palette_only=Fals
     return (success, palette, palette_map, message)
 
 
+def set_kmeans_update(mode):
+    """KMeans centroid update: 0 (default) = the reference's sequential f32 chains, bit for bit; 1 = order-free exact sums rounded
+    once (faster, content-independent, within the north_star tolerance of the reference but not its bits).  Process-wide; returns
+    the previous setting (include/patolette_amd.h: patolette_amd_set_kmeans_update)."""
+    return int(_native.lib().patolette_amd_set_kmeans_update(int(mode)))
+
+
 def saliency_weights(width, height, colors, tile_size=512):
     """The weights `quantize` derives when tile_size > 0 (reference `get_weights`, patolette.pyx:203-313),
     computed on the GPU.  colors as for `quantize`.  Returns width*height float64."""

@@ -22,6 +22,7 @@ struct KMeansWork {
     DevBuf<unsigned char> lut, grid, clist;   // pruned assignment: candidate records per grid cell, sample bounding box, coarse lists
     DevBuf<unsigned int> mid;                 // 32^3 table of four-candidate entries (held in LDS by k_km_assign_mid)
     DevBuf<unsigned int> bkeys;
+    DevBuf<unsigned long long> fsum;          // order-free update (KmSums): per centroid 4 fixed-point sums (x, y, z, weight or count)
     void reserve(size_t nx, int k);
 };
 
@@ -33,6 +34,13 @@ void kmeans_gather_slice(const double *d_planar, size_t n_local, bool weighted, 
 // few-samples path replays a centroid's chain at one sample per dependent add (3.3 ns), so one long cluster paces every
 // iteration (a colour covering 30 % of the image: 46 ms instead of 5); from 4096 expected samples on the iterations take the
 // sorted path, whose update sums long clusters block-parallel (km_chain_coop).
-void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s, size_t expect_longest = 0);
+// sums: null = the reference's update bit for bit (sequential f32 chains in sample order).  Otherwise the ORDER-FREE update
+// (patolette_amd_set_kmeans_update(1)): a centroid's sums are taken as 64-bit fixed-point integers -- exact in any order, so still
+// run-to-run and launch-geometry deterministic -- and rounded to f32 once; no sort, no chain.  The centroids then differ from the
+// reference's by what ITS f32 chains round away (~1e-6 of the colour range per iteration) and from there by the samples whose
+// nearest centroid that flips (|x - c| / members each).
+struct KmSums { double bound_x, bound_w; };   // |coordinate| <= bound_x and 0 <= weight <= bound_w over all samples
+void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s, size_t expect_longest = 0,
+                    const KmSums *sums = nullptr);
 
 }  // namespace pamd

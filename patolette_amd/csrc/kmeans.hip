@@ -1672,6 +1672,81 @@ __global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restric
 }
 
 // --------------------------------------------------------------------------------------------
+// Order-free update (option, kmeans.h KmSums): per-centroid sums as 64-bit fixed-point integers.  An addend v (|v| <= 2^E, at
+// most 2^P of them) is rounded to the nearest multiple of the quantum 2^Q, Q = E + P - 62 (35 bits below the bound at 2^27
+// samples), by the magic-number add, and summed as an integer: LDS atomics per block, one global 64-bit atomic per centroid,
+// quantity and block at the end -- any order gives the same bits.  13 (17) bytes per sample.
+// --------------------------------------------------------------------------------------------
+struct KmFix { double magic_x, quantum_x, magic_w, quantum_w; };
+__device__ __forceinline__ long long km_fix_quant(const double v, const double magic) {       // v / quantum to nearest-even
+    return __double_as_longlong(v + magic) - __double_as_longlong(magic);
+}
+template <bool W, typename AT>
+__global__ __launch_bounds__(256) void k_km_accum(KmSamples s, const AT *__restrict__ assign, size_t nx, int k, KmFix f,
+                                                  unsigned long long *gsum /* [k][4] */) {
+    extern __shared__ unsigned long long acc64[];                                               // [k][4]
+    for (int i = threadIdx.x; i < 4 * k; i += 256) acc64[i] = 0ULL;
+    __syncthreads();
+    auto add = [&](const unsigned a, const float x, const float y, const float z, const float w) {
+        const double wd = W ? (double)w : 1.0;                                                  // f32 * f32: exact in f64
+        unsigned long long *r = acc64 + 4 * (size_t)a;
+        atomicAdd(r, (unsigned long long)km_fix_quant((double)x * wd, f.magic_x));
+        atomicAdd(r + 1, (unsigned long long)km_fix_quant((double)y * wd, f.magic_x));
+        atomicAdd(r + 2, (unsigned long long)km_fix_quant((double)z * wd, f.magic_x));
+        atomicAdd(r + 3, W ? (unsigned long long)km_fix_quant(wd, f.magic_w) : 1ULL);
+    };
+    const size_t stride = (size_t)gridDim.x * 1024;
+    for (size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; base < nx; base += stride) {
+        if (base + 4 <= nx) {                                                                   // the arrays are 16-byte aligned
+            const float4 vx = *reinterpret_cast<const float4 *>(s.x + base), vy = *reinterpret_cast<const float4 *>(s.y + base),
+                         vz = *reinterpret_cast<const float4 *>(s.z + base);
+            float4 vw = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (W) vw = *reinterpret_cast<const float4 *>(s.w + base);
+            unsigned a0, a1, a2, a3;
+            if constexpr (sizeof(AT) == 1) {
+                const unsigned pk = *reinterpret_cast<const unsigned int *>(assign + base);
+                a0 = pk & 0xffu; a1 = (pk >> 8) & 0xffu; a2 = (pk >> 16) & 0xffu; a3 = pk >> 24;
+            } else {
+                const int4 pk = *reinterpret_cast<const int4 *>(assign + base);
+                a0 = (unsigned)pk.x; a1 = (unsigned)pk.y; a2 = (unsigned)pk.z; a3 = (unsigned)pk.w;
+            }
+            add(a0, vx.x, vy.x, vz.x, vw.x); add(a1, vx.y, vy.y, vz.y, vw.y);
+            add(a2, vx.z, vy.z, vz.z, vw.z); add(a3, vx.w, vy.w, vz.w, vw.w);
+        } else {
+            for (size_t i = base; i < nx; i++) add((unsigned)assign[i], s.x[i], s.y[i], s.z[i], W ? s.w[i] : 1.f);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * k; i += 256) { const unsigned long long v = acc64[i]; if (v) atomicAdd(&gsum[i], v); }
+}
+
+// One block: sums -> centroids (c = f32(sum) * (1 / h), h = the count or the weight sum as a float), empty clusters (Clustering.cpp:216-263), the (y, |y|^2) records of the next assignment; zeroes the sums.
+template <bool W>
+__global__ __launch_bounds__(256) void k_km_update_sums(unsigned long long *gsum, int k, unsigned long long nx, KmFix f, float *cent,
+                                                        float *hassign, float4 *c4, DevMT *mt) {
+    __shared__ int s_empty;
+    if (threadIdx.x == 0) s_empty = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 256) {
+        const double sx = (double)(long long)gsum[4 * j] * f.quantum_x, sy = (double)(long long)gsum[4 * j + 1] * f.quantum_x,
+                     sz = (double)(long long)gsum[4 * j + 2] * f.quantum_x;
+        float h;
+        if constexpr (W) h = (float)((double)(long long)gsum[4 * j + 3] * f.quantum_w);
+        else h = (float)gsum[4 * j + 3];                                                        // (the reference's count sticks at 2^24)
+        float c0 = (float)sx, c1 = (float)sy, c2 = (float)sz;
+        if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
+        else s_empty = 1;
+        cent[3 * j] = c0; cent[3 * j + 1] = c1; cent[3 * j + 2] = c2; hassign[j] = h;
+        gsum[4 * j] = 0ULL; gsum[4 * j + 1] = 0ULL; gsum[4 * j + 2] = 0ULL; gsum[4 * j + 3] = 0ULL;
+    }
+    __threadfence();
+    __syncthreads();
+    if (s_empty && threadIdx.x == 0) { km_split_clusters(cent, hassign, k, nx, *mt); __threadfence(); }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 256) km_store_c4(c4, k, j, cent[3 * j], cent[3 * j + 1], cent[3 * j + 2]);
+}
+
+// --------------------------------------------------------------------------------------------
 static int chunk_len_for(size_t nx) {
     size_t c = ceil_div(nx, 4096);                 // at most ~4096 chunks (one wavefront each)
     c = ceil_div(c, 64) * 64;
@@ -1715,8 +1790,46 @@ void kmeans_gather_slice(const double *d_planar, size_t n_local, bool weighted, 
     HIP_CHECK(hipGetLastError());
 }
 
-void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s, size_t expect_longest) {
+void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, hipStream_t s, size_t expect_longest, const KmSums *sums) {
     KmSamples ks{w.sx.p, w.sy.p, w.sz.p, w.sw.p};
+    KmFix fix{};
+    int ablocks = 1;
+    if (sums) {
+        int ex = 0, ew = 0, P = 1;
+        (void)frexp(std::max(sums->bound_x, 1e-300) * (weighted ? std::max(sums->bound_w, 1e-300) : 1.0), &ex);   // |w x| <= 2^ex
+        (void)frexp(std::max(sums->bound_w, 1e-300), &ew);
+        while (((size_t)1 << P) < nx) P++;
+        P = std::max(P + 1, 12);                                    // |addend| / quantum = 2^(62 - P) must stay below 2^51
+        fix.quantum_x = ldexp(1.0, ex + P - 62); fix.magic_x = ldexp(1.5, 52 + ex + P - 62);
+        fix.quantum_w = ldexp(1.0, ew + P - 62); fix.magic_w = ldexp(1.5, 52 + ew + P - 62);
+        w.fsum.reserve(4 * (size_t)k);
+        HIP_CHECK(hipMemsetAsync(w.fsum.p, 0, 4 * (size_t)k * sizeof(unsigned long long), s));
+        ablocks = (int)std::min<size_t>(std::max<size_t>(ceil_div(nx, (size_t)4096), 1), 2048);
+        static PerDeviceOnce attr5;
+        if (attr5.first()) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_accum<true, int>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * kKMeansMaxK));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_accum<false, int>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * kKMeansMaxK));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_accum<true, unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * kKMeansMaxK));
+            HIP_CHECK(hipFuncSetAttribute((const void *)k_km_accum<false, unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * kKMeansMaxK));
+        }
+    }
+    // the order-free update after any of the assignment kernels below (a8: one byte per sample, else an int)
+    auto update_sums = [&](const bool a8) {
+        {
+            KTIME("k_km_accum", s, ((weighted ? 16.0 : 12.0) + (a8 ? 1.0 : 4.0)) * nx);
+            const size_t lds = (size_t)32 * k;
+            if (a8) {
+                if (weighted) hipLaunchKernelGGL((k_km_accum<true, unsigned char>), ablocks, 256, lds, s, ks, (const unsigned char *)w.assign.p, nx, k, fix, w.fsum.p);
+                else hipLaunchKernelGGL((k_km_accum<false, unsigned char>), ablocks, 256, lds, s, ks, (const unsigned char *)w.assign.p, nx, k, fix, w.fsum.p);
+            } else {
+                if (weighted) hipLaunchKernelGGL((k_km_accum<true, int>), ablocks, 256, lds, s, ks, (const int *)w.assign.p, nx, k, fix, w.fsum.p);
+                else hipLaunchKernelGGL((k_km_accum<false, int>), ablocks, 256, lds, s, ks, (const int *)w.assign.p, nx, k, fix, w.fsum.p);
+            }
+        }
+        KTIME("k_km_update", s, 32.0 * k);
+        if (weighted) hipLaunchKernelGGL(k_km_update_sums<true>, 1, 256, 0, s, w.fsum.p, k, (unsigned long long)nx, fix, w.cent.p, w.hassign.p, w.c4.p, w.mt.p);
+        else hipLaunchKernelGGL(k_km_update_sums<false>, 1, 256, 0, s, w.fsum.p, k, (unsigned long long)nx, fix, w.cent.p, w.hassign.p, w.c4.p, w.mt.p);
+    };
     int nbits = 0;
     while ((1 << nbits) < k) nbits++;
     const int chunk_len = chunk_len_for(nx);
@@ -1759,7 +1872,7 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     // few flat regions refines in 2.3 ms instead of 3.2; beyond that the global sort + k_km_update's long-chain form wins: a colour
     // covering 10 % / 30 % of the image 4.5 / 6.9 ms against 8.2 / 18.7, measured with the threshold swept over 4096 .. 131 072)
     const size_t list_longest = getenv("PAMD_KM_LIST_LONGEST") ? (size_t)atoll(getenv("PAMD_KM_LIST_LONGEST")) : (size_t)16384;
-    const bool use_direct = !use_lut && k <= 256 && nx <= direct_max && nx < ((size_t)1 << 32) && expect_longest < list_longest;
+    const bool use_direct = !sums && !use_lut && k <= 256 && nx <= direct_max && nx < ((size_t)1 << 32) && expect_longest < list_longest;
     if (use_direct) {
         static PerDeviceOnce attr4;
         if (attr4.first()) {
@@ -1818,6 +1931,7 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             KTIME("k_km_assign", s, 16.0 * nx);
             hipLaunchKernelGGL(k_km_assign_count, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p);
         }
+        if (sums) { update_sums(use_lut && use_mid); continue; }
         { KTIME("k_km_rowscan", s, 8.0 * k * nchunks); hipLaunchKernelGGL(k_km_rowscan, k, 256, 0, s, w.table.p, nchunks, w.rowtot.p); }
         {
             KTIME("k_km_scatter", s, (weighted ? 36.0 : 32.0) * nx - (use_mid ? 3.0 : 0.0) * nx);

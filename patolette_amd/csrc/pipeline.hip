@@ -931,9 +931,20 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
 // --------------------------------------------------------------------------------------------
 // largest_cluster: pixels of the most populous cluster the centres come from (0 = unknown): a dominant colour means one very long
 // centroid chain, and the iterations then take the sorted path with the block-parallel chain from the start (kmeans_iterate)
+// patolette_amd_set_kmeans_update: process-wide (the batch entry's helper threads must see the caller's choice).  -1: not set, the
+// environment's default (PAMD_KMEANS_UPDATE)
+std::atomic<int> g_km_update{-1};
+static bool km_update_order_free() {
+    static const bool env = getenv("PAMD_KMEANS_UPDATE") && atoi(getenv("PAMD_KMEANS_UPDATE")) != 0;
+    const int v = g_km_update.load(std::memory_order_relaxed);
+    return v < 0 ? env : v != 0;
+}
+// bound_x / bound_w: upper bounds of |colour value| and of the weights over the image (the order-free update scales by them)
 static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double> &centers, size_t k, int niter, size_t max_samples,
-                          bool nonfinite, unsigned long long largest_cluster = 0) {
+                          bool nonfinite, unsigned long long largest_cluster, double bound_x, double bound_w) {
     hipStream_t s = E.stream;
+    const KmSums sums_v{bound_x, bound_w};
+    const KmSums *sums = km_update_order_free() ? &sums_v : nullptr;
     if (k > (size_t)kKMeansMaxK) throw HipError("patolette_amd: KMeans refinement supports at most 4096 palette entries");
     std::vector<float> cent(3 * k);
     for (size_t i = 0; i < k; i++) for (int j = 0; j < 3; j++) cent[3 * i + j] = (float)centers[(size_t)j * k + i];   // refine.c:102-125
@@ -981,7 +992,7 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
             } else {
                 HIP_CHECK(hipMemcpyAsync(E.km.cent.p, cent.data(), 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                kmeans_iterate(E.km, nx, (int)k, weighted, niter, s, expect_longest(nx));
+                kmeans_iterate(E.km, nx, (int)k, weighted, niter, s, expect_longest(nx), sums);
                 HIP_CHECK(hipMemcpyAsync(cent.data(), E.km.cent.p, 3 * k * sizeof(float), hipMemcpyDeviceToHost, s));
                 E.sync();
                 E.stats.kmeans_samples = nx;
@@ -995,7 +1006,7 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
             E.h_cent.reserve(3 * k);                                               // pinned: no synchronisation before the iterations
             std::memcpy(E.h_cent.p, cent.data(), 3 * k * sizeof(float));
             HIP_CHECK(hipMemcpyAsync(E.km.cent.p, E.h_cent.p, 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
-            kmeans_iterate(E.km, nx, (int)k, weighted, niter, s, expect_longest(nx));
+            kmeans_iterate(E.km, nx, (int)k, weighted, niter, s, expect_longest(nx), sums);
             HIP_CHECK(hipMemcpyAsync(E.h_cent.p, E.km.cent.p, 3 * k * sizeof(float), hipMemcpyDeviceToHost, s));
             E.sync();
             std::memcpy(cent.data(), E.h_cent.p, 3 * k * sizeof(float));
@@ -1132,7 +1143,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     t0 = now_ms();
     if (opt->kmeans_niter > 0) {
         if (opt->verbose) printf("patolette ======== KMeans refinement\n");                // patolette.c:249-251
-        kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples, bnd.nonfinite, largest_cluster);
+        kmeans_refine(E, N, weighted, pal, len, opt->kmeans_niter, opt->kmeans_max_samples, bnd.nonfinite, largest_cluster, bnd.cmax, bnd.wmax);
     }
     E.stats.ms_kmeans = now_ms() - t0;
 
@@ -1564,6 +1575,12 @@ int patolette_amd_set_invariant_sums(int on) {
     return before;
 }
 
+int patolette_amd_set_kmeans_update(int mode) {
+    const int before = km_update_order_free() ? 1 : 0;
+    g_km_update.store(mode != 0 ? 1 : 0, std::memory_order_relaxed);
+    return before;
+}
+
 int patolette_amd_saliency_weights(size_t width, size_t height, const double *data, double tile_size, double *weights_out) {
     const size_t N = width * height;
     if (N == 0) return kSalBadShape;
@@ -1889,7 +1906,12 @@ int patolette_amd_kmeans_refine(const double *colors, const double *weights, siz
     std::vector<double> pal(centers_io, centers_io + 3 * k);
     bool nonfinite = false;                                     // Clustering.cpp:295-304 over every colour value as f32
     for (size_t i = 0; i < 3 * n && !nonfinite; i++) nonfinite = !(std::fabs(colors[i]) < 0x1.ffffffp127);
-    kmeans_refine(E, n, weighted, pal, k, niter, max_samples, nonfinite);
+    double bx = 0, bw = 1;
+    if (!nonfinite && km_update_order_free()) {
+        for (size_t i = 0; i < 3 * n; i++) bx = std::max(bx, std::fabs(colors[i]));
+        if (weighted) for (size_t i = 0; i < n; i++) bw = std::max(bw, std::fabs(weights[i]));
+    }
+    kmeans_refine(E, n, weighted, pal, k, niter, max_samples, nonfinite, 0, bx, bw);
     std::memcpy(centers_io, pal.data(), 3 * k * sizeof(double));
     return 0;
     PAMD_GUARD_END(-1)
