@@ -18,7 +18,8 @@ struct KMeansWork {
     DevBuf<float> cent, hassign;       // interleaved xyz centroids (faiss layout)
     DevBuf<float4> c4;                 // (y0,y1,y2,|y|^2)
     DevBuf<int> perm;                  // subsample indices
-    DevBuf<struct DevMT> mt;
+    DevBuf<struct DevMT> mt;           // std::mt19937(1234) as seeded (read-only after k_km_mt_seed)
+    bool mt_seeded = false;
     DevBuf<unsigned char> lut, grid, clist;   // pruned assignment: candidate records per grid cell, sample bounding box, coarse lists
     DevBuf<unsigned int> mid;                 // 32^3 table of four-candidate entries (held in LDS by k_km_assign_mid)
     DevBuf<unsigned int> bkeys;

@@ -1017,32 +1017,60 @@ struct DevMT {
         for (int i = 1; i < 624; i++) mt[i] = 1812433253U * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned)i;
         idx = 624;
     }
-    __device__ unsigned next() {
-        if (idx >= 624) {
-            for (int i = 0; i < 624; i++) {
-                unsigned y = (mt[i] & 0x80000000U) | (mt[(i + 1) % 624] & 0x7fffffffU);
-                unsigned v = mt[(i + 397) % 624] ^ (y >> 1);
-                if (y & 1U) v ^= 0x9908b0dfU;
-                mt[i] = v;
-            }
-            idx = 0;
-        }
-        unsigned y = mt[idx++];
-        y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680U; y ^= (y << 15) & 0xefc60000U; y ^= (y >> 18);
-        return y;
-    }
 };
 
-__device__ void km_split_clusters(float *cent, float *hassign, int k, unsigned long long n, DevMT &rng) {
-    rng.seed(1234u);
+// split_clusters (Clustering.cpp:216-263): every empty cluster ci, in index order, takes over half of a donor cj found by walking
+// cj = 0, 1, ... (cyclically) with one draw r of std::mt19937(1234) per candidate until r < (h[cj] - 1) / (n - k); ci becomes a
+// copy of cj, the two are nudged apart by a factor 1 +- 1/1024 per coordinate, and the size is shared.
+// Taken by ONE WAVEFRONT (all 64 lanes call it).  An empty cluster costs ~k draws (each candidate is accepted
+// with probability ~1/k), a posterised image leaves a hundred clusters empty in every iteration, and one lane gets through a draw
+// in ~7 ns: 190 us per iteration.  Here lane t tests candidate cj0 + t against draw number t of the remaining sequence -- the
+// first hit is the sequential loop's hit, and exactly the draws up to it are consumed.  The generator's state sits in LDS: its
+// start (seed 1234, `seeded`, built once per workspace) is copied in, a block of 624 outputs is re-generated 64 words at a time
+// in ascending order, every lane reading its three inputs before any lane writes -- word i sees the old i + 1 and i + 397 (or
+// the new i - 227), as in the sequential loop.  s_mt: 624 words, s_h: k floats (the sizes, updated as clusters are split).
+__device__ __forceinline__ void km_split_clusters_wave(float *cent, float *hassign, const int k, const unsigned long long n, const DevMT *seeded,
+                                                       unsigned *s_mt, float *s_h, const int lane) {
+    for (int i = lane; i < 624; i += 64) s_mt[i] = seeded->mt[i];
+    for (int j = lane; j < k; j += 64) s_h[j] = hassign[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int idx = 624;                                                          // nothing generated yet (DevMT::seed)
+    const float denom = (float)(n - (unsigned long long)k);
     for (int ci = 0; ci < k; ci++) {
-        if (hassign[ci] == 0.f) {
-            int cj;
-            for (cj = 0; true; cj = (cj + 1) % k) {
-                float p = (float)(((double)hassign[cj] - 1.0) / (double)(float)(n - (unsigned long long)k));
-                float r = (float)rng.next() / 4294967296.0f;
-                if (r < p) break;
+        if (s_h[ci] != 0.f) continue;                                       // wave-uniform (one LDS word)
+        int cj0 = 0, cj = 0;
+        for (;;) {
+            if (idx >= 624) {
+                for (int c0 = 0; c0 < 624; c0 += 64) {
+                    const int i = c0 + lane;
+                    unsigned v = 0;
+                    if (i < 624) {
+                        const unsigned y = (s_mt[i] & 0x80000000U) | (s_mt[(i + 1) % 624] & 0x7fffffffU);
+                        v = s_mt[(i + 397) % 624] ^ (y >> 1);
+                        if (y & 1U) v ^= 0x9908b0dfU;
+                    }
+                    __builtin_amdgcn_wave_barrier();                       // all reads of this chunk before its writes
+                    if (i < 624) s_mt[i] = v;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                idx = 0;
             }
+            const int navail = 624 - idx < 64 ? 624 - idx : 64;
+            bool hit = false;
+            if (lane < navail) {
+                unsigned y = s_mt[idx + lane];
+                y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680U; y ^= (y << 15) & 0xefc60000U; y ^= (y >> 18);
+                const float r = (float)y / 4294967296.0f;
+                const float p = (float)(((double)s_h[(cj0 + lane) % k] - 1.0) / (double)denom);
+                hit = r < p;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) { const int t = __ffsll((long long)m) - 1; idx += t + 1; cj = (cj0 + t) % k; break; }
+            idx += navail; cj0 = (cj0 + navail) % k;
+        }
+        if (lane == 0) {
             for (int j = 0; j < 3; j++) cent[ci * 3 + j] = cent[cj * 3 + j];
             for (int j = 0; j < 3; j++) {
                 if (j % 2 == 0) {
@@ -1053,11 +1081,15 @@ __device__ void km_split_clusters(float *cent, float *hassign, int k, unsigned l
                     cent[cj * 3 + j] = (float)((double)cent[cj * 3 + j] * (1 + (1 / 1024.)));
                 }
             }
-            hassign[ci] = hassign[cj] / 2;
-            hassign[cj] -= hassign[ci];
+            const float hi = s_h[cj] / 2, hj = s_h[cj] - hi;
+            s_h[ci] = hi; s_h[cj] = hj;
+            hassign[ci] = hi; hassign[cj] = hj;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
+__global__ void k_km_mt_seed(DevMT *mt) { mt->seed(1234u); }
 
 // ---- centroid update: one wavefront replays one centroid's sequential f32 chain; the last
 // wavefront to finish handles empty clusters and writes (y, |y|^2) for the next assignment ----
@@ -1412,14 +1444,14 @@ __device__ __forceinline__ void km_update_finish(const int kidx, const int k, co
     for (int ci = lane; ci < k; ci += 64)
         if (__hip_atomic_load(&hassign[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.f) mine_empty = true;
     const bool any = __ballot(mine_empty) != 0ULL;
-    if (lane == 0) {
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next iteration's launch
-        if (any) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // the split code uses plain accesses
-            km_split_clusters(cent, hassign, k, nx, *mt);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next iteration's launch
+    if (any) {                                                            // wave-uniform
+        __shared__ unsigned s_mt[624];
+        __shared__ float s_hs[kKMeansMaxK];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // the split code uses plain accesses
+        km_split_clusters_wave(cent, hassign, k, nx, mt, s_mt, s_hs, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     for (int j = lane; j < k; j += 64) {
@@ -1741,7 +1773,12 @@ __global__ __launch_bounds__(256) void k_km_update_sums(unsigned long long *gsum
     }
     __threadfence();
     __syncthreads();
-    if (s_empty && threadIdx.x == 0) { km_split_clusters(cent, hassign, k, nx, *mt); __threadfence(); }
+    if (s_empty && threadIdx.x < 64) {
+        __shared__ unsigned s_mt[624];
+        __shared__ float s_hs[kKMeansMaxK];
+        km_split_clusters_wave(cent, hassign, k, nx, mt, s_mt, s_hs, (int)threadIdx.x);
+        __threadfence();
+    }
     __syncthreads();
     for (int j = threadIdx.x; j < k; j += 256) km_store_c4(c4, k, j, cent[3 * j], cent[3 * j + 1], cent[3 * j + 2]);
 }
@@ -1763,7 +1800,7 @@ void KMeansWork::reserve(size_t nx, int k) {
     rowtot.reserve(k);
     cent.reserve(3 * (size_t)k); hassign.reserve(k); c4.reserve(2 * (size_t)k + 2);        // + the pairwise copy (km_store_c4)
     perm.reserve(nx);
-    if (!mt.p) mt.reserve(1);
+    if (!mt.p) { mt.reserve(1); mt_seeded = false; }
     if (!ticket.p) { ticket.reserve(1); HIP_CHECK(hipMemset(ticket.p, 0, sizeof(unsigned int))); }
 }
 
@@ -1848,6 +1885,7 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
     }
+    if (!w.mt_seeded) { hipLaunchKernelGGL(k_km_mt_seed, 1, 1, 0, s, w.mt.p); w.mt_seeded = true; }   // the start of std::mt19937(1234), kept
     { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (k + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p); }
     // many samples: exact candidate pruning (the grid is rebuilt per iteration, ~0.1 ms, against ~1 ms of full scans per
     // 16 M samples); few samples (the default 512^2): the full scan is cheaper than building the grid

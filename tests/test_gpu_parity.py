@@ -118,6 +118,25 @@ def test_kmeans_bit_exact_vs_reference_faiss_golden(gpu, monkeypatch, pruned):
             ci, int(np.sum(got.view(np.uint32) != ref.view(np.uint32))))
 
 
+@pytest.mark.parametrize("ncol,k,weighted,n", [(20, 256, False, 100000), (5, 200, True, 60000), (40, 64, False, 300000)])
+def test_kmeans_many_empty_clusters_every_iteration(gpu, ob, ncol, k, weighted, n):
+    """Fewer distinct colours than centroids (a posterised image): dozens to hundreds of clusters come out empty in every iteration
+    and are re-seeded by split_clusters (Clustering.cpp:216-263) from ~k draws of mt19937(1234) each -- tens of thousands of
+    draws per iteration, i.e. many regenerations of the generator's 624-word block on the wavefront-parallel path."""
+    rng = np.random.default_rng(ncol)
+    colours = rng.random((ncol, 3))
+    pick = rng.integers(0, ncol, size=n)
+    pts = colours[pick]
+    flat = np.ascontiguousarray(pts.T).reshape(-1).copy()
+    w = ob.weights(n, 3) if weighted else None
+    cent = pts[rng.choice(n, size=k, replace=False)].copy() + 1e-3 * rng.standard_normal((k, 3))
+    want = ob.kmeans_refine(flat, w, n, cent, 4, n)
+    c = np.ascontiguousarray(cent.T).reshape(-1).copy()
+    assert gpu.patolette_amd_kmeans_refine(_d(flat), _d(w), n, _d(c), k, 4, n) == 0
+    got = c.reshape(3, k).T
+    assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
+
+
 @pytest.mark.parametrize("cs,k,weighted,g64", [("srgb_to_ictcp", 256, False, False), ("srgb_to_cieluv", 200, True, False), ("srgb_to_ictcp", 61, False, False),
                                                ("srgb_to_ictcp", 256, False, True), ("srgb_to_cieluv", 203, True, True)])
 def test_kmeans_pruned_assignment_many_samples(gpu, ob, monkeypatch, cs, k, weighted, g64):
