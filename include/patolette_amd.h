@@ -188,8 +188,9 @@ int patolette_amd_set_invariant_sums(int on);
  * once: deterministic, independent of how the samples spread over the centroids, 4.4x faster per KMeans stage at 67 M samples,
  * but NOT the reference's bits: per iteration the centroids differ by what its f32 chains round away (~1e-6 of the colour range),
  * and a sample on the border of two cells that therefore changes sides moves a centroid of m members by |x - c| / m (1e-4 at the
- * default 1024 members, 1e-6 at 65 536): most palette rows stay within BASELINE's 1e-5, a few do not, and ~0.02 % of the index
- * map follows them (tests/test_gpu_kmeans_update.py prints the measured figures).  Process-wide; applies to later calls.  Returns
+ * default 1024 members, 1e-6 at 65 536), which over the 32 iterations of the default spreads to most rows: the palette then agrees
+ * with the reference's to ~1e-4 of the colour range, not to BASELINE's 1e-5, and ~0.02 % of the index map follows
+ * (tests/test_gpu_kmeans_update.py prints the measured figures).  Process-wide; applies to later calls.  Returns
  * the previous setting.  Environment default: PAMD_KMEANS_UPDATE=1. */
 int patolette_amd_set_kmeans_update(int mode);
 
