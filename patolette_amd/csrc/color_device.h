@@ -40,13 +40,22 @@ __device__ __forceinline__ void pow_tables_to_lds() {
 #define PAMD_POW_LOG kLog
 #define PAMD_POW_EXP kExp
 #endif
+// One Horner step z * acc + c with the coefficient in scalar registers: written with __builtin_fma the compiler emits
+// v_mov_b64 (coefficient into the accumulator) + v_fmac_f64 -- two vector instructions per step, thirteen steps per pow, nine
+// pow per ICtCp pixel -- where one v_fma_f64 reading the constant from an SGPR pair does the same arithmetic.
+__device__ __forceinline__ double horner_sc(const double z, const double acc, const double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(z), "v"(acc), "s"(c));
+    return r;
+}
 __device__ __forceinline__ double pamd_pow(double x, double y) {
     using namespace powtab;
     if (!(x > 0.0)) return x == 0.0 ? (y > 0 ? 0.0 : (y == 0 ? 1.0 : INFINITY)) : NAN;
     if (isinf(x)) return y > 0 ? INFINITY : (y == 0 ? 1.0 : 0.0);
     const double m = __builtin_amdgcn_frexp_mant(x) * 2.0;                 // [1, 2)
     const int e = __builtin_amdgcn_frexp_exp(x) - 1;
-    const int i = (int)((m - 1.0) * 128.0);
+    const int i = (int)((m - 1.0) * 128.0) & 127;                           // (already in 0..127: the mask tells the compiler, whose full
+                                                                             // 32-bit multiply for the table offset runs at a quarter of the rate)
     const double r = PAMD_POW_LOG[i][0], Thi = PAMD_POW_LOG[i][1], Tlo = PAMD_POW_LOG[i][2];
     const double ph = m * r, pl = __builtin_fma(m, r, -ph);                  // m*r exactly = ph + pl
     const double zh = ph - 1.0, zl = pl;                                     // z = m*r - 1 exactly = zh + zl, |z| < 2^-8
@@ -54,16 +63,16 @@ __device__ __forceinline__ double pamd_pow(double x, double y) {
     const double s = (double)e + Thi;                                        // exact: Thi is a multiple of 2^-42
     const double Lh = s + a, bb = Lh - s, err = (s - (Lh - bb)) + (a - bb);  // two-sum
     const double z = zh;
-    const double poly = (z * z) * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, kL8, kL7), kL6), kL5), kL4), kL3), kL2);
+    const double poly = (z * z) * horner_sc(z, horner_sc(z, horner_sc(z, horner_sc(z, horner_sc(z, horner_sc(z, kL8, kL7), kL6), kL5), kL4), kL3), kL2);
     const double Ll = ((((err + ae) + zh * kInvLn2Lo) + zl * kInvLn2Hi) + Tlo) + (poly + (2 * kL2) * (zh * zl));
     const double Ph = y * Lh, Pl = __builtin_fma(y, Lh, -Ph) + y * Ll;       // y * log2(x) = Ph + Pl
     if (Ph > 1100.0) return INFINITY;
     if (Ph < -1200.0) return 0.0;
     const double kd = __builtin_rint(Ph * 64.0);
     const double f = (Ph - kd * 0.015625) + Pl;                              // the subtraction is exact
-    const long long k = (long long)kd;
-    const int j = (int)(k & 63), n = (int)(k >> 6);
-    const double q = f * __builtin_fma(f, __builtin_fma(f, __builtin_fma(f, __builtin_fma(f, __builtin_fma(f, __builtin_fma(f, kE7, kE6), kE5), kE4), kE3), kE2), kE1);
+    const int k = (int)kd;                                                   // |kd| <= 1200 * 64: one conversion (a 64-bit one costs six)
+    const int j = k & 63, n = k >> 6;
+    const double q = f * horner_sc(f, horner_sc(f, horner_sc(f, horner_sc(f, horner_sc(f, horner_sc(f, kE7, kE6), kE5), kE4), kE3), kE2), kE1);
     const double Th = PAMD_POW_EXP[j][0], Tl = PAMD_POW_EXP[j][1];
     return ldexp(Th + __builtin_fma(Th, q, Tl), n);
 }
