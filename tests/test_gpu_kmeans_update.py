@@ -38,7 +38,8 @@ def _refine(gpu, x, w, n, cent, k, niter, max_samples):
     return c.reshape(3, k).T.astype(np.float32)
 
 
-@pytest.mark.parametrize("n,k,weighted", [(262144, 256, False), (300000, 200, True), (5008, 16, False), (61 * 1147, 61, True)])
+@pytest.mark.parametrize("n,k,weighted", [(262144, 256, False), (300000, 200, True), (5008, 16, False), (61 * 1147, 61, True), (2000 * 150, 2000, False),
+                                          (4096 * 40, 4096, True)])
 def test_one_iteration_is_the_exact_mean(gpu, ob, n, k, weighted):
     """One iteration from the same start: the assignment is the reference's (the same kernels make it), so the exact-chain result
     tells which centroids moved, and the order-free centroids must be f32(sum in f64 / f32 count-or-weight) of the same members.
