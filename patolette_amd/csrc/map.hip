@@ -794,17 +794,21 @@ __device__ __forceinline__ int wave_argmin_nonneg_f64(double v) {
 template <typename OutT, int PER>
 __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, size_t plane_stride, unsigned width, unsigned height,
                                                const double *__restrict__ pal /* planar (k,3), linear Rec2020 */, int k,
-                                               OutT *__restrict__ out, DitherWeights wts) {
+                                               OutT *__restrict__ out, DitherWeights wts, double *gtab) {
     extern __shared__ double lds[];
     constexpr int kRing = 128;                                       // >= 64 + 15 pending pixels
-    double *praw = lds;                                              // [3][k] raw palette
-    double *pwt = lds + 3 * k;                                       // [3][k] palette scaled by (float)-cast weights (riemersma.c:419-425)
-    double *rpx = lds + 6 * k;                                       // [3][kRing] channels of the pending pixels
+    // the two palette tables live in LDS; a palette too large for that (K > 3200; the reference takes any K,
+    // riemersma.c:437-459) keeps them in the 6 k doubles of global memory at `gtab` -- correct, and as slow as it sounds
+    double *tab = gtab ? gtab : lds;
+    double *praw = tab;                                              // [3][k] raw palette
+    double *pwt = tab + 3 * k;                                       // [3][k] palette scaled by (float)-cast weights (riemersma.c:419-425)
+    double *rpx = gtab ? lds : lds + 6 * k;                          // [3][kRing] channels of the pending pixels
     unsigned int *rpos = reinterpret_cast<unsigned int *>(rpx + 3 * kRing);   // [kRing] their linear pixel numbers
     const int lane = threadIdx.x;
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
     for (int j = lane; j < k; j += 64)
         for (int c = 0; c < 3; c++) { const double a = pal[c * k + j]; praw[c * k + j] = a; pwt[c * k + j] = a * fw[c]; }
+    __threadfence_block();                                           // (the tables may be global memory)
     __syncthreads();
     const int per = PER > 0 ? PER : (k + 63) / 64;
     // own entries in registers when they fit (PER <= 4)
@@ -952,11 +956,11 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
 
 template <typename OutT>
 static void launch_dither_t(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k, OutT *out,
-                            const DitherWeights &wts, size_t lds, hipStream_t s) {
+                            const DitherWeights &wts, size_t lds, double *gtab, hipStream_t s) {
 #define PAMD_DITHER(PER)                                                                                                       \
     do {                                                                                                                       \
         HIP_CHECK(hipFuncSetAttribute((const void *)(k_dither<OutT, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_dither<OutT, PER>), 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts); \
+        hipLaunchKernelGGL((k_dither<OutT, PER>), 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts, gtab); \
     } while (0)
     if (k <= 64) PAMD_DITHER(1);
     else if (k <= 128) PAMD_DITHER(2);
@@ -969,7 +973,11 @@ void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_
                    void *d_out, int elem_bytes, hipStream_t s) {
     if (width * height >> 32) throw HipError("patolette_amd: the dither kernel numbers pixels with 32 bits");
     size_t lds = ((size_t)6 * k + 3 * 128) * sizeof(double) + 128 * sizeof(unsigned int);      // palette (raw + weighted) + the ring of pending pixels
-    if (lds > 150 * 1024) throw HipError("patolette_amd: palette too large for the dither kernel (K <= 3200)");
+    double *gtab = nullptr;
+    if (lds > 150 * 1024) {                                      // K > 3200: the tables in global memory (freed behind the kernel)
+        HIP_CHECK(hipMallocAsync((void **)&gtab, (size_t)6 * k * sizeof(double), s));
+        lds = (size_t)3 * 128 * sizeof(double) + 128 * sizeof(unsigned int);
+    }
     DitherWeights wts;
     {
         const double m = std::exp(std::log(16.0) / (16.0 - 1));
@@ -977,11 +985,12 @@ void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_
         for (int i = 0; i < 16; i++) { wts.w[i] = v / 16.0; v *= m; }
     }
     KTIME("k_dither", s, (24.0 + elem_bytes) * width * height);
-    if (elem_bytes == 1) launch_dither_t<unsigned char>(d_img, plane_stride, width, height, d_pal, k, (unsigned char *)d_out, wts, lds, s);
-    else if (elem_bytes == 4) launch_dither_t<unsigned int>(d_img, plane_stride, width, height, d_pal, k, (unsigned int *)d_out, wts, lds, s);
-    else if (elem_bytes == 8) launch_dither_t<unsigned long long>(d_img, plane_stride, width, height, d_pal, k, (unsigned long long *)d_out, wts, lds, s);
-    else throw HipError("patolette_amd: map element size must be 1, 4 or 8");
+    if (elem_bytes == 1) launch_dither_t<unsigned char>(d_img, plane_stride, width, height, d_pal, k, (unsigned char *)d_out, wts, lds, gtab, s);
+    else if (elem_bytes == 4) launch_dither_t<unsigned int>(d_img, plane_stride, width, height, d_pal, k, (unsigned int *)d_out, wts, lds, gtab, s);
+    else if (elem_bytes == 8) launch_dither_t<unsigned long long>(d_img, plane_stride, width, height, d_pal, k, (unsigned long long *)d_out, wts, lds, gtab, s);
+    else { if (gtab) (void)hipFreeAsync(gtab, s); throw HipError("patolette_amd: map element size must be 1, 4 or 8"); }
     HIP_CHECK(hipGetLastError());
+    if (gtab) HIP_CHECK(hipFreeAsync(gtab, s));
 }
 
 }  // namespace pamd

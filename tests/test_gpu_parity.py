@@ -313,6 +313,21 @@ def test_dither_bit_exact(gpu, ob, wh):
         assert np.array_equal(got, want), "%dx%d k=%d: %d mismatches" % (w, h, k, int(np.sum(got != want)))
 
 
+@pytest.mark.parametrize("k", [700, 3300, 5000])
+def test_dither_large_palettes(gpu, ob, k):
+    """Palettes beyond 256 entries (the general per-lane loop over LDS tables) and beyond 3200, where the two tables no longer
+    fit LDS and sit in global memory (the reference takes any palette size, riemersma.c:437-459)."""
+    w, h = 96, 50
+    n = w * h
+    flat = ob.convert("srgb_to_rec2020", ob.image(n, 17))
+    pal = ob.convert("srgb_to_rec2020", ob.image(k, 19)).reshape(3, k).T.copy()
+    want = ob.dither(flat, w, h, pal)
+    got = np.zeros(n, dtype=np.uintp)
+    p = np.ascontiguousarray(pal.T).reshape(-1)
+    assert gpu.patolette_amd_dither(_d(flat), w, h, _d(p), k, got.ctypes.data_as(zp)) == 0
+    assert np.array_equal(got, want), "k=%d: %d mismatches" % (k, int(np.sum(got != want)))
+
+
 def test_dither_1x1_leaves_map_untouched(gpu, ob):
     flat = ob.image(1, 3)
     pal = np.array([[0.1, 0.2, 0.3], [0.5, 0.5, 0.5]])
