@@ -286,6 +286,54 @@ def host_to_host(L, native, cfg, reps=3):
             "ms_upload": round(st["ms_upload"], 3), "ms_download": round(st["ms_download"], 3)}
 
 
+def parity_record(L, native, cfg, d_img, d_wt, pal_timed, res_all, res_one, ob):
+    """The metric's second half ("palette dE vs ref"): rank 0's image 0 (seed 0) of the timed region against the CPU oracle's
+    result for the SAME full-size image -- the one the cpu_baseline leg has just computed.  The palette compared is the one a
+    timed step returned; the index map (left in HBM during the timed region) is taken from one more, untimed, call on the same
+    image and entry point, whose palette must be the timed step's bit for bit.  The oracle is the checker here, nothing else."""
+    import numpy as np
+    width, height, K, cs, niter, max_samples, dither, weighted, _ = cfg
+    n = width * height
+    ec, pal_o, map_o = res_all
+    if ec != 0 or map_o is None:
+        return {"note": "oracle exit code %d" % ec}
+    dmap = L.patolette_amd_malloc(n)
+    if not dmap:
+        return None
+    try:
+        opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+        pal = np.zeros((K, 3), dtype=np.float64, order="F")
+        code = C.c_int(0)
+        L.patolette_amd_device(width, height, d_img, d_wt, K, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+        L.patolette_amd_synchronize()
+        if code.value != 0:
+            return {"note": "HIP path exit code %d" % code.value}
+        m8 = np.empty(n, dtype=np.uint8)
+        assert L.patolette_amd_memcpy_d2h(m8.ctypes.data_as(C.c_void_p), dmap, n) == 0
+    finally:
+        L.patolette_amd_free(dmap)
+    pal_o = np.asarray(pal_o, dtype=np.float64)
+    rows_o = int(np.sum(pal_o[:, 0] != -1.0))
+    same_tail = bool(np.array_equal(pal == -1.0, pal_o == -1.0))
+    used = pal_o[:, 0] != -1.0
+    rel = float(np.max(np.abs(pal[used] - pal_o[used])) / max(1e-300, float(np.max(np.abs(pal_o[used]))))) if same_tail and rows_o else None
+    # dE_ITP between the two palettes: 720 * sqrt(dI^2 + dT^2 + dP^2) with T = Ct / 2 -- the reference's ICtCp already halves Ct
+    # (lib/src/color/ICtCp.c:78); the conversion used for this report is the oracle's
+    de = None
+    if same_tail and rows_o:
+        a = ob.convert("srgb_to_ictcp", ob.planar(np.clip(pal[used], 0.0, 1.0))).reshape(3, -1)
+        b = ob.convert("srgb_to_ictcp", ob.planar(np.clip(pal_o[used], 0.0, 1.0))).reshape(3, -1)
+        de = float(np.max(720.0 * np.sqrt(np.sum((a - b) ** 2, axis=0))))
+    mism = int(np.count_nonzero(m8 != np.asarray(map_o).astype(np.uint8))) if K <= 256 else None
+    return {"image": "rank 0, image 0 (seed 0) of the timed region, %dx%d, full size" % (width, height),
+            "against": "oracle/ (CPU restatement of the reference path) on this host, the cpu_baseline run",
+            "pixels": n, "palette_rows": rows_o, "unused_rows_match": same_tail,
+            "palette_max_rel": rel, "palette_max_deltaE_ITP": de, "map_mismatches": mism,
+            "palette_of_timed_step_identical": (bool(np.array_equal(pal_timed, pal)) if pal_timed is not None else None),
+            "oracle_all_core_equals_single_thread": bool(np.array_equal(res_all[1], res_one[1]) and np.array_equal(res_all[2], res_one[2])),
+            "tolerance": "north_star: index map bit-exact, palette 1e-5 relative"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +344,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras of the default run: north_star_kernels, host_to_host")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed (RCCL) path even with one rank")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST MODE, never a measurement of scaling: the N ranks share the GPUs the box has (rank r on device r mod count) and the "
+                         "final gather runs on the gloo backend through host staging (RCCL refuses two ranks on one device); everything else -- "
+                         "sharding, per-step asynchronous gather, palette gather, barrier + max-over-ranks timing -- is the N > 1 code of the RCCL path")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="after the timed region rank 0 quantises every rank's images itself, one call per image, and compares the gathered "
+                         "maps and palettes with them (reported as gather_check)")
     ap.add_argument("--streams", type=int, default=1, help="images quantised concurrently per GPU and step in the timed region")
     ap.add_argument("--extra-streams", type=int, default=3,
                     help="after the timed region also measure throughput with this many concurrent images per GPU; reported "
@@ -312,7 +367,7 @@ def main():
         import subprocess
         from patolette_amd import _native
         have = _native.lib().patolette_amd_device_count()
-        if have < args.gpus:
+        if have < args.gpus and not (args.oversubscribe and have >= 1):
             raise SystemExit("bench.py: --gpus %d but %d HIP device(s) visible" % (args.gpus, have))
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
@@ -336,8 +391,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
+        if args.oversubscribe:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if args.oversubscribe else "nccl", rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:          # n_gpus in the line = the ranks RCCL actually saw
             raise SystemExit("bench.py: RCCL group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
         world = dist.get_world_size()
@@ -385,6 +442,9 @@ def main():
         warm_t = torch.empty((max(S, S2, 1), n), dtype=torch.uint8, device="cuda")
         map_ptr = lambda i, j: (maps_t[(i - args.warmup) * S + j].data_ptr() if i >= args.warmup else warm_t[j].data_ptr())
         map_ptr2 = lambda i, j: warm_t[j].data_ptr()
+        # what a collective is handed: the device tensor itself on RCCL; a host copy on gloo (--oversubscribe)
+        wire = (lambda t: t.cpu()) if args.oversubscribe else (lambda t: t)
+        wire_dev = "cpu" if args.oversubscribe else "cuda"
     else:
         d_maps = [L.patolette_amd_malloc(n) for _ in range(max(S, S2, 1))]      # K <= 256 -> u8 index map left in HBM
         map_ptr = lambda i, j: d_maps[j]
@@ -407,10 +467,10 @@ def main():
         run.step(i)
         if dist is not None:
             # a warm-up step is a whole step: its maps are gathered too (the first gather sets up RCCL's channels and buffers)
-            part = warm_t[:S]
+            part = wire(warm_t[:S])
             gl = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
             dist.gather(part, gl, dst=0)
-            pw_t = torch.from_numpy(pals[i * S:(i + 1) * S]).to("cuda")
+            pw_t = torch.from_numpy(pals[i * S:(i + 1) * S]).to(wire_dev)
             gp = [torch.empty_like(pw_t) for _ in range(world)] if rank == 0 else None
             dist.gather(pw_t, gp, dst=0)
             torch.cuda.synchronize()
@@ -431,13 +491,13 @@ def main():
         if dist is not None:
             # The only collective of the job: the results go to rank 0 over RCCL/xGMI.  The u8 maps of step i (complete: the
             # library call has returned) are gathered asynchronously on RCCL's own stream while step i+1 computes.
-            part = maps_t[i * S:(i + 1) * S]
+            part = wire(maps_t[i * S:(i + 1) * S])
             gl = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
             gathered.append(gl)
             works.append(dist.gather(part, gl, dst=0, async_op=True))
     L.patolette_amd_synchronize()
     if dist is not None:
-        pal_t = torch.from_numpy(pals[args.warmup * S:]).to("cuda")
+        pal_t = torch.from_numpy(pals[args.warmup * S:]).to(wire_dev)
         gl_p = [torch.empty_like(pal_t) for _ in range(world)] if rank == 0 else None
         works.append(dist.gather(pal_t, gl_p, dst=0, async_op=True))
         for w in works:
@@ -445,6 +505,12 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     stats = _native.last_stats()
+    # the palette a TIMED step produced for rank 0's image 0 (seed 0): what `parity` below holds to the oracle
+    pal_timed = None
+    for i in range(args.steps):
+        if ((args.warmup + i) * S) % len(d_imgs) == 0:
+            pal_timed = pals[(args.warmup + i) * S].copy()
+            break
     prof = _native.profile_results() if not args.no_profile else {}
     _native.profile(False)
     prof_full = prof
@@ -456,7 +522,7 @@ def main():
         _native.profile(False)
     run.close()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=wire_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -474,13 +540,54 @@ def main():
         e2 = time.perf_counter() - t1
         run2.close()
         if dist is not None:
-            t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+            t = torch.tensor([e2], dtype=torch.float64, device=wire_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e2 = float(t.item())
         conc = {"images_in_flight_per_gpu": S2, "value": round(float(n) * k2 * S2 * world / e2 / 1e6, 3), "unit": "Mpx/s",
                 "steps": k2, "note": "one host thread + HIP stream per image; host-side split-loop work of one image overlaps kernels of another"}
     if dist is not None:
         dist.barrier()
+
+    gather_check = None
+    if args.check_gather and dist is not None and rank == 0:
+        # rank 0 makes every rank's images itself (the generator is a pure function of the seed), quantises them one call per
+        # image, and holds what the collective delivered to that: maps bit for bit, palettes bit for bit
+        tmp = L.patolette_amd_malloc(3 * n * 8)
+        tmpw = L.patolette_amd_malloc(n * 8) if weighted is True else None
+        tmpm = L.patolette_amd_malloc(n)
+        opts_c = _native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+        mism = compared = 0
+        pal_ok = True
+        try:
+            ref_cache = {}
+            for r in range(world):
+                for i in range(args.steps):
+                    for j in range(S):
+                        src = ((args.warmup + i) * S + j) % pool
+                        if (r, src) not in ref_cache:
+                            assert L.patolette_amd_fill_image(tmp, n, 100 * r + src) == 0
+                            if tmpw:
+                                assert L.patolette_amd_fill_weights(tmpw, n, 100 * r + src) == 0
+                            pal_c = np.zeros((K, 3), dtype=np.float64, order="F")
+                            code_c = C.c_int(0)
+                            L.patolette_amd_device(width, height, tmp, tmpw, K, C.byref(opts_c), pal_c.ctypes.data_as(_native.dp), tmpm, 1, C.byref(code_c))
+                            L.patolette_amd_synchronize()
+                            assert code_c.value == 0, _native.last_error()
+                            m_c = np.empty(n, dtype=np.uint8)
+                            assert L.patolette_amd_memcpy_d2h(m_c.ctypes.data_as(C.c_void_p), tmpm, n) == 0
+                            ref_cache[(r, src)] = (pal_c.copy(), m_c)
+                        pal_c, m_c = ref_cache[(r, src)]
+                        got_m = gathered[i][r][j].cpu().numpy()
+                        got_p = gl_p[r][i * S + j].cpu().numpy()
+                        mism += int(np.count_nonzero(got_m != m_c))
+                        pal_ok = pal_ok and bool(np.array_equal(got_p, pal_c))
+                        compared += 1
+        finally:
+            for p_ in (tmp, tmpw, tmpm):
+                if p_:
+                    L.patolette_amd_free(p_)
+        gather_check = {"maps_compared": compared, "ranks": world, "map_mismatches": mism, "palettes_identical": pal_ok,
+                        "against": "one patolette_amd_device call per image on rank 0"}
 
     if rank != 0:
         if dist is not None:
@@ -527,6 +634,7 @@ def main():
     # all-core = the loops the reference's dependencies thread (faiss search / compute_centroids, FLANN's NN search) on every
     # core of the box, the rest single-threaded as in the reference; single_thread = everything on one core.
     cpu = None
+    parity = None
     if not args.no_cpu_baseline and world == 1:
         from oracle import binding as ob
         ncores = os.cpu_count() or 1
@@ -547,12 +655,17 @@ def main():
             if weighted == "saliency":               # the reference derives these on the CPU inside quantize(): part of the job
                 from oracle import saliency
                 w_ = saliency.get_weights(np.ascontiguousarray(flat.reshape(3, sn).T).reshape(sh, sw, 3), 512.0)
-            ec, _, _ = ob.patolette(sw, sh, flat, w_, K, dither=dither, color_space=cs, kmeans_niter=niter, kmeans_max_samples=kms)
+            ec, pal_, map_ = ob.patolette(sw, sh, flat, w_, K, dither=dither, color_space=cs, kmeans_niter=niter, kmeans_max_samples=kms)
             dt_ = time.perf_counter() - t1
             ob.set_threads(1)
-            return dt_, {k: round(v, 2) for k, v in ob.last_timings().items()}
-        dt_all, st_all = cpu_run(ncores)
-        dt_one, st_one = cpu_run(1)
+            return dt_, {k: round(v, 2) for k, v in ob.last_timings().items()}, (ec, pal_, map_)
+        dt_all, st_all, res_all = cpu_run(ncores)
+        dt_one, st_one, res_one = cpu_run(1)
+        if sn == n and weighted != "saliency":
+            parity = parity_record(L, _native, cfg, d_imgs[0], d_wts[0] if weighted is True else None, pal_timed, res_all, res_one, ob)
+        else:
+            parity = {"note": "the CPU sample is smaller than the workload (or derives its own weights): no full-size comparison in this run; "
+                              "see tests/test_gpu_parity.py"}
         scale = "the full %dx%d workload" % (sw, sh) if sn == n else "%dx%d of the same workload (the %dx%d image would take %.0fx as long)" % (sw, sh, width, height, n / sn)
         cpu = {"value": round(sn / dt_all / 1e6, 4), "unit": "Mpx/s", "cores": ncores, "kind": "port",
                "sample": "oracle (plain-C restatement of the reference path; KMeans assign/update and the NN map on %d threads as faiss / FLANN "
@@ -560,7 +673,8 @@ def main():
                "single_thread": {"value": round(sn / dt_one / 1e6, 4), "cores": 1, "seconds": round(dt_one, 1), "stages": st_one}}
 
     out = {
-        "metric": "Mpixels/sec quantized (256-color ICtCp + KMeans) at 1 GPU" if args.config.startswith("c3") else "Mpixels/sec quantized",
+        "metric": ("Mpixels/sec quantized (256-color ICtCp + KMeans) at %s; palette \u0394E vs ref" % ("1 GPU" if world == 1 else "%d GPUs" % world))
+                  if args.config.startswith("c3") else "Mpixels/sec quantized; palette \u0394E vs ref",
         "value": round(value, 3), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -575,8 +689,11 @@ def main():
                                                      ("dominant kernel only (%s), every %d-th launch (two event records cost ~12 us per launch); "
                                                       "per-kernel table from one extra untimed step" % (dom_name, EVENT_SAMPLE)
                                                       if dom_name else "all kernels")),
-                   "final_gather": ("RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region" if dist is not None else "none (1 GPU)")},
-        "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "content": content, "throughput_concurrent": conc,
+                   "final_gather": ("none (1 GPU)" if dist is None else
+                                    "TEST MODE --oversubscribe: %d ranks on %d device(s), gloo gather through host copies -- the N > 1 code path, not a scaling figure" % (world, L.patolette_amd_device_count())
+                                    if args.oversubscribe else
+                                    "RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region")},
+        "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "content": content, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -47,3 +47,24 @@ def test_gpus_n_starts_n_ranks_or_fails_loudly(gpu):
         assert line["scaling"] == "weak"
     else:
         assert r.returncode != 0 and line is None, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams", [1, 2])
+def test_n_greater_one_code_path_runs_on_ranks_sharing_a_device(gpu, streams):
+    """bench.py's N > 1 branch (batch shard + final gather) EXECUTED on a one-GPU box: two ranks share the device
+    (`--oversubscribe`: gloo + host staging for the collective, because RCCL refuses two ranks on one GPU); sharding by rank, the
+    per-step asynchronous gather of the u8 maps, the palette gather, the index arithmetic of `map_ptr` and the max-over-ranks
+    timing are the lines the RCCL run executes.  Rank 0 then quantises every rank's images itself, one call per image: what the
+    gather delivered must be those maps and palettes bit for bit."""
+    r, line = _bench("--gpus", "2", "--oversubscribe", "--check-gather", "--steps", "4", "--warmup", "2", "--config", "c2",
+                     "--streams", str(streams), timeout=600)
+    assert r.returncode == 0 and line is not None, r.stdout[-2000:] + r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert "TEST MODE" in line["config"]["final_gather"]
+    gc = line["gather_check"]
+    assert gc["ranks"] == 2 and gc["maps_compared"] == 2 * 4 * streams
+    assert gc["map_mismatches"] == 0 and gc["palettes_identical"]
+    # whole-job value = the pixels of BOTH ranks over the max-over-ranks time
+    px = 1920 * 1080 * 4 * 2 * streams
+    assert abs(line["value"] - px / (line["ms_per_step"] * 4e-3) / 1e6) <= 2e-3 * line["value"]

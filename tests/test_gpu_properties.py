@@ -96,6 +96,34 @@ def test_full_size_ictcp(gpu, native, ob, cfg):
         d.free()
 
 
+@pytest.mark.parametrize("cfg", [("c2", 1920, 1080, 0), ("c3", 4096, 4096, 32)], ids=lambda c: c[0])
+def test_full_size_matches_oracle(gpu, native, ob, cfg):
+    """BASELINE configs[1] and configs[2] AT THEIR OWN SIZE against the CPU oracle (seed 0: the image bench.py's `parity`
+    record uses): index map bit for bit, palette within north_star's 1e-5 relative -- 1e-9 asserted (patolette.c:157-343)."""
+    import os
+    name, w, h, niter = cfg
+    n, K = w * h, 256
+    d = Dev(gpu, n, 0)
+    try:
+        pal, pmap, st = run(native, d, w, h, K, kmeans_niter=niter)
+        img = d.host_image()
+    finally:
+        d.free()
+    assert np.array_equal(img, ob.image(n, 0))              # the device generator and the oracle's make the same image
+    ob.set_threads(os.cpu_count() or 1)                     # faiss / FLANN loops on every core; results independent of it
+    try:
+        ec, pal_o, map_o = ob.patolette(w, h, img, None, K, dither=False, color_space=2, kmeans_niter=niter, kmeans_max_samples=512 ** 2)
+    finally:
+        ob.set_threads(1)
+    assert ec == 0
+    assert np.array_equal(pal == -1.0, pal_o == -1.0)
+    rel = np.max(np.abs(pal - pal_o)) / np.max(np.abs(pal_o))
+    mism = int(np.count_nonzero(pmap != map_o.astype(np.uint8)))
+    print("%s: palette max rel %.3g, map mismatches %d / %d" % (name, rel, mism, n))
+    assert rel <= 1e-9                                      # tolerance: north_star asks 1e-5
+    assert mism == 0                                        # bit-exact index map
+
+
 def test_kmeans_lowers_distortion_at_full_size(gpu, native, ob):
     w = h = 2048
     n, K = w * h, 64
