@@ -194,6 +194,12 @@ int patolette_amd_set_invariant_sums(int on);
  * the previous setting.  Environment default: PAMD_KMEANS_UPDATE=1. */
 int patolette_amd_set_kmeans_update(int mode);
 
+/* The KMeans subsample list (faiss rand_perm(N, seed 1234), Clustering.cpp:311-319: a pure function of the pixel count) is made
+ * on a helper thread that starts at call entry and is joined when the KMeans stage begins.  1 (default): the list stays on the
+ * device between calls on images of one size; 0: every call makes it again -- the cost of a FIRST call of a size, call after
+ * call (bench.py reports both).  Process-wide.  Returns the previous setting. */
+int patolette_amd_set_subsample_cache(int on);
+
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
 /* patolette__EIGEN_solve (math/eigen.c:83-140: LAPACK dsyev 'V','L', n = 3) as the split loop's host side solves it:
  * a column-major 3x3 (lower triangle read) -> w ascending, z = eigenvectors as columns; returns LAPACK's info (0 = ok).

@@ -6,7 +6,7 @@
 
 namespace pamd {
 
-constexpr int kKMeansMaxK = 4096;      // per-wavefront LDS counters in the stable sort: 4 waves x K x 4 B
+constexpr int kKMeansMaxK = 4096;      // up to here the stable sort keeps per-wavefront counters in LDS (4 waves x K x 4 B); beyond: counters in memory
 
 struct KmSamples { float *x, *y, *z, *w; };
 
@@ -15,6 +15,8 @@ struct KMeansWork {
     DevBuf<int> assign;
     DevBuf<float4> sorted;             // samples grouped by centroid, sample order kept
     DevBuf<unsigned int> table, rowtot, ticket;
+    DevBuf<unsigned int> rowbase;      // k > kKMeansMaxK: exclusive prefix of rowtot
+    DevBuf<float> hs;                  // k > kKMeansMaxK: split_clusters' working copy of the cluster sizes
     DevBuf<float> cent, hassign;       // interleaved xyz centroids (faiss layout)
     DevBuf<float4> c4;                 // (y0,y1,y2,|y|^2)
     DevBuf<int> perm;                  // subsample indices

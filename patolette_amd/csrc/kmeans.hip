@@ -130,6 +130,9 @@ __device__ __forceinline__ unsigned long long match_mask(int key, int nbits, uns
 
 // ---- assignment + first half of the stable counting sort: one wavefront owns a chunk of consecutive
 // samples, assigns them 64 at a time and counts per centroid in wave-private LDS ----
+// BIG (k > kKMeansMaxK, no limit): the wave-private counters do not fit LDS; the wavefront counts straight into its column of
+// the (zeroed) table with L2 atomics -- the column is its own, the atomics only keep the vector L1 out of the way.
+template <bool BIG>
 __global__ __launch_bounds__(256) void k_km_assign_count(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, int nbits,
                                                          int chunk_len, int nchunks, int *__restrict__ assign,
                                                          unsigned int *table /* [k][nchunks] */) {
@@ -138,8 +141,10 @@ __global__ __launch_bounds__(256) void k_km_assign_count(KmSamples s, size_t nx,
     // the centroid table (k x 16 bytes, read-only here) is read through the scalar cache: every lane needs the same
     // entry at the same time, so the operands arrive in SGPRs and no LDS traffic sits between the FMAs
     unsigned int *cnt = lds_u + 4 * (size_t)k + (size_t)wid * k;
-    for (int j = lane; j < k; j += 64) cnt[j] = 0u;
-    __syncthreads();
+    if constexpr (!BIG) {
+        for (int j = lane; j < k; j += 64) cnt[j] = 0u;
+        __syncthreads();
+    }
     const int chunk = blockIdx.x * 4 + wid;
     if (chunk >= nchunks) return;
     const size_t lo = (size_t)chunk * chunk_len;
@@ -151,9 +156,63 @@ __global__ __launch_bounds__(256) void k_km_assign_count(KmSamples s, size_t nx,
         if (v) { a = km_assign_one(s.x[i], s.y[i], s.z[i], (scalar_c4_t)(unsigned long long)c4, k); assign[i] = a; }
         const unsigned long long valid = __ballot(v);
         const unsigned long long m = match_mask(a, nbits, valid);
-        if (v && (m & ((1ULL << lane) - 1ULL)) == 0ULL) cnt[a] += (unsigned)__popcll(m);   // group leader; distinct addresses
+        if (v && (m & ((1ULL << lane) - 1ULL)) == 0ULL) {                                    // group leader; distinct addresses
+            if constexpr (BIG) (void)atomicAdd(&table[(size_t)a * nchunks + chunk], (unsigned)__popcll(m));
+            else cnt[a] += (unsigned)__popcll(m);
+        }
     }
-    for (int j = lane; j < k; j += 64) table[(size_t)j * nchunks + chunk] = cnt[j];
+    if constexpr (!BIG) for (int j = lane; j < k; j += 64) table[(size_t)j * nchunks + chunk] = cnt[j];
+}
+
+// BIG: exclusive prefix of the row totals (where every centroid's segment of `sorted` starts), one block
+__global__ __launch_bounds__(256) void k_km_rowbase(const unsigned int *__restrict__ rowtot, int k, unsigned int *rowbase) {
+    __shared__ unsigned int wsum[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int per = (k + 255) / 256;
+    const int j0 = threadIdx.x * per, j1 = (j0 + per < k) ? j0 + per : k;
+    unsigned sum = 0;
+    for (int j = j0; j < j1; j++) sum += rowtot[j];
+    unsigned inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    unsigned pre = 0;
+    for (int w = 0; w < wid; w++) pre += wsum[w];
+    unsigned run = pre + inc - sum;
+    for (int j = j0; j < j1; j++) { rowbase[j] = run; run += rowtot[j]; }
+}
+
+// BIG: second half of the stable counting sort with the cursors in memory: after k_km_rowscan table[j][chunk] = members of
+// centroid j in earlier chunks; the wavefront that owns the chunk advances that entry as it places its samples (one L2 atomic
+// per group of equal assignments and trip of 64 samples, the old value handed to the group's lanes)
+template <bool W>
+__global__ __launch_bounds__(256) void k_km_scatter_big(KmSamples s, const int *__restrict__ assign, size_t nx, int nbits, int chunk_len,
+                                                        int nchunks, unsigned int *table, const unsigned int *__restrict__ rowbase,
+                                                        float4 *sorted) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int chunk = blockIdx.x * 4 + wid;
+    if (chunk >= nchunks) return;
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    for (size_t base = lo; base < hi; base += 64) {
+        const size_t i = base + lane;
+        const bool v = i < hi;
+        const int a = v ? assign[i] : 0;
+        const unsigned long long valid = __ballot(v);
+        const unsigned long long m = match_mask(a, nbits, valid);
+        const unsigned r = (unsigned)__popcll(m & lt);
+        unsigned cur = 0;
+        if (v && r == 0) cur = atomicAdd(&table[(size_t)a * nchunks + chunk], (unsigned)__popcll(m));
+        const int leader = (v && m) ? __ffsll((long long)m) - 1 : lane;
+        cur = (unsigned)__shfl((int)cur, leader, 64);
+        if (v) {
+            float w = 1.0f;
+            if constexpr (W) w = s.w[i];
+            sorted[(size_t)rowbase[a] + cur + r] = make_float4(s.x[i], s.y[i], s.z[i], w);
+        }
+    }
 }
 
 // per centroid: exclusive scan of its row of chunk counts (in place) + row total
@@ -1029,16 +1088,30 @@ struct DevMT {
 // start (seed 1234, `seeded`, built once per workspace) is copied in, a block of 624 outputs is re-generated 64 words at a time
 // in ascending order, every lane reading its three inputs before any lane writes -- word i sees the old i + 1 and i + 397 (or
 // the new i - 227), as in the sequential loop.  s_mt: 624 words, s_h: k floats (the sizes, updated as clusters are split).
+// HMEM: s_h is a scratch array in device memory (k beyond what LDS holds): read and written past the vector L1 (agent scope).
+template <bool HMEM>
+struct KmSizes {
+    float *p;
+    __device__ __forceinline__ float get(const int j) const {
+        if constexpr (HMEM) return __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return p[j];
+    }
+    __device__ __forceinline__ void put(const int j, const float v) const {
+        if constexpr (HMEM) __hip_atomic_store(p + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else p[j] = v;
+    }
+};
+template <bool HMEM = false>
 __device__ __forceinline__ void km_split_clusters_wave(float *cent, float *hassign, const int k, const unsigned long long n, const DevMT *seeded,
-                                                       unsigned *s_mt, float *s_h, const int lane) {
+                                                       unsigned *s_mt, float *s_h_, const int lane) {
+    const KmSizes<HMEM> s_h{s_h_};
     for (int i = lane; i < 624; i += 64) s_mt[i] = seeded->mt[i];
-    for (int j = lane; j < k; j += 64) s_h[j] = hassign[j];
+    for (int j = lane; j < k; j += 64) s_h.put(j, hassign[j]);
+    if constexpr (HMEM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     int idx = 624;                                                          // nothing generated yet (DevMT::seed)
     const float denom = (float)(n - (unsigned long long)k);
     for (int ci = 0; ci < k; ci++) {
-        if (s_h[ci] != 0.f) continue;                                       // wave-uniform (one LDS word)
+        if (s_h.get(ci) != 0.f) continue;                                   // wave-uniform (one LDS word)
         int cj0 = 0, cj = 0;
         for (;;) {
             if (idx >= 624) {
@@ -1063,7 +1136,7 @@ __device__ __forceinline__ void km_split_clusters_wave(float *cent, float *hassi
                 unsigned y = s_mt[idx + lane];
                 y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680U; y ^= (y << 15) & 0xefc60000U; y ^= (y >> 18);
                 const float r = (float)y / 4294967296.0f;
-                const float p = (float)(((double)s_h[(cj0 + lane) % k] - 1.0) / (double)denom);
+                const float p = (float)(((double)s_h.get((cj0 + lane) % k) - 1.0) / (double)denom);
                 hit = r < p;
             }
             const unsigned long long m = __ballot(hit);
@@ -1081,9 +1154,11 @@ __device__ __forceinline__ void km_split_clusters_wave(float *cent, float *hassi
                     cent[cj * 3 + j] = (float)((double)cent[cj * 3 + j] * (1 + (1 / 1024.)));
                 }
             }
-            const float hi = s_h[cj] / 2, hj = s_h[cj] - hi;
-            s_h[ci] = hi; s_h[cj] = hj;
+            const float hcj = s_h.get(cj);
+            const float hi = hcj / 2, hj = hcj - hi;
+            s_h.put(ci, hi); s_h.put(cj, hj);
             hassign[ci] = hi; hassign[cj] = hj;
+            if constexpr (HMEM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1416,9 +1491,12 @@ __device__ __forceinline__ float km_coop_lds(const float *mine, const float *wts
 
 // Tail of a centroid's update block: res[0..3] = the four chain results; scales the centroid, publishes it, and the LAST block
 // to arrive handles empty clusters and writes (y, |y|^2) for the next assignment.  All 256 threads of the block call it.
-template <bool W>
+// HS: capacity of the LDS copy of the cluster sizes split_clusters works on (256 for the list path, kKMeansMaxK for the sorted
+// path); 0 = any k, the copy lives in device memory (hs_mem, k floats)
+template <bool W, int HS>
 __device__ __forceinline__ void km_update_finish(const int kidx, const int k, const unsigned long long nx, const size_t cnt, const float *res,
-                                                 int *s_last, float *cent, float *hassign, float4 *c4, unsigned int *ticket, DevMT *mt) {
+                                                 int *s_last, float *cent, float *hassign, float4 *c4, unsigned int *ticket, DevMT *mt,
+                                                 float *hs_mem = nullptr) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float c0 = res[0], c1 = res[1], c2 = res[2], h = res[3];
     if constexpr (!W) {
@@ -1447,9 +1525,11 @@ __device__ __forceinline__ void km_update_finish(const int kidx, const int k, co
     if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next iteration's launch
     if (any) {                                                            // wave-uniform
         __shared__ unsigned s_mt[624];
-        __shared__ float s_hs[kKMeansMaxK];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // the split code uses plain accesses
-        km_split_clusters_wave(cent, hassign, k, nx, mt, s_mt, s_hs, lane);
+        if constexpr (HS > 0) {
+            __shared__ float s_hs[HS];
+            km_split_clusters_wave<false>(cent, hassign, k, nx, mt, s_mt, s_hs, lane);
+        } else km_split_clusters_wave<true>(cent, hassign, k, nx, mt, s_mt, hs_mem, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1462,10 +1542,10 @@ __device__ __forceinline__ void km_update_finish(const int kidx, const int k, co
     }
 }
 
-template <bool W>
+template <bool W, bool BIGK = false>
 __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ sorted, const unsigned int *__restrict__ rowtot, int k,
                                                   unsigned long long nx, float *cent, float *hassign, float4 *c4,
-                                                  unsigned int *ticket, DevMT *mt, unsigned long long long_min) {
+                                                  unsigned int *ticket, DevMT *mt, unsigned long long long_min, float *hs_mem) {
     __shared__ float4 stage[4][2][64];
     extern __shared__ __attribute__((aligned(16))) float coop[];          // km_chain_coop: [4 components][4096 samples] when launched with it
     __shared__ float res[4];
@@ -1488,7 +1568,7 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
     }
     if (lane == 0) res[wid] = acc;
     __syncthreads();
-    km_update_finish<W>(kidx, k, nx, hi - lo, res, &s_last, cent, hassign, c4, ticket, mt);
+    km_update_finish<W, BIGK ? 0 : kKMeansMaxK>(kidx, k, nx, hi - lo, res, &s_last, cent, hassign, c4, ticket, mt, hs_mem);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1700,7 +1780,7 @@ __global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restric
     replay();
     if (lane == 0) res[wid] = acc;
     __syncthreads();
-    km_update_finish<W>(kidx, k, nx, total, res, &s_last, cent, hassign, c4, ticket, mt);
+    km_update_finish<W, 256>(kidx, k, nx, total, res, &s_last, cent, hassign, c4, ticket, mt);            // this path runs for k <= 256 only
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1798,6 +1878,7 @@ void KMeansWork::reserve(size_t nx, int k) {
     table.reserve(std::max((size_t)k * (size_t)(nchunks > 0 ? nchunks : 1),
                            (ceil_div(nx, (size_t)1024) * 257 + 1) / 2 + 1));        // also the u16 group offsets of k_km_assign_sort
     rowtot.reserve(k);
+    if (k > kKMeansMaxK) { rowbase.reserve(k); hs.reserve(k); }
     cent.reserve(3 * (size_t)k); hassign.reserve(k); c4.reserve(2 * (size_t)k + 2);        // + the pairwise copy (km_store_c4)
     perm.reserve(nx);
     if (!mt.p) { mt.reserve(1); mt_seeded = false; }
@@ -1831,6 +1912,7 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     KmSamples ks{w.sx.p, w.sy.p, w.sz.p, w.sw.p};
     KmFix fix{};
     int ablocks = 1;
+    if (sums && k > kKMeansMaxK) sums = nullptr;     // the order-free option keeps its sums in LDS (32 bytes per centroid): beyond that the exact update
     if (sums) {
         int ex = 0, ew = 0, P = 1;
         (void)frexp(std::max(sums->bound_x, 1e-300) * (weighted ? std::max(sums->bound_w, 1e-300) : 1.0), &ex);   // |w x| <= 2^ex
@@ -1872,18 +1954,19 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     const int chunk_len = chunk_len_for(nx);
     const int nchunks = (int)ceil_div(nx, (size_t)chunk_len);
     const int cblocks = (nchunks + 3) / 4;
-    const size_t lds_cnt = (size_t)8 * k * sizeof(unsigned int);     // k float4 + 4 x k counters
+    const bool bigk = k > kKMeansMaxK;                                // no LDS-resident tables: counters and cursors in memory
+    const size_t lds_cnt = bigk ? 0 : (size_t)8 * k * sizeof(unsigned int);     // k float4 + 4 x k counters
     const size_t lds_sct = (size_t)5 * k * sizeof(unsigned int);
     const size_t lds_sct_pair = (size_t)9 * k * sizeof(unsigned int) + (size_t)4 * (k + 64) * sizeof(float4);
     static PerDeviceOnce attr;
     if (attr.first()) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_count, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_assign_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true, int>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false, int>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true, unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<false, unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * kKMeansMaxK * 4));
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
-        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
     }
     if (!w.mt_seeded) { hipLaunchKernelGGL(k_km_mt_seed, 1, 1, 0, s, w.mt.p); w.mt_seeded = true; }   // the start of std::mt19937(1234), kept
     { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (k + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p); }
@@ -1967,9 +2050,37 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             }
         } else {
             KTIME("k_km_assign", s, 16.0 * nx);
-            hipLaunchKernelGGL(k_km_assign_count, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p);
+            if (bigk) {
+                HIP_CHECK(hipMemsetAsync(w.table.p, 0, (size_t)k * nchunks * sizeof(unsigned int), s));
+                hipLaunchKernelGGL(k_km_assign_count<true>, cblocks, 256, 0, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p);
+            } else hipLaunchKernelGGL(k_km_assign_count<false>, cblocks, 256, lds_cnt, s, ks, nx, w.c4.p, k, nbits, chunk_len, nchunks, w.assign.p, w.table.p);
         }
         if (sums) { update_sums(use_lut && use_mid); continue; }
+        if (bigk) {
+            // palettes beyond kKMeansMaxK entries (the reference has no limit, refine.c:77-89): the same stable counting sort and the
+            // same chains, with the sort's per-centroid cursors in memory instead of LDS
+            { KTIME("k_km_rowscan", s, 8.0 * k * nchunks); hipLaunchKernelGGL(k_km_rowscan, k, 256, 0, s, w.table.p, nchunks, w.rowtot.p); }
+            hipLaunchKernelGGL(k_km_rowbase, 1, 256, 0, s, (const unsigned int *)w.rowtot.p, k, w.rowbase.p);
+            {
+                KTIME("k_km_scatter", s, (weighted ? 36.0 : 32.0) * nx);
+                if (weighted) hipLaunchKernelGGL(k_km_scatter_big<true>, cblocks, 256, 0, s, ks, (const int *)w.assign.p, nx, nbits, chunk_len, nchunks, w.table.p, (const unsigned int *)w.rowbase.p, w.sorted.p);
+                else hipLaunchKernelGGL(k_km_scatter_big<false>, cblocks, 256, 0, s, ks, (const int *)w.assign.p, nx, nbits, chunk_len, nchunks, w.table.p, (const unsigned int *)w.rowbase.p, w.sorted.p);
+            }
+            {
+                KTIME("k_km_update", s, 16.0 * nx);
+                const bool coop_on = nx >= long_min;
+                const size_t lds_up = coop_on ? (size_t)4 * 4096 * sizeof(float) : 0;
+                const unsigned long long lm = coop_on ? long_min : ~0ULL;
+                static PerDeviceOnce attr6;
+                if (attr6.first()) {
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
+                }
+                if (weighted) hipLaunchKernelGGL((k_km_update<true, true>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, w.hs.p);
+                else hipLaunchKernelGGL((k_km_update<false, true>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, w.hs.p);
+            }
+            continue;
+        }
         { KTIME("k_km_rowscan", s, 8.0 * k * nchunks); hipLaunchKernelGGL(k_km_rowscan, k, 256, 0, s, w.table.p, nchunks, w.rowtot.p); }
         {
             KTIME("k_km_scatter", s, (weighted ? 36.0 : 32.0) * nx - (use_mid ? 3.0 : 0.0) * nx);
@@ -1997,8 +2108,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             const bool coop_on = nx >= long_min;
             const size_t lds_up = coop_on ? (size_t)4 * 4096 * sizeof(float) : 0;
             const unsigned long long lm = coop_on ? long_min : ~0ULL;
-            if (weighted) hipLaunchKernelGGL(k_km_update<true>, k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm);
-            else hipLaunchKernelGGL(k_km_update<false>, k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm);
+            if (weighted) hipLaunchKernelGGL((k_km_update<true, false>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, (float *)nullptr);
+            else hipLaunchKernelGGL((k_km_update<false, false>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, (float *)nullptr);
         }
     }
     HIP_CHECK(hipGetLastError());

@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <future>
 
 #include "color_device.h"
 #include "common.h"
@@ -257,8 +258,15 @@ struct Engine {
     DevBuf<double> wsal;
     DevBuf<GqDpDev> gq;
     PinBuf<GqDpDev> h_gq;
+    // KMeans subsample list = a prefix of rand_perm(N, seed 1234) (Clustering.cpp:311-319): a pure function of N, and the list
+    // for FEWER samples is a prefix of the list for more.  perm_dev holds the first perm_nx entries for an image of perm_N pixels;
+    // h_perm (pinned) the first hperm_nx for hperm_N, written by a helper thread (perm_job) that starts at call entry and is
+    // waited for when the KMeans stage needs the list -- by then conversion and both quantisers have run (subsample_start/_list)
     DevBuf<int> perm_dev;
     size_t perm_N = 0, perm_nx = 0;
+    PinBuf<int32_t> h_perm;
+    size_t hperm_N = 0, hperm_nx = 0;
+    std::future<void> perm_job;
     patolette_amd__Stats stats{};
     double ms_saliency = 0.0;
     std::string last_error;
@@ -934,6 +942,42 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
 // patolette_amd_set_kmeans_update: process-wide (the batch entry's helper threads must see the caller's choice).  -1: not set, the
 // environment's default (PAMD_KMEANS_UPDATE)
 std::atomic<int> g_km_update{-1};
+// patolette_amd_set_subsample_cache: 1 (default) keep the subsample list on the device between calls on images of one size;
+// 0 every call makes it again (on the helper thread): what a first call of a size costs, call after call
+std::atomic<int> g_perm_cache{1};
+
+// Call entry: if this image will be subsampled (assuming the quantisers deliver all K clusters; fewer only shorten the list),
+// start making the list on a helper thread.  take = the longest list any cluster count <= K can ask for: min(ms, N).
+static void subsample_start(Engine &E, size_t Nt, size_t K, size_t max_samples) {
+    if (E.perm_job.valid()) E.perm_job.wait();                                  // a job left behind by a call that threw
+    const size_t ms = std::max(max_samples, (size_t)(256 * 256));                // refine.c:21
+    if (K == 0 || Nt < K) return;
+    const size_t nxK = K * (size_t)(int)(ms / K);
+    if (!(Nt > nxK)) return;                                                     // Clustering.cpp:311: no subsampling
+    const size_t take = std::min(ms, Nt);
+    if (!g_perm_cache.load(std::memory_order_relaxed)) { E.perm_N = 0; E.perm_nx = 0; E.hperm_N = 0; E.hperm_nx = 0; }
+    if (E.perm_N == Nt && E.perm_nx >= nxK) return;                              // on the device already
+    if (E.hperm_N == Nt && E.hperm_nx >= nxK) return;
+    E.h_perm.reserve(take);
+    E.hperm_N = 0; E.hperm_nx = 0;
+    int32_t *dst = E.h_perm.p;
+    E.perm_job = std::async(std::launch::async, [dst, Nt, take] { hm::rand_perm_prefix(Nt, take, 1234u, dst); });   // random.cpp:184-194
+    E.hperm_N = Nt; E.hperm_nx = take;                                           // valid once perm_job has been waited for
+}
+// The KMeans stage: the first nx entries of rand_perm(Nt) on the device; no stream synchronisation (pinned staging)
+static const int *subsample_list(Engine &E, size_t Nt, size_t nx, hipStream_t s) {
+    if (E.perm_job.valid()) E.perm_job.get();
+    if (E.perm_N == Nt && E.perm_nx >= nx) return E.perm_dev.p;
+    if (!(E.hperm_N == Nt && E.hperm_nx >= nx)) {                                // no helper was started (a stage-level call, fewer clusters than K)
+        E.h_perm.reserve(nx);
+        hm::rand_perm_prefix(Nt, nx, 1234u, E.h_perm.p);
+        E.hperm_N = Nt; E.hperm_nx = nx;
+    }
+    E.perm_dev.reserve(E.hperm_nx);
+    HIP_CHECK(hipMemcpyAsync(E.perm_dev.p, E.h_perm.p, E.hperm_nx * sizeof(int), hipMemcpyHostToDevice, s));
+    E.perm_N = Nt; E.perm_nx = E.hperm_nx;
+    return E.perm_dev.p;
+}
 static bool km_update_order_free() {
     static const bool env = getenv("PAMD_KMEANS_UPDATE") && atoi(getenv("PAMD_KMEANS_UPDATE")) != 0;
     const int v = g_km_update.load(std::memory_order_relaxed);
@@ -945,7 +989,6 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
     hipStream_t s = E.stream;
     const KmSums sums_v{bound_x, bound_w};
     const KmSums *sums = km_update_order_free() ? &sums_v : nullptr;
-    if (k > (size_t)kKMeansMaxK) throw HipError("patolette_amd: KMeans refinement supports at most 4096 palette entries");
     std::vector<float> cent(3 * k);
     for (size_t i = 0; i < k; i++) for (int j = 0; j < 3; j++) cent[3 * i + j] = (float)centers[(size_t)j * k + i];   // refine.c:102-125
     const size_t min_samples = 256 * 256;                                          // refine.c:21
@@ -964,19 +1007,7 @@ static void kmeans_refine(Engine &E, size_t N, bool weighted, std::vector<double
         if (sub) nx = k * (size_t)mppc;
         E.km.reserve(nx, (int)k);
         const int *dperm = nullptr;
-        if (sub) {
-            // faiss draws the subsample from rand_perm(N, seed 1234): a pure function of (N, nx), so the
-            // index list is kept on the device between calls (a batch of same-sized images pays once)
-            if (E.perm_N != Nt || E.perm_nx != nx) {
-                std::vector<int32_t> perm(nx);
-                hm::rand_perm_prefix(Nt, nx, 1234u, perm.data());                  // random.cpp:184-194
-                E.perm_dev.reserve(nx);
-                HIP_CHECK(hipMemcpyAsync(E.perm_dev.p, perm.data(), nx * sizeof(int), hipMemcpyHostToDevice, s));
-                HIP_CHECK(hipStreamSynchronize(s));
-                E.perm_N = Nt; E.perm_nx = nx;
-            }
-            dperm = E.perm_dev.p;
-        }
+        if (sub) dperm = subsample_list(E, Nt, nx, s);                            // faiss draws the subsample from rand_perm(N, seed 1234)
         if (sh) {
             // every GPU contributes the samples that fall into its slice (zero bits elsewhere); the integer SUM of the bit
             // patterns hands every GPU the whole sample set, and each runs the same deterministic iterations on it
@@ -1095,6 +1126,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     const double t_start = now_ms();
     E.stats = patolette_amd__Stats{};
     E.prep_N = 0;
+    if (opt->kmeans_niter > 0) subsample_start(E, E.shard ? E.shard->total : N, K, opt->kmeans_max_samples);
     // S1: colour conversion into the working image (x|y|z|w planar), patolette.c:201-207
     double t0 = now_ms();
     E.cvt.reserve((weighted ? 4 : 3) * N);
@@ -1573,6 +1605,10 @@ int patolette_amd_set_invariant_sums(int on) {
     EngineHolder &h = holder();
     if (h.e) h.e->invariant = on != 0;                // the engine already serving this thread; later ones copy tl_invariant
     return before;
+}
+
+int patolette_amd_set_subsample_cache(int on) {
+    return g_perm_cache.exchange(on != 0 ? 1 : 0, std::memory_order_relaxed);
 }
 
 int patolette_amd_set_kmeans_update(int mode) {

@@ -137,6 +137,42 @@ def test_kmeans_many_empty_clusters_every_iteration(gpu, ob, ncol, k, weighted, 
     assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
 
 
+@pytest.mark.parametrize("k,weighted,n,ncol", [(5000, False, 300000, 0), (4100, True, 70000, 0), (6000, False, 90000, 900), (5000, True, 40000, 0)])
+def test_kmeans_palettes_beyond_4096(gpu, ob, k, weighted, n, ncol):
+    """The reference refines any palette size (refine.c:77-89, Clustering.cpp:267-554); beyond 4096 entries the stable sort's counters
+    and cursors and split_clusters' size table leave LDS for device memory.  Bit-exact centroids against the oracle: subsampled
+    (300 000 > k * max_points_per_centroid) and not, weighted, and with `ncol` < k distinct colours so that thousands of clusters
+    come out empty in every iteration and are re-seeded."""
+    rng = np.random.default_rng(k + n)
+    if ncol:
+        colours = rng.random((ncol, 3))
+        pts = colours[rng.integers(0, ncol, size=n)]
+        flat = np.ascontiguousarray(pts.T).reshape(-1).copy()
+    else:
+        flat = ob.convert("srgb_to_ictcp", ob.image(n, 41))
+        pts = flat.reshape(3, n).T
+    w = ob.weights(n, 5) if weighted else None
+    cent = pts[rng.choice(n, size=k, replace=False)].copy() + 1e-4 * rng.standard_normal((k, 3))
+    want = ob.kmeans_refine(flat, w, n, cent, 3, 512 ** 2)
+    c = np.ascontiguousarray(cent.T).reshape(-1).copy()
+    assert gpu.patolette_amd_kmeans_refine(_d(flat), _d(w), n, _d(c), k, 3, 512 ** 2) == 0
+    got = c.reshape(3, k).T
+    assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
+
+
+def test_end_to_end_5000_colours_with_kmeans(gpu, ob):
+    """patolette() with palette_size 5000 and the KMeans refinement on (the stage that used to stop at 4096): palette and map."""
+    import patolette_amd as p
+    w_, h_ = 640, 480
+    n = w_ * h_
+    colors = ob.unplanar(ob.image(n, 43), n)
+    ok, pal, pmap, msg = p.quantize(w_, h_, colors, 5000, dither=False, color_space=2, tile_size=0, kmeans_niter=3, kmeans_max_samples=512 ** 2)
+    ec, pal_o, pmap_o = ob.patolette(w_, h_, ob.planar(colors), None, 5000, dither=False, color_space=2, kmeans_niter=3, kmeans_max_samples=512 ** 2)
+    assert ok and ec == 0, msg
+    assert np.allclose(pal, pal_o, rtol=0, atol=1e-9)
+    assert np.array_equal(pmap, pmap_o)
+
+
 @pytest.mark.parametrize("cs,k,weighted,g64", [("srgb_to_ictcp", 256, False, False), ("srgb_to_cieluv", 200, True, False), ("srgb_to_ictcp", 61, False, False),
                                                ("srgb_to_ictcp", 256, False, True), ("srgb_to_cieluv", 203, True, True)])
 def test_kmeans_pruned_assignment_many_samples(gpu, ob, monkeypatch, cs, k, weighted, g64):
