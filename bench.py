@@ -356,8 +356,10 @@ def main():
                     help="after the timed region also measure throughput with this many concurrent images per GPU; reported "
                          "separately as throughput_concurrent, never as `value` (0 = skip)")
     ap.add_argument("--kmeans-update", type=int, default=0, choices=[0, 1],
-                    help="1: the order-free centroid update (patolette_amd_set_kmeans_update(1): an option within north_star's 1e-5, "
-                         "not the reference's bits); the line then says so in config.kmeans_update and is never the headline")
+                    help="1: the order-free centroid update (patolette_amd_set_kmeans_update(1)): NOT the reference's bits and OUTSIDE north_star's "
+                         "1e-5 -- ~1e-6 of the colour range per iteration, ~1e-4 after the default 32 iterations at ~1000 members per centroid, "
+                         "~0.02 %% of the index map follows (tests/test_gpu_kmeans_update.py); the line says so in config.kmeans_update and is "
+                         "never the headline")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -695,7 +697,8 @@ def main():
         "value": round(value, 3), "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": desc, "kmeans_update": ("order-free exact sums (OPTION: within 1e-5 of the reference, not its bits)"
+        "config": {"workload": desc, "kmeans_update": ("order-free exact sums (OPTION, NOT a parity result: palette ~1e-4 of the colour range from the reference's after 32 "
+                                                        "iterations -- outside north_star's 1e-5 --, ~0.02 % of the index map differs)"
                                                         if args.kmeans_update else "reference (sequential f32 chains, bit-exact)"),
                    "width": width, "height": height, "palette_size": K, "images_per_step_per_gpu": S,
                    "input": "uniform random sRGB (splitmix64), planar f64, resident in HBM; index map left in HBM as u8",

@@ -12,11 +12,12 @@ struct NNWork {                        // scratch of the pruned NN map
     DevBuf<unsigned long long> keys;   // min/max keys when the caller has no bounds
     DevBuf<unsigned char> clist;       // coarse pass of the LUT build: surviving entries per 4x4x4 block of cells
     DevBuf<unsigned int> mid;          // (G/2)^3 table of up to four candidates per cell, held in LDS by k_nn_map_mid
+    DevBuf<double> dtab;               // dither with more than 3200 palette entries: its two palette tables (6 k doubles)
 };
 // lo/hi: exact per-plane min/max of the colours if known (else nullptr: computed with one more pass)
 void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k,
                    void *d_out, int elem_bytes, const double *lo, const double *hi, NNWork &w, hipStream_t s);
 void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
-                   void *d_out, int elem_bytes, hipStream_t s);
+                   void *d_out, int elem_bytes, NNWork &w, hipStream_t s);
 
 }  // namespace pamd

@@ -970,12 +970,13 @@ static void launch_dither_t(const double *d_img, size_t plane_stride, size_t wid
 }
 
 void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
-                   void *d_out, int elem_bytes, hipStream_t s) {
+                   void *d_out, int elem_bytes, NNWork &w, hipStream_t s) {
     if (width * height >> 32) throw HipError("patolette_amd: the dither kernel numbers pixels with 32 bits");
     size_t lds = ((size_t)6 * k + 3 * 128) * sizeof(double) + 128 * sizeof(unsigned int);      // palette (raw + weighted) + the ring of pending pixels
     double *gtab = nullptr;
-    if (lds > 150 * 1024) {                                      // K > 3200: the tables in global memory (freed behind the kernel)
-        HIP_CHECK(hipMallocAsync((void **)&gtab, (size_t)6 * k * sizeof(double), s));
+    if (lds > 150 * 1024) {                                      // K > 3200: the tables in global memory (workspace kept with the engine)
+        w.dtab.reserve((size_t)6 * k);
+        gtab = w.dtab.p;
         lds = (size_t)3 * 128 * sizeof(double) + 128 * sizeof(unsigned int);
     }
     DitherWeights wts;
@@ -988,9 +989,8 @@ void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_
     if (elem_bytes == 1) launch_dither_t<unsigned char>(d_img, plane_stride, width, height, d_pal, k, (unsigned char *)d_out, wts, lds, gtab, s);
     else if (elem_bytes == 4) launch_dither_t<unsigned int>(d_img, plane_stride, width, height, d_pal, k, (unsigned int *)d_out, wts, lds, gtab, s);
     else if (elem_bytes == 8) launch_dither_t<unsigned long long>(d_img, plane_stride, width, height, d_pal, k, (unsigned long long *)d_out, wts, lds, gtab, s);
-    else { if (gtab) (void)hipFreeAsync(gtab, s); throw HipError("patolette_amd: map element size must be 1, 4 or 8"); }
+    else throw HipError("patolette_amd: map element size must be 1, 4 or 8");
     HIP_CHECK(hipGetLastError());
-    if (gtab) HIP_CHECK(hipFreeAsync(gtab, s));
 }
 
 }  // namespace pamd

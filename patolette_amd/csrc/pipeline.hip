@@ -626,20 +626,32 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     // image front to back, so the root's moments are taken back to front, the extrema front to back, ...
     static const bool snake = !(getenv("PAMD_SWEEP_SNAKE") && atoi(getenv("PAMD_SWEEP_SNAKE")) == 0);
     std::vector<NodeOut> got;
-    const bool mom_path = bnd.have_mom && !sh;                  // one sweep less: the directions of the following ones flip
+    bool mom_path = bnd.have_mom && !sh;                        // one sweep less: the directions of the following ones flip
     if (mom_path) {
         // The conversion pass took the column sums S1 and the raw second moments S2 as exact pairs: the centred sums
-        // S2_jk - S1_j S1_k / n (pca.c:62-101 about the mean, matrix2D.c:200-233) follow in extended precision -- the
-        // difference keeps ~60 of its 64 bits, then ONE rounding to double -- instead of a sweep over the image and a round trip.
+        // S2_jk - S1_j S1_k / n (pca.c:62-101 about the mean, matrix2D.c:200-233) follow in extended precision, then ONE rounding
+        // to double -- instead of a sweep over the image and a round trip.  What the shortcut cannot undo: every product x_j x_k was
+        // rounded to double before it was binned (relative 2^-53, systematic for a flat image), so the difference is good to
+        // ~1e-16 of S2 and no better: an image whose spread is tiny against its mean -- trace(cov) below 1e-6 of trace(S2), i.e.
+        // fewer than ~10 digits left --, or a difference that came out negative, takes the centred sweep below instead.
         const long double nn = (long double)Nt;
-        long double s1[3], c6[6];
+        long double s1[3], c6[6], s2d[3] = {0, 0, 0};
         for (int j = 0; j < 3; j++) s1[j] = (long double)bnd.sum2[j][0] + (long double)bnd.sum2[j][1];
         static const int ja[6] = {0, 1, 2, 1, 2, 2}, jb[6] = {0, 0, 0, 1, 1, 2};       // xx, yx, zx, yy, zy, zz
-        for (int q = 0; q < 6; q++)
-            c6[q] = ((long double)bnd.mom2[q][0] + (long double)bnd.mom2[q][1]) - s1[ja[q]] * s1[jb[q]] / nn;
-        for (int q = 0; q < 6; q++) hn[0].cov6[q] = (double)c6[q];
-        hn[0].dist = (double)(c6[0] + c6[3] + c6[5]);
-    } else {
+        for (int q = 0; q < 6; q++) {
+            const long double s2 = (long double)bnd.mom2[q][0] + (long double)bnd.mom2[q][1];
+            if (ja[q] == jb[q]) s2d[ja[q]] = s2;
+            c6[q] = s2 - s1[ja[q]] * s1[jb[q]] / nn;
+        }
+        const long double tr = c6[0] + c6[3] + c6[5], tr2 = s2d[0] + s2d[1] + s2d[2];
+        static const bool guard = !(getenv("PAMD_ROOT_MOMENTS_GUARD") && atoi(getenv("PAMD_ROOT_MOMENTS_GUARD")) == 0);
+        if (guard && (!(tr > 1e-6L * tr2) || c6[0] < 0 || c6[3] < 0 || c6[5] < 0)) mom_path = false;
+        else {
+            for (int q = 0; q < 6; q++) hn[0].cov6[q] = (double)c6[q];
+            hn[0].dist = (double)tr;
+        }
+    }
+    if (!mom_path) {
         NodeIn d = make_nodedev(hn[0], bnd);
         put_nodes(E, {0}, {d});
         launch_cov_nodes(qroot, E.cvt.p, E.tilesA.p, ntA0, N, E.nodes.p, s, snake);
@@ -1196,7 +1208,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
                 launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);          // plane stride of cvt is N for x,y,z
                 HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                launch_dither(E.aux.p, N, width, height, E.dpal.p, (int)len, d_map, map_elem, s);
+                launch_dither(E.aux.p, N, width, height, E.dpal.p, (int)len, d_map, map_elem, E.nn, s);
             }
             palette_rows(pal, len, hm::color::rec2020_to_srgb);
         } else {                                                               // patolette.c:300-324
@@ -1975,7 +1987,7 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
     E.src.reserve(3 * n); E.dpal.reserve(3 * k); E.dmap.reserve(n * 4);
     HIP_CHECK(hipMemcpy(E.src.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(E.dpal.p, palette, 3 * k * sizeof(double), hipMemcpyHostToDevice));
-    launch_dither(E.src.p, n, width, height, E.dpal.p, (int)k, E.dmap.p, 4, E.stream);
+    launch_dither(E.src.p, n, width, height, E.dpal.p, (int)k, E.dmap.p, 4, E.nn, E.stream);
     E.sync();
     if (std::max(width, height) > 1) {
         std::vector<unsigned int> tmp(n);

@@ -204,16 +204,22 @@ def quantize_batch_sharded(width, height, images, palette_size, dist=None, quant
 
         def fail(j, e):
             # Nothing an image (or its loader) raises may leave this rank before the gathers: the others would wait for ever.
-            # Saliency stage: shape (-5) / singular covariance (-6); anything else is the reference's "internal error".
-            code = -6 if isinstance(e, np.linalg.LinAlgError) else (-5 if isinstance(e, ValueError) else -1)
-            errors[idx[j]] = str(e) if code != -1 else "%s: %s" % (type(e).__name__, e)
-            put(j, (False, None, None, str(e)), code)
+            # Only what the SALIENCY STAGE raises keeps its own exit code -- the binding turns codes -5 / -6 into a ValueError /
+            # LinAlgError carrying the library's message for that code (patolette_amd._raise_saliency); a ValueError from a loader,
+            # a shape check or an unknown keyword is the reference's "internal error" (-1) with its text, as on the RCCL path.
+            text = str(e)
+            code = -1
+            if isinstance(e, np.linalg.LinAlgError) and messages.get(-6) and messages[-6] in text:
+                code = -6
+            elif isinstance(e, ValueError) and messages.get(-5) and text == messages[-5]:
+                code = -5
+            errors[idx[j]] = text if code != -1 else "%s: %s" % (type(e).__name__, e)
+            put(j, (False, None, None, text), code)
 
         if quantize_fn is None:
             from . import quantize_batch, quantize_u8_batch
 
-            def run_group(js):
-                group = [get(idx[j]) for j in js]
+            def run_group(js, group):
                 ws = None if weights is None else [weights[idx[j]] for j in js]
                 if all(getattr(im, "dtype", None) == np.uint8 and getattr(im, "ndim", 0) == 3 for im in group):
                     # 8-bit images as decoded, (H, W, 3|4): 3 bytes per pixel over PCIe instead of 24
@@ -224,14 +230,22 @@ def quantize_batch_sharded(width, height, images, palette_size, dist=None, quant
                 return quantize_batch(width, height, group, palette_size, weights=ws, **kwargs)
 
             for g0 in range(0, n, 6):                             # groups of six bound the host memory held at once
-                grp = list(range(g0, min(g0 + 6, n)))
+                grp, imgs = [], []
+                for j in range(g0, min(g0 + 6, n)):               # a failing loader fails its own image, before any GPU work
+                    try:
+                        imgs.append(get(idx[j]))
+                        grp.append(j)
+                    except Exception as e:                        # noqa: BLE001
+                        fail(j, e)
+                if not grp:
+                    continue
                 try:
-                    for j, r in zip(grp, run_group(grp)):
+                    for j, r in zip(grp, run_group(grp, imgs)):
                         put(j, r)
-                except Exception:                                 # noqa: BLE001 -- find the culprit: one image at a time
-                    for j in grp:
+                except Exception:                                 # noqa: BLE001 -- a malformed image: find it, one image at a time
+                    for j, im in zip(grp, imgs):
                         try:
-                            put(j, run_group([j])[0])
+                            put(j, run_group([j], [im])[0])
                         except Exception as e:                    # noqa: BLE001
                             fail(j, e)
         else:

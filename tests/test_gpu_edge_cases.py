@@ -128,16 +128,23 @@ def test_kmeans_with_fewer_samples_than_min_and_k_not_multiple_of_8(gpu, native,
     assert got[0] == want[0] == 0
 
 
-def test_kmeans_beyond_supported_palette_size_fails_loudly(gpu, native, ob):
+def test_kmeans_beyond_4096_palette_entries_matches_oracle(gpu, native, ob):
+    """The limit round 3 still had (KMeans stopped, loudly, at palette_size 4096) is gone: the reference has none (refine.c:77-89)."""
     w, h, K = 128, 128, 5000
     flat = ob.image(w * h, 90)
-    L = native.lib()
-    opts = native.QuantizationOptions(False, False, 2, 2, 512 ** 2, False)
-    pal = np.zeros((K, 3), dtype=np.float64, order="F")
-    pmap = np.zeros(w * h, dtype=np.uintp)
-    code = C.c_int(0)
-    L.patolette(w, h, _d(flat), None, K, C.byref(opts), pal.ctypes.data_as(dp), pmap.ctypes.data_as(zp), C.byref(code))
-    assert code.value == -1 and "4096" in native.last_error()
+    got, want = run_both(native, ob, w, h, flat, None, K, kmeans_niter=2)
+    assert_same(got, want)
+
+
+@pytest.mark.parametrize("cs,amp", [(2, 1e-6), (2, 1e-9), (1, 1e-7), (2, 3e-4)])
+def test_low_variance_image_root_covariance(gpu, native, ob, cs, amp):
+    """A nearly flat image: the root covariance as S2 - S1 S1' / n (the moments that ride with the conversion) cancels all
+    its digits here, so the pipeline must fall back to the centred sweep -- axis, buckets and everything after it as the oracle's."""
+    w, h, K = 512, 384, 16
+    n = w * h
+    flat = np.clip(np.repeat([0.6, 0.35, 0.2], n) + amp * (ob.image(n, 91) - 0.5), 0.0, 1.0)
+    got, want = run_both(native, ob, w, h, flat, None, K, color_space=cs)
+    assert_same(got, want)
 
 
 def test_kmeans_skipped_when_a_value_is_not_finite_as_float(gpu, native, ob):
