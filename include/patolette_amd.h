@@ -201,6 +201,9 @@ int patolette_amd_set_kmeans_update(int mode);
 int patolette_amd_set_subsample_cache(int on);
 
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */
+/* The KMeans subsample the refinement draws (faiss Clustering.cpp:311-319: the first `take` entries of rand_perm(n, seed 1234),
+ * utils/random.cpp:184-194) as the product's host code makes it (host only: needs no device).  0 = ok. */
+int patolette_amd_subsample_indices(size_t n, size_t take, int32_t *out);
 /* patolette__EIGEN_solve (math/eigen.c:83-140: LAPACK dsyev 'V','L', n = 3) as the split loop's host side solves it:
  * a column-major 3x3 (lower triangle read) -> w ascending, z = eigenvectors as columns; returns LAPACK's info (0 = ok).
  * patolette_amd_principal_axis: covariance as (xx,xy,xz,yy,yz,zz) -> eigenvector of the largest eigenvalue incl. its

@@ -66,6 +66,7 @@ SYMBOLS = {
     "patolette_amd_set_invariant_sums": (C.c_int, [C.c_int]),
     "patolette_amd_set_kmeans_update": (C.c_int, [C.c_int]),
     "patolette_amd_set_subsample_cache": (C.c_int, [C.c_int]),
+    "patolette_amd_subsample_indices": (C.c_int, [C.c_size_t, C.c_size_t, C.POINTER(C.c_int32)]),
     "patolette_amd_eigen_sym3": (C.c_int, [dp, dp, dp]),
     "patolette_amd_principal_axis": (C.c_int, [dp, dp]),
     "patolette_amd_fill_image": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),

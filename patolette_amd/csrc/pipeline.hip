@@ -266,6 +266,7 @@ struct Engine {
     size_t perm_N = 0, perm_nx = 0;
     PinBuf<int32_t> h_perm;
     size_t hperm_N = 0, hperm_nx = 0;
+    hm::PermScratch perm_ws;          // the helper's tables (kept: no page faults after the first call)
     std::future<void> perm_job;
     patolette_amd__Stats stats{};
     double ms_saliency = 0.0;
@@ -973,7 +974,8 @@ static void subsample_start(Engine &E, size_t Nt, size_t K, size_t max_samples) 
     E.h_perm.reserve(take);
     E.hperm_N = 0; E.hperm_nx = 0;
     int32_t *dst = E.h_perm.p;
-    E.perm_job = std::async(std::launch::async, [dst, Nt, take] { hm::rand_perm_prefix(Nt, take, 1234u, dst); });   // random.cpp:184-194
+    hm::PermScratch *ws = &E.perm_ws;
+    E.perm_job = std::async(std::launch::async, [dst, Nt, take, ws] { hm::rand_perm_prefix(Nt, take, 1234u, dst, *ws); });   // random.cpp:184-194
     E.hperm_N = Nt; E.hperm_nx = take;                                           // valid once perm_job has been waited for
 }
 // The KMeans stage: the first nx entries of rand_perm(Nt) on the device; no stream synchronisation (pinned staging)
@@ -982,7 +984,7 @@ static const int *subsample_list(Engine &E, size_t Nt, size_t nx, hipStream_t s)
     if (E.perm_N == Nt && E.perm_nx >= nx) return E.perm_dev.p;
     if (!(E.hperm_N == Nt && E.hperm_nx >= nx)) {                                // no helper was started (a stage-level call, fewer clusters than K)
         E.h_perm.reserve(nx);
-        hm::rand_perm_prefix(Nt, nx, 1234u, E.h_perm.p);
+        hm::rand_perm_prefix(Nt, nx, 1234u, E.h_perm.p, E.perm_ws);
         E.hperm_N = Nt; E.hperm_nx = nx;
     }
     E.perm_dev.reserve(E.hperm_nx);
@@ -1879,6 +1881,11 @@ void patolette_amd_batch_dmap(size_t count, size_t width, size_t height, const v
 
 int patolette_amd_principal_axis(const double cov6[6], double axis[3]) {
     return hm::principal_axis(cov6, axis) ? 0 : -1;
+}
+int patolette_amd_subsample_indices(size_t n, size_t take, int32_t *out) {
+    if (!out || take > n) return -1;
+    hm::rand_perm_prefix(n, take, 1234u, out);                              // host code: needs no device
+    return 0;
 }
 int patolette_amd_eigen_sym3(const double a_colmajor[9], double w[3], double z[9]) {
     std::memcpy(z, a_colmajor, 9 * sizeof(double));

@@ -113,3 +113,31 @@ def test_slice_entry_validation_needs_no_gpu(native):
     bad = _native.Comm(2, 2, cb, None, 1)
     assert call(20, 0, 10, 4, C.byref(bad)) == -1                     # rank outside the group
     assert not calls
+
+
+def test_product_subsample_list_is_the_rand_perm_prefix_of_faiss(native, ob):
+    """The product's host code for the KMeans subsample (two-pass sparse Fisher-Yates with prefetched table slots, host_math.h)
+    against numpy's MT19937 driving a full Fisher-Yates (random.cpp:184-194) and against the oracle's list at the sizes the
+    pipeline uses (262 144 of 16.8 M; n barely above take; take == n; tiny n)."""
+    import numpy as np
+    L = native.lib()
+    i32p = C.POINTER(C.c_int32)
+    n, take = 5000, 5000
+    mt = np.random.MT19937()
+    mt._legacy_seeding(1234)
+    raw = mt.random_raw(n)
+    perm = np.arange(n)
+    for i in range(n - 1):
+        j = i + int(raw[i]) % (n - i)
+        perm[i], perm[j] = perm[j], perm[i]
+    for tk in (1, 700, 4999, 5000):
+        out = np.zeros(tk, dtype=np.int32)
+        assert L.patolette_amd_subsample_indices(n, tk, out.ctypes.data_as(i32p)) == 0
+        assert np.array_equal(out, perm[:tk]), tk
+    for n, tk in ((4096 * 4096, 262144), (262145, 262144), (300000, 262144), (70000, 65536), (1, 1), (2, 2)):
+        a = np.zeros(tk, dtype=np.int32)
+        b = np.zeros(tk, dtype=np.int32)
+        assert L.patolette_amd_subsample_indices(n, tk, a.ctypes.data_as(i32p)) == 0
+        ob.lib().orc_kmeans_subsample_indices(n, tk, 1234, b.ctypes.data_as(i32p))
+        assert np.array_equal(a, b), (n, tk)
+        assert len(np.unique(a)) == tk and a.min() >= 0 and a.max() < n

@@ -133,13 +133,19 @@ def test_kmeans_beyond_4096_palette_entries_matches_oracle(gpu, native, ob):
     w, h, K = 128, 128, 5000
     flat = ob.image(w * h, 90)
     got, want = run_both(native, ob, w, h, flat, None, K, kmeans_niter=2)
-    assert_same(got, want)
+    # ~3 pixels per cluster: the last splits divide two-pixel clusters, whose left / right order is the sign dsyev gives a
+    # rank-1 covariance (undefined) -- two rows come out swapped; compared up to that permutation
+    assert_same(got, want, ordered=False)
 
 
-@pytest.mark.parametrize("cs,amp", [(2, 1e-6), (2, 1e-9), (1, 1e-7), (2, 3e-4)])
+@pytest.mark.parametrize("cs,amp", [(2, 1e-3), (2, 1e-4), (2, 3e-5), (1, 1e-4), (1, 3e-5)])
 def test_low_variance_image_root_covariance(gpu, native, ob, cs, amp):
-    """A nearly flat image: the root covariance as S2 - S1 S1' / n (the moments that ride with the conversion) cancels all
-    its digits here, so the pipeline must fall back to the centred sweep -- axis, buckets and everything after it as the oracle's."""
+    """A nearly flat image: the root covariance as S2 - S1 S1' / n (the moments that ride with the conversion) cancels most of
+    its digits here (trace(cov) / trace(S2) ~ 1e-8 .. 1e-11: the pipeline then takes the centred sweep) -- axis, buckets and
+    everything after them as the oracle's.  Not below a spread of ~1e-5: there the REFERENCE's own split objective (uncentred
+    f64 sums per bucket, csl^2 / sl, local.c:118-176) varies by (spread)^2 ~ 1e-10 relative across the cuts against ~1e-13
+    of summation noise, and its arg-max is decided by that noise (measured: 70-549 of 196 608 map entries differ at 1e-5,
+    with and without the fallback)."""
     w, h, K = 512, 384, 16
     n = w * h
     flat = np.clip(np.repeat([0.6, 0.35, 0.2], n) + amp * (ob.image(n, 91) - 0.5), 0.0, 1.0)
