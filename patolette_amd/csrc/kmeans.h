@@ -15,6 +15,7 @@ struct KMeansWork {
     DevBuf<int> assign;
     DevBuf<float4> sorted;             // samples grouped by centroid, sample order kept
     DevBuf<unsigned int> table, rowtot, ticket;
+    DevBuf<unsigned int> flags;        // list path: [0] fixed point reached, [1 + j] centroid j dirty (kmeans.hip, k_km_prep)
     DevBuf<unsigned int> rowbase;      // k > kKMeansMaxK: exclusive prefix of rowtot
     DevBuf<float> hs;                  // k > kKMeansMaxK: split_clusters' working copy of the cluster sizes
     DevBuf<float> cent, hassign;       // interleaved xyz centroids (faiss layout)

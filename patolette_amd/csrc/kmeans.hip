@@ -68,9 +68,16 @@ __device__ __forceinline__ void km_store_c4(float4 *c4, const int k, const int j
     float *pp = reinterpret_cast<float *>(c4 + k) + 8 * (j >> 1) + (j & 1);
     pp[0] = r.x; pp[2] = r.y; pp[4] = r.z; pp[6] = r.w;
 }
-__global__ void k_km_prep(const float *__restrict__ cent, int k, float4 *c4) {
+// flags (kKmFlagWords words, the list path of the default 512^2 samples): [0] = the iterations have reached a fixed point (no sample
+// changed its centroid in the last assignment and no cluster was re-seeded: every later iteration reproduces the same centroids bit
+// for bit, so the remaining launches return at once); [1 + j] = centroid j is DIRTY -- a sample joined or left it in the last
+// assignment, or split_clusters touched it after the last update.  A clean centroid's members are the same samples in the same
+// order as one iteration ago: its sequential f32 sums come out the same, and its block skips collecting them.
+constexpr int kKmFlagWords = 2 + 256;
+__global__ void k_km_prep(const float *__restrict__ cent, int k, float4 *c4, unsigned int *flags) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < k) km_store_c4(c4, k, j, cent[3 * j], cent[3 * j + 1], cent[3 * j + 2]);
+    if (flags && j < kKmFlagWords) flags[j] = j == 0 ? 0u : 1u;         // nothing is known about the first assignment: all dirty
 }
 
 // top-1 of one sample against all centroids, exactly as the AVX2 fused kernel orders it
@@ -1101,7 +1108,7 @@ struct KmSizes {
 };
 template <bool HMEM = false>
 __device__ __forceinline__ void km_split_clusters_wave(float *cent, float *hassign, const int k, const unsigned long long n, const DevMT *seeded,
-                                                       unsigned *s_mt, float *s_h_, const int lane) {
+                                                       unsigned *s_mt, float *s_h_, const int lane, unsigned int *flags = nullptr) {
     const KmSizes<HMEM> s_h{s_h_};
     for (int i = lane; i < 624; i += 64) s_mt[i] = seeded->mt[i];
     for (int j = lane; j < k; j += 64) s_h.put(j, hassign[j]);
@@ -1158,6 +1165,7 @@ __device__ __forceinline__ void km_split_clusters_wave(float *cent, float *hassi
             const float hi = hcj / 2, hj = hcj - hi;
             s_h.put(ci, hi); s_h.put(cj, hj);
             hassign[ci] = hi; hassign[cj] = hj;
+            if (flags) { flags[1 + ci] = 1u; flags[1 + cj] = 1u; }          // their next update must not be skipped
             if constexpr (HMEM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1496,7 +1504,8 @@ __device__ __forceinline__ float km_coop_lds(const float *mine, const float *wts
 template <bool W, int HS>
 __device__ __forceinline__ void km_update_finish(const int kidx, const int k, const unsigned long long nx, const size_t cnt, const float *res,
                                                  int *s_last, float *cent, float *hassign, float4 *c4, unsigned int *ticket, DevMT *mt,
-                                                 float *hs_mem = nullptr) {
+                                                 float *hs_mem = nullptr, unsigned int *flags = nullptr, const bool clean = false) {
+    // clean (flags only): this centroid's members did not change -- its centroid and size stand as they are, nothing to publish
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float c0 = res[0], c1 = res[1], c2 = res[2], h = res[3];
     if constexpr (!W) {
@@ -1504,6 +1513,7 @@ __device__ __forceinline__ void km_update_finish(const int kidx, const int k, co
         h = cnt < (size_t)16777216 ? (float)cnt : 16777216.0f;
     }
     if (threadIdx.x == 0) {
+        if (!clean) {
         if (h != 0.f) { const float norm = 1 / h; c0 *= norm; c1 *= norm; c2 *= norm; }
         // publish with write-through (sc1) stores + drained counter: no per-wave L2 write-back fence
         // (256 release fences, each flushing the XCD's dirty lines, cost more than the chains themselves)
@@ -1511,30 +1521,59 @@ __device__ __forceinline__ void km_update_finish(const int kidx, const int k, co
         __hip_atomic_store(&cent[3 * kidx + 1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&cent[3 * kidx + 2], c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&hassign[kidx], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // its record of the next assignment's table too (read by the NEXT kernel): the last block rebuilds the table only after
+        // split_clusters has changed centroids -- before, one wavefront re-read all k centroids in the tail of every launch
+        km_store_c4(c4, k, kidx, c0, c1, c2);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_last = (tk == (unsigned)k - 1u) ? 1 : 0;
     }
     __syncthreads();
     if (!*s_last || wid != 0) return;                                     // terminated wavefronts do not count at later barriers
-    // last block: every centroid was published with sc1 stores; read them back with sc1 (L1-bypassing) loads
-    bool mine_empty = false;
-    for (int ci = lane; ci < k; ci += 64)
-        if (__hip_atomic_load(&hassign[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.f) mine_empty = true;
+    // last block: every centroid was published with sc1 stores; read the sizes back with sc1 (L1-bypassing) loads, and with
+    // them the dirty flags (every block read its own before it took its ticket): all requests of a batch go out before the
+    // first answer is looked at
+    bool mine_empty = false, mine_dirty = false;
+    for (int cb = 0; cb < k; cb += 256) {
+        float hv[4]; unsigned fv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ci = cb + 64 * q + lane;
+            hv[q] = 1.f; fv[q] = 0u;
+            if (ci < k) {
+                hv[q] = __hip_atomic_load(&hassign[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (flags) fv[q] = __hip_atomic_load(&flags[1 + ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ci = cb + 64 * q + lane;
+            mine_empty = mine_empty || hv[q] == 0.f;
+            mine_dirty = mine_dirty || fv[q] != 0u;
+            if (flags && ci < k) __hip_atomic_store(&flags[1 + ci], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cleared for the next assignment
+        }
+    }
     const bool any = __ballot(mine_empty) != 0ULL;
     if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next iteration's launch
-    if (any) {                                                            // wave-uniform
+    if (flags) {
+        // no sample moved and no cluster is empty: the centroids are a fixed point of the iteration
+        const bool any_dirty = __ballot(mine_dirty) != 0ULL;
+        if (!any_dirty && !any && lane == 0) __hip_atomic_store(&flags[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!any) return;                                                     // wave-uniform
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the cleared flags are out before split_clusters raises its own
         __shared__ unsigned s_mt[624];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // the split code uses plain accesses
         if constexpr (HS > 0) {
             __shared__ float s_hs[HS];
-            km_split_clusters_wave<false>(cent, hassign, k, nx, mt, s_mt, s_hs, lane);
+            km_split_clusters_wave<false>(cent, hassign, k, nx, mt, s_mt, s_hs, lane, flags);
         } else km_split_clusters_wave<true>(cent, hassign, k, nx, mt, s_mt, hs_mem, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
-    for (int j = lane; j < k; j += 64) {
+    for (int j = lane; j < k; j += 64) {                                  // split_clusters moved centroids: the whole table again
         const float v0 = __hip_atomic_load(&cent[3 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float v1 = __hip_atomic_load(&cent[3 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float v2 = __hip_atomic_load(&cent[3 * j + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1641,30 +1680,213 @@ __device__ __forceinline__ int km_assign_one_pk(const float x0, const float x1, 
     return (int)cur_i;
 }
 
-// Full scan + the block-local stable counting sort: sixteen wavefronts, wavefront w = the block's w-th run of 64 consecutive
-// samples.  sorted_rec[block][.] = the block's samples themselves (x, y, z, w) grouped by centroid, sample order kept inside a
-// group (16 KB per block, so the update reads a centroid's members of a block as one run instead of chasing sample numbers);
-// offs[block][j] = where centroid j's group starts (offs[block][256] = the number of samples of the block).
-__global__ __launch_bounds__(1024) void k_km_assign_sort(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, const bool weighted,
-                                                         float4 *__restrict__ sorted_rec, unsigned short *__restrict__ offs) {
+// The same top-1 with HALF the instructions (the scan is what k_km_assign_sort spends its time on: sixteen wavefronts per CU at
+// ~1600 VALU instructions each, four cycles per instruction on a 16-lane SIMD = 13 us of an 18 us launch).  The reference's
+// result is a function of the eight lane trackers' MINIMA only, so pass 1 keeps nothing but the minima -- v_min3_f32 folds the
+// two candidates a tracker meets in sixteen centroids into it in one instruction: 2.5 instructions per centroid instead of
+// 6.25 -- and remembers, per tracker, the last QUARTER of the table in which its minimum went down (compare + select per
+// tracker and quarter).  The merge of the trackers needs an index only from the tracker(s) that attain the smallest clamped
+// distance -- one, unless two trackers tie bit for bit -- and that index is the FIRST entry of the remembered quarter whose
+// value equals the minimum (strict '<' kept the first): pass 2 re-evaluates that tracker's entries of that quarter (8 of 256)
+// with the same four operations, from a copy of the table in LDS (per-lane addresses).  Bit-identical to km_assign_one.
+__device__ __forceinline__ float km_min3(const float a, const float b, const float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// NS samples per lane share every scalar load of the table.  What the scan waits for besides its arithmetic is the scalar cache:
+// scalar loads return out of order, so a wavefront waits for ALL it has issued before it computes (no overlap inside a
+// wavefront), and a round trip of eight 32-byte loads cost ~1000 cycles with sixteen wavefronts per CU asking.  The table unit of
+// sixteen centroids is therefore fetched as four 64-byte loads: 19 300 -> 15 100 cycles for the scan (s_memtime inside the kernel,
+// tools/diag/km_trace.py), of which 16 x 640 are the SIMD's own issue time.
+template <int NS>
+__device__ __forceinline__ void km_assign_min3(const float (&x0)[NS], const float (&x1)[NS], const float (&x2)[NS], const scalar_c4_t c4,
+                                               const scalar_c8_t c8, const float4 *c4s, const int k, int (&out)[NS]) {
+    f2_t m0[NS], m1[NS], m2[NS];
+    float xn[NS], ld[NS][8]; int lc[NS][8];
+#pragma unroll
+    for (int e = 0; e < NS; e++) {
+        m0[e] = f2_t{-2 * x0[e], -2 * x0[e]}; m1[e] = f2_t{-2 * x1[e], -2 * x1[e]}; m2[e] = f2_t{-2 * x2[e], -2 * x2[e]};
+        xn[e] = __builtin_fmaf(x2[e], x2[e], __builtin_fmaf(x0[e], x0[e], x1[e] * x1[e]));
+#pragma unroll
+        for (int l = 0; l < 8; l++) { ld[e][l] = 3.402823466e+38F - xn[e]; lc[e][l] = -1; }
+    }
+    const int ny_p = (k / 8) * 8;
+    const int U = ny_p >> 4;                                  // units of sixteen centroids; a trailing group of eight is "quarter" 4
+    const int CUN = (U + 3) >> 2;                             // units per quarter
+    auto pair_dp = [&](const f8_t y, const int e) {
+        const f2_t y0 = {y[0], y[1]}, y1 = {y[2], y[3]}, y2 = {y[4], y[5]}, yw = {y[6], y[7]};
+        f2_t dp = m0[e] * y0;
+        dp = __builtin_elementwise_fma(m1[e], y1, dp);
+        dp = __builtin_elementwise_fma(m2[e], y2, dp);
+        return dp + yw;
+    };
+    for (int c = 0; c < 4; c++) {
+        const int u0 = c * CUN, u1 = u0 + CUN < U ? u0 + CUN : U;
+        if (u0 >= u1) break;                                  // wave-uniform
+        float snap[NS][8];
+#pragma unroll
+        for (int e = 0; e < NS; e++)
+#pragma unroll
+            for (int l = 0; l < 8; l++) snap[e][l] = ld[e][l];
+        for (int u = u0; u < u1; u++) {
+            const int p0 = u << 3;                            // pair index of centroid 16 u
+            // the unit's 256 bytes as four 64-byte scalar loads (a scalar load is a round trip the wavefront cannot overlap with
+            // its own arithmetic -- they return out of order, so it waits for all of them: fewer, wider requests)
+            typedef float f16_t __attribute__((ext_vector_type(16)));
+            typedef const __attribute__((address_space(4))) f16_t *scalar_c16_t;
+            const scalar_c16_t c16 = (scalar_c16_t)c8;
+            const f16_t q0 = c16[p0 >> 1], q1 = c16[(p0 >> 1) + 1], q2 = c16[(p0 >> 1) + 2], q3 = c16[(p0 >> 1) + 3];
+            auto half = [](const f16_t q, const int h) { return h ? f8_t{q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15]} : f8_t{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]}; };
+#pragma unroll
+            for (int l = 0; l < 8; l += 2) {
+                const f8_t ya = half(l < 4 ? q0 : q1, (l >> 1) & 1), yb = half(l < 4 ? q2 : q3, (l >> 1) & 1);
+#pragma unroll
+                for (int e = 0; e < NS; e++) {
+                    const f2_t a = pair_dp(ya, e), b = pair_dp(yb, e);
+                    ld[e][l] = km_min3(ld[e][l], a[0], b[0]);
+                    ld[e][l + 1] = km_min3(ld[e][l + 1], a[1], b[1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NS; e++)
+#pragma unroll
+            for (int l = 0; l < 8; l++) lc[e][l] = ld[e][l] < snap[e][l] ? c : lc[e][l];
+    }
+    if (ny_p & 8) {                                           // the trailing group of eight
+        const int p0 = U << 3;
+#pragma unroll
+        for (int l = 0; l < 8; l += 2) {
+            const f8_t ya = c8[p0 + (l >> 1)];
+#pragma unroll
+            for (int e = 0; e < NS; e++) {
+                const f2_t a = pair_dp(ya, e);
+                if (a[0] < ld[e][l]) { ld[e][l] = a[0]; lc[e][l] = 4; }
+                if (a[1] < ld[e][l + 1]) { ld[e][l + 1] = a[1]; lc[e][l + 1] = 4; }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NS; e++) {
+        // merge of the lane trackers (simdlib_based.cpp:178-199): smallest clamped distance, smallest index among those attaining it
+        float cand[8];
+        float cur_d = 3.402823466e+38F;
+#pragma unroll
+        for (int l = 0; l < 8; l++) { float cd = ld[e][l] + xn[e]; if (cd < 0) cd = 0; cand[l] = cd; cur_d = cd < cur_d ? cd : cur_d; }
+        unsigned tm = 0u;
+#pragma unroll
+        for (int l = 0; l < 8; l++) tm |= cand[l] == cur_d ? (1u << l) : 0u;
+        unsigned cur_i = 0xFFFFFFFFu;
+        while (__any(tm != 0u)) {                             // one trip unless a lane has two trackers tied
+            if (tm) {
+                const int l = __ffs((int)tm) - 1;
+                tm &= tm - 1u;
+                float target = ld[e][0]; int c = lc[e][0];
+#pragma unroll
+                for (int q = 1; q < 8; q++) { target = l == q ? ld[e][q] : target; c = l == q ? lc[e][q] : c; }
+                unsigned idx = 0u;                            // a tracker that never went down holds index 0 (lb = -l)
+                if (c == 4) idx = (unsigned)((U << 4) + l);
+                else if (c >= 0) {
+                    const int u0 = c * CUN, u1 = u0 + CUN < U ? u0 + CUN : U;
+                    const int base = (u0 << 4) + l, lim = u1 << 4;
+                    for (int q = 2 * CUN - 1; q >= 0; q--) {  // descending: the first entry that attains the minimum wins
+                        const int j = base + 8 * q;
+                        if (j < lim) {
+                            const float4 y = c4s[j];
+                            float dp = (-2 * x0[e]) * y.x;
+                            dp = __builtin_fmaf(-2 * x1[e], y.y, dp);
+                            dp = __builtin_fmaf(-2 * x2[e], y.z, dp);
+                            dp = dp + y.w;
+                            if (dp == target) idx = (unsigned)j;
+                        }
+                    }
+                }
+                cur_i = idx < cur_i ? idx : cur_i;
+            }
+        }
+        for (int j0 = ny_p; j0 < k; j0++) {                   // simdlib_based.cpp:201-216
+            const auto y = c4[j0];
+            float dp = __builtin_fmaf(x2[e], y.z, __builtin_fmaf(x1[e], y.y, x0[e] * y.x));
+            float d = xn[e] + y.w - 2 * dp;
+            if (d < 0) d = 0;
+            if (cur_d > d) { cur_d = d; cur_i = (unsigned)j0; }
+        }
+        out[e] = cur_i < (unsigned)k ? (int)cur_i : 0;
+    }
+}
+
+#ifdef PAMD_KM_TRACE
+// diagnostic build only (make TRACE=1): per-block phase timestamps of the two kernels of the default KMeans iteration
+__device__ unsigned long long g_km_trace[2][256][32];
+#define KM_TRACE(kern, slot) do { if ((threadIdx.x & 63) == 0) g_km_trace[kern][blockIdx.x & 255][slot] = wall_clock64(); } while (0)
+#define KM_TRACE0(kern, slot) do { if (threadIdx.x == 0) g_km_trace[kern][blockIdx.x & 255][slot] = wall_clock64(); } while (0)
+#else
+#define KM_TRACE(kern, slot) do { } while (0)
+#define KM_TRACE0(kern, slot) do { } while (0)
+#endif
+
+// NS = samples per lane: 1 = sixteen wavefronts and the packed full scan (km_assign_one_pk, the round-3 form); 2 = eight wavefronts,
+// each taking two of the sixteen runs, with the min3 scan
+template <int NS>
+__global__ __launch_bounds__(1024 / NS) void k_km_assign_sort(KmSamples s, size_t nx, const float4 *__restrict__ c4, int k, const bool weighted,
+                                                              float4 *__restrict__ sorted_rec, unsigned short *__restrict__ offs,
+                                                              unsigned char *__restrict__ prev, unsigned int *flags, const bool min3) {
+    if (flags[0]) return;                                              // fixed point reached (k_km_prep's comment): nothing changes any more
     __shared__ unsigned char cnt[16][256];                             // members of (step, centroid): 64 at most
     __shared__ unsigned short stepbase[16][256];                       // start of centroid j's group + its members in earlier steps
     __shared__ unsigned int wsum[16];
-    const int lane = threadIdx.x & 63, step = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 16 * 256 / 4; i += 1024) reinterpret_cast<unsigned int *>(&cnt[0][0])[i] = 0u;
+    __shared__ float4 c4s[256];                                        // the centroid records once more, for per-lane reads (km_assign_min3)
+    constexpr int NT = 1024 / NS;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    KM_TRACE0(0, 0);
+    for (int i = threadIdx.x; i < 16 * 256 / 4; i += NT) reinterpret_cast<unsigned int *>(&cnt[0][0])[i] = 0u;
+    if ((int)threadIdx.x < k) c4s[threadIdx.x] = c4[threadIdx.x];
     __syncthreads();
+    KM_TRACE0(0, 1);
     const scalar_c4_t t4 = (scalar_c4_t)(unsigned long long)c4;
     const scalar_c8_t t8 = (scalar_c8_t)(unsigned long long)(c4 + k);
     const size_t blk0 = (size_t)blockIdx.x * kKmSortBlock;
-    const size_t i = blk0 + (size_t)threadIdx.x;
-    const bool v = i < nx;
-    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v) { rec.x = s.x[i]; rec.y = s.y[i]; rec.z = s.z[i]; if (weighted) rec.w = s.w[i]; }
-    const int a = v ? km_assign_one_pk(rec.x, rec.y, rec.z, t4, t8, k) : 0;
-    const unsigned long long m = match_mask(a, 8, __ballot(v));
-    const unsigned rk = (unsigned)__popcll(m & ((1ULL << lane) - 1ULL)); // rank among the step's samples of the same centroid
-    if (v && rk == 0u) cnt[step][a] = (unsigned char)__popcll(m);      // group leader
+    size_t i[NS]; bool v[NS]; float4 rec[NS]; int step[NS];
+#pragma unroll
+    for (int e = 0; e < NS; e++) {
+        step[e] = wv * NS + e;                                         // the block's run of 64 consecutive samples this lane's e-th sample is in
+        i[e] = blk0 + (size_t)step[e] * 64 + lane;
+        v[e] = i[e] < nx;
+        rec[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v[e]) { rec[e].x = s.x[i[e]]; rec[e].y = s.y[i[e]]; rec[e].z = s.z[i[e]]; if (weighted) rec[e].w = s.w[i[e]]; }
+    }
+#ifdef PAMD_KM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KM_TRACE0(0, 2);
+    if (threadIdx.x == 0) g_km_trace[0][blockIdx.x & 255][24] = clock64();
+#endif
+    int a[NS];
+    if (NS == 1 && !min3) a[0] = v[0] ? km_assign_one_pk(rec[0].x, rec[0].y, rec[0].z, t4, t8, k) : 0;
+    else {
+        float x0[NS], x1[NS], x2[NS];
+#pragma unroll
+        for (int e = 0; e < NS; e++) { x0[e] = rec[e].x; x1[e] = rec[e].y; x2[e] = rec[e].z; }
+        km_assign_min3<NS>(x0, x1, x2, t4, t8, c4s, k, a);
+    }
+    unsigned rk[NS];
+#pragma unroll
+    for (int e = 0; e < NS; e++) {
+        if (!v[e]) a[e] = 0;
+        if (v[e]) {                                                    // a sample that changed sides marks both centroids dirty
+            const int old = prev[i[e]];
+            if (old != a[e]) { prev[i[e]] = (unsigned char)a[e]; flags[1 + old] = 1u; flags[1 + a[e]] = 1u; }
+        }
+        const unsigned long long m = match_mask(a[e], 8, __ballot(v[e]));
+        rk[e] = (unsigned)__popcll(m & ((1ULL << lane) - 1ULL));       // rank among the step's samples of the same centroid
+        if (v[e] && rk[e] == 0u) cnt[step[e]][a[e]] = (unsigned char)__popcll(m);   // group leader
+    }
+#ifdef PAMD_KM_TRACE
+    if (lane == 0) g_km_trace[0][blockIdx.x & 255][8 + wv] = wall_clock64();
+    if (threadIdx.x == 0) g_km_trace[0][blockIdx.x & 255][25] = clock64();
+#endif
     __syncthreads();
+    KM_TRACE0(0, 3);
     // thread j < 256: centroid j's counts over the sixteen steps -> exclusive prefix; then the groups' starts by a block scan
     unsigned tot = 0;
     unsigned short pre[16];
@@ -1682,13 +1904,21 @@ __global__ __launch_bounds__(1024) void k_km_assign_sort(KmSamples s, size_t nx,
         if (threadIdx.x == 255) ob[256] = (unsigned short)total;
     }
     __syncthreads();
-    if (v) sorted_rec[blk0 + (unsigned)stepbase[step][a] + rk] = rec;      // the sample itself: the update reads its members in runs
+    KM_TRACE0(0, 4);
+#pragma unroll
+    for (int e = 0; e < NS; e++)
+        if (v[e]) sorted_rec[blk0 + (unsigned)stepbase[step[e]][a[e]] + rk[e]] = rec[e];   // the sample itself: the update reads its members in runs
+#ifdef PAMD_KM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KM_TRACE0(0, 5);
+#endif
 }
 
 template <bool W>
 __global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restrict__ sorted_rec, const unsigned short *__restrict__ offs,
                                                         unsigned long long nx, int k, float *cent, float *hassign, float4 *c4,
-                                                        unsigned int *ticket, DevMT *mt) {
+                                                        unsigned int *ticket, DevMT *mt, unsigned int *flags) {
+    if (flags[0]) return;                                                 // fixed point reached: the centroids stand
     __shared__ float4 stage[4][2][64];
     extern __shared__ __attribute__((aligned(16))) float members[];       // [4][kKmDirectCap]: the listed members in sample order, one array per component
     __shared__ float res[4];
@@ -1701,6 +1931,7 @@ __global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restric
     float acc = 0.f;
     size_t total = 0;
     unsigned fill = 0;                                                    // block-uniform
+    KM_TRACE0(1, 0);
     bool long_list = false;                                               // a full piece has gone by: this centroid holds thousands of samples
     auto replay = [&]() {                                                 // the chains over the fill listed members, continuing `acc`
         const unsigned n = fill;
@@ -1720,7 +1951,8 @@ __global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restric
         else if (wid == 2) acc = km_chain_over<W, 2>(rec, n, stage[2], lane, acc);
         else if (W) acc = km_chain_over<W, 3>(rec, n, stage[3], lane, acc);
     };
-    const unsigned long long nblocks = (nx + kKmSortBlock - 1) / kKmSortBlock;
+    const bool clean = flags[1 + kidx] == 0u;                             // block-uniform; read before this block takes its ticket
+    const unsigned long long nblocks = clean ? 0ULL : (nx + kKmSortBlock - 1) / kKmSortBlock;
     for (unsigned long long c0 = 0; c0 < nblocks; c0 += 256) {            // 256 blocks of samples at a time: one per thread
         const unsigned long long b = c0 + threadIdx.x;
         unsigned o0 = 0, nb = 0;
@@ -1777,10 +2009,16 @@ __global__ __launch_bounds__(256) void k_km_update_lists(const float4 *__restric
         total += chunk_total;
     }
     __syncthreads();
+    KM_TRACE0(1, 1);
     replay();
+#ifdef PAMD_KM_TRACE
+    if (lane == 0) g_km_trace[1][blockIdx.x & 255][8 + wid] = wall_clock64();
+#endif
     if (lane == 0) res[wid] = acc;
     __syncthreads();
-    km_update_finish<W, 256>(kidx, k, nx, total, res, &s_last, cent, hassign, c4, ticket, mt);            // this path runs for k <= 256 only
+    KM_TRACE0(1, 2);
+    km_update_finish<W, 256>(kidx, k, nx, total, res, &s_last, cent, hassign, c4, ticket, mt, nullptr, flags, clean);   // this path runs for k <= 256 only
+    KM_TRACE0(1, 3);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1883,6 +2121,7 @@ void KMeansWork::reserve(size_t nx, int k) {
     perm.reserve(nx);
     if (!mt.p) { mt.reserve(1); mt_seeded = false; }
     if (!ticket.p) { ticket.reserve(1); HIP_CHECK(hipMemset(ticket.p, 0, sizeof(unsigned int))); }
+    flags.reserve(2 + 256);
 }
 
 void kmeans_gather(const double *d_planar, size_t N, bool weighted, const int *d_perm, size_t nx, KMeansWork &w, hipStream_t s) {
@@ -1969,7 +2208,7 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
         HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
     }
     if (!w.mt_seeded) { hipLaunchKernelGGL(k_km_mt_seed, 1, 1, 0, s, w.mt.p); w.mt_seeded = true; }   // the start of std::mt19937(1234), kept
-    { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (k + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p); }
+    { KTIME("k_km_prep", s, 28.0 * k); hipLaunchKernelGGL(k_km_prep, (std::max(k, kKmFlagWords) + 255) / 256, 256, 0, s, w.cent.p, k, w.c4.p, w.flags.p); }
     // many samples: exact candidate pruning (the grid is rebuilt per iteration, ~0.1 ms, against ~1 ms of full scans per
     // 16 M samples); few samples (the default 512^2): the full scan is cheaper than building the grid
     const size_t lut_min = getenv("PAMD_KM_LUT_MIN") ? (size_t)atoll(getenv("PAMD_KM_LUT_MIN")) : ((size_t)1 << 21);
@@ -2012,14 +2251,19 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             const int sblocks = (int)ceil_div(nx, (size_t)kKmSortBlock);
             {
                 KTIME("k_km_assign", s, (weighted ? 32.0 : 28.0) * nx);
-                hipLaunchKernelGGL(k_km_assign_sort, sblocks, 1024, 0, s, ks, nx, w.c4.p, k, weighted, w.sorted.p, offs);
+                // 1 (default): sixteen wavefronts, one sample per lane, min3 scan; 2: eight wavefronts with two samples per lane (measured
+                // slower: 23 000 against 15 100 cycles for the scan -- a wavefront waits for its scalar loads, and with half the
+                // wavefronts per SIMD fewer of those waits overlap); 3: the round-3 scan (km_assign_one_pk: 23 500 cycles)
+                static const int per_lane = getenv("PAMD_KM_SCAN") ? atoi(getenv("PAMD_KM_SCAN")) : 1;
+                if (per_lane == 2) hipLaunchKernelGGL(k_km_assign_sort<2>, sblocks, 512, 0, s, ks, nx, w.c4.p, k, weighted, w.sorted.p, offs, (unsigned char *)w.assign.p, w.flags.p, true);
+                else hipLaunchKernelGGL(k_km_assign_sort<1>, sblocks, 1024, 0, s, ks, nx, w.c4.p, k, weighted, w.sorted.p, offs, (unsigned char *)w.assign.p, w.flags.p, per_lane == 1);
             }
             {
                 KTIME("k_km_update", s, 16.0 * nx);
                 if (weighted) hipLaunchKernelGGL(k_km_update_lists<true>, k, 256, kKmDirectCap * 20, s, (const float4 *)w.sorted.p, (const unsigned short *)offs,
-                                                 (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+                                                 (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, w.flags.p);
                 else hipLaunchKernelGGL(k_km_update_lists<false>, k, 256, kKmDirectCap * 20, s, (const float4 *)w.sorted.p, (const unsigned short *)offs,
-                                        (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p);
+                                        (unsigned long long)nx, k, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, w.flags.p);
             }
             continue;
         }
@@ -2116,3 +2360,9 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
 }
 
 }  // namespace pamd
+
+#ifdef PAMD_KM_TRACE
+extern "C" int patolette_amd_debug_km_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pamd::g_km_trace), sizeof(pamd::g_km_trace)) == hipSuccess ? 0 : -1;
+}
+#endif

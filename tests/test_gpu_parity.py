@@ -137,6 +137,28 @@ def test_kmeans_many_empty_clusters_every_iteration(gpu, ob, ncol, k, weighted, 
     assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32))
 
 
+@pytest.mark.parametrize("k,weighted,n,niter", [(12, False, 50000, 40), (64, True, 120000, 60), (256, False, 262144, 25), (9, True, 3000, 50)])
+def test_kmeans_fixed_point_and_clean_centroids(gpu, ob, k, weighted, n, niter):
+    """Tight, well separated blobs: after a few iterations no sample changes its centroid any more.  The list path then skips the
+    update of every centroid whose members did not change (its sequential sums would come out the same) and, once nothing moves
+    at all, the remaining iterations -- the oracle runs all of them; the centroids must agree bit for bit after `niter`, and also
+    after every smaller count on the way (1, 2, 3, 5, 8: iterations with some clean and some dirty centroids)."""
+    rng = np.random.default_rng(k)
+    centres = rng.random((k, 3)) * 0.8 + 0.1
+    pick = rng.integers(0, k, size=n)
+    pts = np.clip(centres[pick] + 0.004 * rng.standard_normal((n, 3)), 0.0, 1.0)
+    pts[: n // 7] = rng.random((n // 7, 3))                  # and a share of noise, so that some samples sit on cell borders for a while
+    flat = np.ascontiguousarray(pts.T).reshape(-1).copy()
+    w = ob.weights(n, 3) if weighted else None
+    cent0 = pts[rng.choice(n, size=k, replace=False)].copy()
+    for it in (1, 2, 3, 5, 8, niter):
+        want = ob.kmeans_refine(flat, w, n, cent0, it, n)
+        c = np.ascontiguousarray(cent0.T).reshape(-1).copy()
+        assert gpu.patolette_amd_kmeans_refine(_d(flat), _d(w), n, _d(c), k, it, n) == 0
+        got = c.reshape(3, k).T
+        assert np.array_equal(got.astype(np.float32).view(np.uint32), want.astype(np.float32).view(np.uint32)), it
+
+
 @pytest.mark.parametrize("k,weighted,n,ncol", [(5000, False, 300000, 0), (4100, True, 70000, 0), (6000, False, 90000, 900), (5000, True, 40000, 0)])
 def test_kmeans_palettes_beyond_4096(gpu, ob, k, weighted, n, ncol):
     """The reference refines any palette size (refine.c:77-89, Clustering.cpp:267-554); beyond 4096 entries the stable sort's counters
