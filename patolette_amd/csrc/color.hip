@@ -19,7 +19,9 @@ namespace pamd {
 // sumk.M0 != 0: also accumulate the column sums of the output (order-independent binned parts; the bound behind sumk
 // is a property of the colour space, so it is known before the pass)
 template <int WHICH, class SRC>
-__global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ dst, size_t n, ConvertStats *stats, BinK sumk, BinK momk) {
+__global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ dst, size_t n, ConvertStats *stats, BinK sumk, BinK momk,
+                                                 size_t begin, size_t end) {
+    // pixels [begin, end) of the n-pixel image (n = plane stride): the host entry converts an image chunk by chunk behind its upload
     // per-plane min / max of the OUTPUT (bounds for the binned accumulators downstream)
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -53,15 +55,15 @@ __global__ __launch_bounds__(256) void k_convert(SRC src, double *__restrict__ d
     };
     // the pow chains are VALU work (nine pow per pixel for ICtCp) during which nothing was in flight: the NEXT pixel's
     // components are requested before this pixel's chain starts
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double nxt[3] = {0, 0, 0};
     unsigned nr = 0, ng = 0, nb = 0;
-    if (i < n) { if constexpr (kLut) src.load_bytes(i, nr, ng, nb); else src.load(i, nxt); }
-    for (; i < n; i += stride) {
+    if (i < end) { if constexpr (kLut) src.load_bytes(i, nr, ng, nb); else src.load(i, nxt); }
+    for (; i < end; i += stride) {
         double c[3];
         if constexpr (kLut) { c[0] = glut[nr]; c[1] = glut[ng]; c[2] = glut[nb]; }
         else { c[0] = nxt[0]; c[1] = nxt[1]; c[2] = nxt[2]; }
-        if (i + stride < n) { if constexpr (kLut) src.load_bytes(i + stride, nr, ng, nb); else src.load(i + stride, nxt); }
+        if (i + stride < end) { if constexpr (kLut) src.load_bytes(i + stride, nr, ng, nb); else src.load(i + stride, nxt); }
         if constexpr (kLut) dev_convert_linear<WHICH>(c); else dev_convert<WHICH>(c);
         finish(i, c);
     }
@@ -141,34 +143,39 @@ static int stream_grid(size_t n) {
     return (int)b;
 }
 
-void launch_convert(int which, const double *src_p, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk, BinK momk) {
-    if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
-    int g = stream_grid(n);
-    KTIME("k_convert", s, 48.0 * n);
+// begin / end: the pixels to convert (the whole image by default); init_stats: clear the statistics first (the first chunk)
+void launch_convert(int which, const double *src_p, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk, BinK momk,
+                    size_t begin, size_t end, bool init_stats) {
+    if (end > n) end = n;
+    if (stats && init_stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
+    int g = stream_grid(end - begin);
+    KTIME("k_convert", s, 48.0 * (end - begin));
     const SrcF64 src{src_p, n};
     switch (which) {
-        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_ICTCP_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_REC2020_TO_SRGB: hipLaunchKernelGGL((k_convert<PAMD_REC2020_TO_SRGB, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_CIELUV_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_ICTCP_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_REC2020, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_REC2020_TO_SRGB: hipLaunchKernelGGL((k_convert<PAMD_REC2020_TO_SRGB, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_CIELUV_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_CIELUV_TO_ICTCP, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
         default: throw HipError("patolette_amd: unknown conversion");
     }
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk, BinK momk) {
-    if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
-    int g = stream_grid(n);
-    KTIME("k_convert", s, 48.0 * n);
+void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk, BinK momk,
+                         size_t begin, size_t end, bool init_stats) {
+    if (end > n) end = n;
+    if (stats && init_stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
+    int g = stream_grid(end - begin);
+    KTIME("k_convert", s, 48.0 * (end - begin));
     const SrcF64Rows src{rows};
     switch (which) {
-        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcF64Rows>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
         default: throw HipError("patolette_amd: unknown conversion");
     }
     HIP_CHECK(hipGetLastError());
@@ -178,12 +185,13 @@ void launch_convert_u8(int which, const unsigned char *pixels, int channels, dou
                        hipStream_t s, BinK sumk, BinK momk) {
     if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
     int g = stream_grid(n);
+    const size_t begin = 0, end = n;
     KTIME("k_convert_u8", s, (24.0 + channels) * n);
     const SrcU8 src{pixels, channels};
     switch (which) {
-        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
-        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk); break;
+        case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_SRGB_TO_CIELUV: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_CIELUV, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
+        case PAMD_COPY: hipLaunchKernelGGL((k_convert<PAMD_COPY, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;
         default: throw HipError("patolette_amd: unknown conversion");
     }
     HIP_CHECK(hipGetLastError());

@@ -28,9 +28,10 @@ namespace pamd {
 
 // launchers defined in color.hip
 void launch_convert(int which, const double *src, double *dst, size_t n, ConvertStats *stats, hipStream_t s, BinK sumk = BinK{0.0, 0.0},
-                    BinK momk = BinK{0.0, 0.0});
+                    BinK momk = BinK{0.0, 0.0}, size_t begin = 0, size_t end = ~(size_t)0, bool init_stats = true);
 void launch_convert_rows(int which, const double *rows, double *dst, size_t n, ConvertStats *stats, hipStream_t s,
-                         BinK sumk = BinK{0.0, 0.0}, BinK momk = BinK{0.0, 0.0});
+                         BinK sumk = BinK{0.0, 0.0}, BinK momk = BinK{0.0, 0.0}, size_t begin = 0, size_t end = ~(size_t)0,
+                         bool init_stats = true);
 void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
                        hipStream_t s, BinK sumk = BinK{0.0, 0.0}, BinK momk = BinK{0.0, 0.0});
 void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned char *pal_u8, int k, unsigned char *out,
@@ -231,6 +232,8 @@ struct Engine {
     PinBuf<float> h_cent;            // KMeans centroids on their way to / from the device
     PinBuf<ConvertStats> h_cstats;
     hipEvent_t ev_stats = nullptr;
+    hipStream_t stream2 = nullptr;        // run_host: the conversion of chunk i runs here while chunk i + 1 is on its way up
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_join = nullptr;
     size_t prep_N = 0, prep_planes = 0;   // gq_prepare() has staged the root's tiles and cleared the tables for an image of this size
     DevBuf<double> src, wsrc, cvt, bufA, bufB, aux;
     DevBuf<unsigned short> bkt;
@@ -284,7 +287,10 @@ struct Engine {
     }
     void sync() { HIP_CHECK(hipStreamSynchronize(stream)); if (ktimer().enabled) ktimer().collect(); }
     ~Engine() {                                  // buffers free themselves (DevBuf / PinBuf); only called while the runtime is alive
-        if (stream) { (void)hipSetDevice(device); (void)hipStreamSynchronize(stream); if (ev_stats) (void)hipEventDestroy(ev_stats); (void)hipStreamDestroy(stream); }
+        if (stream) { (void)hipSetDevice(device); (void)hipStreamSynchronize(stream); if (ev_stats) (void)hipEventDestroy(ev_stats);
+                      for (hipEvent_t e : {ev_up[0], ev_up[1], ev_join}) if (e) (void)hipEventDestroy(e);
+                      if (stream2) (void)hipStreamDestroy(stream2);
+                      (void)hipStreamDestroy(stream); }
     }
 };
 
@@ -1129,7 +1135,29 @@ struct Pixels {                      // device-resident input image: planar f64 
     const unsigned char *u8 = nullptr;
     int channels = 3;
     bool rows = false;               // f64 as (N,3) row-major instead of planar
+    bool converted = false;          // E.cvt already holds the converted image and E.cstats its statistics (run_host: chunk by chunk behind the upload)
 };
+
+// What stage S1 launches: the conversion and the sums that ride with it (run_device; run_host when it converts behind the upload)
+struct ConvertPlan { int which; BinK sumk, momk; };
+static ConvertPlan convert_plan(const Engine &E, const patolette__QuantizationOptions *opt, size_t N) {
+    ConvertPlan p{PAMD_COPY, BinK{0.0, 0.0}, BinK{0.0, 0.0}};
+    if (opt->color_space == patolette__CIELuv) p.which = PAMD_SRGB_TO_CIELUV;
+    else if (opt->color_space == patolette__ICtCp) p.which = PAMD_SRGB_TO_ICTCP;
+    // the root mean of the global quantiser (matrix2D.c:229) rides along with the conversion where the colour space bounds
+    // the values a priori: |I| <= 1, |Ct|, |Cp| <= 0.5 (2^1); L <= 100, |u|, |v| < 256 (2^8).  sRGB passes user data through.
+    const size_t Nt = E.shard ? E.shard->total : N;            // a slice sums on the grids of the whole image
+    int rootP = 1; while ((1ULL << rootP) < (Nt > 1 ? Nt : 2)) rootP++;
+    if (p.which == PAMD_SRGB_TO_ICTCP) p.sumk = make_bink(1, rootP);
+    else if (p.which == PAMD_SRGB_TO_CIELUV) p.sumk = make_bink(8, rootP);
+    // one GPU: the raw second moments ride along too (products < 1, resp. < 2^16), and the root's covariance needs no sweep
+    static const bool mom_on = !(getenv("PAMD_ROOT_MOMENTS") && atoi(getenv("PAMD_ROOT_MOMENTS")) == 0);
+    if (!E.shard && mom_on) {
+        if (p.which == PAMD_SRGB_TO_ICTCP) p.momk = make_bink(1, rootP);
+        else if (p.which == PAMD_SRGB_TO_CIELUV) p.momk = make_bink(16, rootP);
+    }
+    return p;
+}
 
 static void run_device(Engine &E, size_t width, size_t height, Pixels px, const double *d_weights, size_t K,
                        const patolette__QuantizationOptions *opt, double *palette, void *d_map, int map_elem) {
@@ -1145,27 +1173,13 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     double t0 = now_ms();
     E.cvt.reserve((weighted ? 4 : 3) * N);
     E.cstats.reserve(1);
-    int which = PAMD_COPY;
-    if (opt->color_space == patolette__CIELuv) which = PAMD_SRGB_TO_CIELUV;
-    else if (opt->color_space == patolette__ICtCp) which = PAMD_SRGB_TO_ICTCP;
-    // the root mean of the global quantiser (matrix2D.c:229) rides along with the conversion where the colour space bounds
-    // the values a priori: |I| <= 1, |Ct|, |Cp| <= 0.5 (2^1); L <= 100, |u|, |v| < 256 (2^8).  sRGB passes user data through.
-    BinK sumk{0.0, 0.0}, momk{0.0, 0.0};
     if (E.shard && opt->dither && !opt->palette_only)
         throw HipError("patolette_amd: dithering is one serial chain over the whole image; it is not available per slice");
-    {
-        const size_t Nt = E.shard ? E.shard->total : N;        // a slice sums on the grids of the whole image
-        int rootP = 1; while ((1ULL << rootP) < (Nt > 1 ? Nt : 2)) rootP++;
-        if (which == PAMD_SRGB_TO_ICTCP) sumk = make_bink(1, rootP);
-        else if (which == PAMD_SRGB_TO_CIELUV) sumk = make_bink(8, rootP);
-        // one GPU: the raw second moments ride along too (products < 1, resp. < 2^16), and the root's covariance needs no sweep
-        static const bool mom_on = !(getenv("PAMD_ROOT_MOMENTS") && atoi(getenv("PAMD_ROOT_MOMENTS")) == 0);
-        if (!E.shard && mom_on) {
-            if (which == PAMD_SRGB_TO_ICTCP) momk = make_bink(1, rootP);
-            else if (which == PAMD_SRGB_TO_CIELUV) momk = make_bink(16, rootP);
-        }
-    }
-    if (px.u8) launch_convert_u8(which, px.u8, px.channels, E.cvt.p, N, E.cstats.p, s, sumk, momk);
+    const ConvertPlan cp = convert_plan(E, opt, N);
+    const int which = cp.which;
+    const BinK sumk = cp.sumk, momk = cp.momk;
+    if (px.converted) { /* run_host has converted the image chunk by chunk behind its upload */ }
+    else if (px.u8) launch_convert_u8(which, px.u8, px.channels, E.cvt.p, N, E.cstats.p, s, sumk, momk);
     else if (px.rows) launch_convert_rows(which, px.f64, E.cvt.p, N, E.cstats.p, s, sumk, momk);
     else launch_convert(which, px.f64, E.cvt.p, N, E.cstats.p, s, sumk, momk);
     if (weighted) {
@@ -1345,7 +1359,52 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     const size_t N = width * height;
     double t0 = now_ms();
     E.src.reserve(3 * N);
-    HIP_CHECK(hipMemcpyAsync(E.src.p, data, 3 * N * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    // Large images go up in pieces and what a piece completes is converted (on a second stream) while the next one is on the link:
+    // the conversion (0.5 ms of a 4096^2 image's 7 ms upload) disappears behind the copy.  Its statistics are exact sums and keyed
+    // extrema, so the chunking changes no bit.  Not with derived weights (the saliency stage reads the whole sRGB image first).
+    const size_t chunk_min = getenv("PAMD_UPLOAD_CHUNK_MIN") ? (size_t)atoll(getenv("PAMD_UPLOAD_CHUNK_MIN")) : ((size_t)1 << 21);   // (read per call: tests lower it)
+    const bool derive = !weights && tile_size > 0.0;
+    const bool chunked = N >= chunk_min && !E.shard;
+    bool converted = false;
+    if (chunked) {
+        const bool overlap = !derive;
+        // planar source: the first two planes go up whole (every copy call has a fixed cost: 24 pieces made the upload 0.44 ms
+        // longer than one), the third in four pieces with the conversion of the pixels it completes behind each; row-major
+        // source: four pieces of whole pixels
+        const size_t nch = 4, per = ((N + nch - 1) / nch + 255) & ~(size_t)255;
+        ConvertPlan cp{};
+        if (overlap) {
+            if (!E.stream2) {
+                HIP_CHECK(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
+                for (hipEvent_t *e : {&E.ev_up[0], &E.ev_up[1], &E.ev_join}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
+            cp = convert_plan(E, opt, N);
+            E.cvt.reserve((weights ? 4 : 3) * N);
+            E.cstats.reserve(1);
+            HIP_CHECK(hipEventRecord(E.ev_join, E.stream));          // whatever the engine's stream still holds comes first
+            HIP_CHECK(hipStreamWaitEvent(E.stream2, E.ev_join, 0));
+        }
+        if (!rows) HIP_CHECK(hipMemcpyAsync(E.src.p, data, 2 * N * sizeof(double), hipMemcpyHostToDevice, E.stream));
+        size_t c = 0;
+        for (size_t lo = 0; lo < N; lo += per, c++) {
+            const size_t cnt = std::min(per, N - lo);
+            if (rows) HIP_CHECK(hipMemcpyAsync(E.src.p + 3 * lo, data + 3 * lo, 3 * cnt * sizeof(double), hipMemcpyHostToDevice, E.stream));
+            else HIP_CHECK(hipMemcpyAsync(E.src.p + 2 * N + lo, data + 2 * N + lo, cnt * sizeof(double), hipMemcpyHostToDevice, E.stream));
+            if (overlap) {
+                HIP_CHECK(hipEventRecord(E.ev_up[c & 1], E.stream));
+                HIP_CHECK(hipStreamWaitEvent(E.stream2, E.ev_up[c & 1], 0));
+                if (rows) launch_convert_rows(cp.which, E.src.p, E.cvt.p, N, E.cstats.p, E.stream2, cp.sumk, cp.momk, lo, lo + cnt, c == 0);
+                else launch_convert(cp.which, E.src.p, E.cvt.p, N, E.cstats.p, E.stream2, cp.sumk, cp.momk, lo, lo + cnt, c == 0);
+            }
+        }
+        if (overlap) {
+            HIP_CHECK(hipEventRecord(E.ev_join, E.stream2));
+            HIP_CHECK(hipStreamWaitEvent(E.stream, E.ev_join, 0));
+            converted = true;
+        }
+    } else {
+        HIP_CHECK(hipMemcpyAsync(E.src.p, data, 3 * N * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    }
     if (weights) {
         E.wsrc.reserve(N);
         HIP_CHECK(hipMemcpyAsync(E.wsrc.p, weights, N * sizeof(double), hipMemcpyHostToDevice, E.stream));
@@ -1354,11 +1413,13 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     const double up = now_ms() - t0;
     const double *d_w = weights ? E.wsrc.p : nullptr;
     E.ms_saliency = 0.0;
-    if (!weights && tile_size > 0.0) d_w = derive_weights(E, E.src.p, nullptr, rows ? -3 : 3, width, height, tile_size);
+    if (derive) d_w = derive_weights(E, E.src.p, nullptr, rows ? -3 : 3, width, height, tile_size);
     const int me = map_elem_for(K);
     if (!opt->palette_only && !d_map_out) E.dmap.reserve(N * (size_t)me);
     std::vector<double> pal(3 * K);
-    run_device(E, width, height, Pixels{E.src.p, nullptr, 3, rows}, d_w, K, opt, pal.data(), d_map_out ? d_map_out : (void *)E.dmap.p, me);
+    Pixels px{E.src.p, nullptr, 3, rows};
+    px.converted = converted;
+    run_device(E, width, height, px, d_w, K, opt, pal.data(), d_map_out ? d_map_out : (void *)E.dmap.p, me);
     E.stats.ms_saliency = E.ms_saliency;
     E.stats.ms_total += E.ms_saliency;
     t0 = now_ms();

@@ -558,6 +558,27 @@ def test_row_major_and_planar_inputs_agree(gpu, ob, tile_size):
     assert c[1].shape == a[1].shape
 
 
+@pytest.mark.parametrize("rows_major,weighted,cs,n_side", [(False, False, 2, (300, 420)), (True, False, 1, (257, 391)), (False, True, 2, (128, 96)), (True, True, 0, (64, 33))])
+def test_chunked_upload_with_overlapped_conversion(gpu, ob, monkeypatch, rows_major, weighted, cs, n_side):
+    """The host entry uploads large images in eight chunks and converts each behind the next one's copy (second stream, the
+    statistics accumulated over the launches); forced here onto small images -- chunk boundaries not multiples of anything,
+    planar and row-major sources, explicit weights -- the result must be the oracle's as for the single-copy path."""
+    import patolette_amd as p
+    monkeypatch.setenv("PAMD_UPLOAD_CHUNK_MIN", "1000")
+    h, w = n_side
+    n = w * h
+    flat = ob.image(n, 61)
+    colors = ob.unplanar(flat, n)                            # C-contiguous (N,3): the row-major entry
+    if not rows_major:
+        colors = np.asfortranarray(colors)                   # planar: the drop-in layout
+    wts = ob.weights(n, 61) if weighted else None
+    ok, pal, pmap, msg = p.quantize(w, h, colors, 48, dither=False, color_space=cs, tile_size=0, kmeans_niter=2, kmeans_max_samples=65536, weights=wts)
+    ec, pal_o, pmap_o = ob.patolette(w, h, flat, wts, 48, dither=False, color_space=cs, kmeans_niter=2, kmeans_max_samples=65536)
+    assert ok and ec == 0, msg
+    assert np.allclose(pal, pal_o, rtol=0, atol=1e-9)
+    assert np.array_equal(pmap, pmap_o)
+
+
 def test_u8_adaptor_accepts_torch_cuda_tensor(gpu):
     """A torch CUDA uint8 tensor goes through the device entry point: same results as the numpy path, outputs stay in
     HBM.  Own process: torch has to load its HIP runtime before libpatolette_amd.so does (as bench.py --gpus N does)."""
