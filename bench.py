@@ -352,7 +352,7 @@ def main():
                     help="after the timed region rank 0 quantises every rank's images itself, one call per image, and compares the gathered "
                          "maps and palettes with them (reported as gather_check)")
     ap.add_argument("--streams", type=int, default=1, help="images quantised concurrently per GPU and step in the timed region")
-    ap.add_argument("--extra-streams", type=int, default=3,
+    ap.add_argument("--extra-streams", type=int, default=6,
                     help="after the timed region also measure throughput with this many concurrent images per GPU; reported "
                          "separately as throughput_concurrent, never as `value` (0 = skip)")
     ap.add_argument("--kmeans-update", type=int, default=0, choices=[0, 1],
@@ -418,7 +418,7 @@ def main():
     S2 = max(0, args.extra_streams)
     if dither and n > (1 << 24):
         S2 = 0                                  # the serial dither chain of a 67 MP image takes tens of seconds
-    pool = max(S, S2, min(3, args.steps))
+    pool = max(S, min(S2, 3), min(3, args.steps))        # distinct images; more in flight than that re-use them (read-only)
     d_imgs, d_wts = [], []
     for i in range(pool):
         if weighted == "saliency":
@@ -654,6 +654,7 @@ def main():
     # core of the box, the rest single-threaded as in the reference; single_thread = everything on one core.
     cpu = None
     parity = None
+    dither_cmp = None
     if not args.no_cpu_baseline and world == 1:
         from oracle import binding as ob
         ncores = os.cpu_count() or 1
@@ -686,6 +687,14 @@ def main():
             parity = {"note": "the CPU sample is smaller than the workload (or derives its own weights): no full-size comparison in this run; "
                               "see tests/test_gpu_parity.py"}
         scale = "the full %dx%d workload" % (sw, sh) if sn == n else "%dx%d of the same workload (the %dx%d image would take %.0fx as long)" % (sw, sh, width, height, n / sn)
+        if dither:
+            # the stage that is 99.8 % of this configuration, side by side: the GPU's one-wavefront chain against the oracle's
+            # chain on one host core.  The oracle searches the palette by brute force (exact, 256 f64 distances per pixel); the
+            # reference's FLANN kd-tree (nearest.c:115-148) is not in this image and would be faster on the CPU side.
+            dither_cmp = {"gpu_ns_per_px": round(1e6 * stats["ms_map"] / n, 2), "gpu_pixels": n,
+                          "cpu_ns_per_px_one_core": round(1e9 * st_one["map"] / sn, 2), "cpu_pixels": sn,
+                          "note": "GPU: ms_map of the last timed step / pixels (palette conversion + Riemersma chain); CPU: the oracle's map stage "
+                                  "(brute-force exact nearest colour, single thread, serial by construction) on a %dx%d crop-sized image" % (sw, sh)}
         cpu = {"value": round(sn / dt_all / 1e6, 4), "unit": "Mpx/s", "cores": ncores, "kind": "port",
                "sample": "oracle (plain-C restatement of the reference path; KMeans assign/update and the NN map on %d threads as faiss / FLANN "
                          "thread them, everything else single-threaded as in the reference) on %s, %.1f s; stages %s" % (ncores, scale, dt_all, st_all),
@@ -714,7 +723,7 @@ def main():
                                     "TEST MODE --oversubscribe: %d ranks on %d device(s), gloo gather through host copies -- the N > 1 code path, not a scaling figure" % (world, L.patolette_amd_device_count())
                                     if args.oversubscribe else
                                     "RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region")},
-        "first_call": cold, "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "content": content, "throughput_concurrent": conc,
+        "first_call": cold, "dither": dither_cmp, "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "content": content, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -108,7 +108,7 @@ void patolette_amd_u8_device(size_t width, size_t height, const unsigned char *d
 /* ---- batch of independent images (SURVEY.md 8(b) "Batch extension") -----------------------
  * count images of identical width x height; data[i] / weights[i] (weights may be NULL or hold
  * NULL entries) / tile_size / palettes[i] / palette_maps[i] / exit_codes[i] as for
- * patolette_amd_quantize(); up to three images are in flight on the current GPU.  Results are
+ * patolette_amd_quantize(); up to six images are in flight on the current GPU (fewer if the free HBM does not hold their workspaces).  Results are
  * identical to count separate calls. */
 void patolette_amd_batch(size_t count, size_t width, size_t height, const double *const *data,
                          const double *const *weights, double tile_size, size_t palette_size,

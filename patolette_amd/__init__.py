@@ -216,7 +216,7 @@ def _quantize_u8_torch(image, palette_size, dither, palette_only, color_space, t
 def quantize_batch(width, height, images, palette_size, weights=None, dither=True, palette_only=False,
                    color_space=ColorSpace_ICtCp, tile_size=512, kmeans_niter=32, kmeans_max_samples=512 ** 2, verbose=False):
     """Quantise a list of independent images of identical size on the current GPU through
-    `patolette_amd_batch` (up to three images in flight: uploads and host-side work of one image
+    `patolette_amd_batch` (up to six images in flight: uploads and host-side work of one image
     overlap kernels of another).  Per-image results are identical to separate `quantize` calls
     with the same arguments (SURVEY.md 8(b), batch extension).  `weights`: None or one entry (array or None) per image;
     images without explicit weights get the saliency-derived ones when tile_size > 0, as in `quantize`.
@@ -268,7 +268,7 @@ def quantize_batch(width, height, images, palette_size, weights=None, dither=Tru
 
 def quantize_u8_batch(images, palette_size, weights=None, dither=True, palette_only=False, color_space=ColorSpace_ICtCp,
                       tile_size=512, kmeans_niter=32, kmeans_max_samples=512 ** 2, want_quantized=True):
-    """`quantize_u8` for a list of (H, W, 3|4) uint8 images of identical shape through `patolette_amd_batch_u8`: up to three
+    """`quantize_u8` for a list of (H, W, 3|4) uint8 images of identical shape through `patolette_amd_batch_u8`: up to six
     images in flight on the current GPU, and 3 bytes per pixel over PCIe instead of 24, so a host-fed batch is bound by the
     kernels rather than by the upload.  Per-image results are identical to separate `quantize_u8` calls.
     Returns a list of `quantize_u8` tuples."""

@@ -439,6 +439,9 @@ __device__ __forceinline__ int nn_drain_one(const double x, const double y, cons
 // 1024 threads = 16 wavefronts per CU around the 128 KB table.  A wavefront streams its own tiles of 64 * P pixels: a lane takes
 // P / 2 pairs of CONSECUTIVE pixels (pair g = pixels 128 g + 2 lane, + 1): one 16-byte load per plane and pair, the next tile's
 // loads in flight while this one is evaluated, one packed store per pair.
+#ifdef PAMD_KM_TRACE
+__device__ unsigned long long g_nn_trace[256][2];          // diagnostic build: when each block of k_nn_map_mid started and ended
+#endif
 template <typename OutT, int P>
 __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ c, size_t N, size_t n, const double *__restrict__ pal, int k,
                                                      NNGrid g, const unsigned int *__restrict__ mid, const unsigned char *__restrict__ lut,
@@ -446,6 +449,9 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
     extern __shared__ unsigned char smem_mid[];
     constexpr int Gm = 32, ncell = Gm * Gm * Gm;                                  // g.G == 64
     static_assert(P % 2 == 0, "pairs of pixels");
+#ifdef PAMD_KM_TRACE
+    if (threadIdx.x == 0) g_nn_trace[blockIdx.x & 255][0] = wall_clock64();
+#endif
     unsigned int *T = (unsigned int *)smem_mid;                                  // [ncell]
     double *spx = (double *)(smem_mid + (size_t)ncell * 4), *spy = spx + 256, *spz = spy + 256;
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -577,6 +583,10 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
             } while (done < btot);
         }
     }
+#ifdef PAMD_KM_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0) g_nn_trace[blockIdx.x & 255][1] = wall_clock64();
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_minmax3(const double *__restrict__ c, size_t N, size_t n, unsigned long long *keys /* min[3], max[3] */) {
@@ -994,3 +1004,9 @@ void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_
 }
 
 }  // namespace pamd
+
+#ifdef PAMD_KM_TRACE
+extern "C" int patolette_amd_debug_nn_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pamd::g_nn_trace), sizeof(pamd::g_nn_trace)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1832,7 +1832,7 @@ void patolette_amd_u8_device(size_t width, size_t height, const unsigned char *d
              map_elem_bytes, d_quantized, exit_code);
 }
 
-// Independent images: up to three are in flight at once, each on its own engine (HIP stream + workspace) driven by
+// Independent images: up to six are in flight at once, each on its own engine (HIP stream + workspace) driven by
 // its own host thread, so the upload / host-side split-loop work of one image overlaps the kernels of another.
 // Engines are pooled per device and reused across calls.
 
@@ -1842,17 +1842,23 @@ static void batch_run(size_t count, size_t width, size_t height, const patolette
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) { for (size_t i = 0; i < count; i++) exit_codes[i] = -1; return; }
     if (engine().device >= 0) device = engine().device;
-    // Images in flight: three keep the GPU busy through one image's host round trips.  With the Riemersma dither each
-    // image ends in a serial chain that occupies ONE wavefront for seconds, so many more are kept in flight (one chain
-    // per CU runs concurrently), bounded by the free HBM: an engine's workspace is ~170 bytes per pixel.
-    size_t workers = std::min<size_t>(count, 3);
-    if (options->dither && !options->palette_only && count > 3) {
+    // Images in flight: six keep the GPU busy through the host round trips between an image's split rounds (device-resident
+    // 4096^2 images, one MI355X: 2960 Mpx/s one at a time, 3330 / 3410 / 3740 / 3990 / 3880 with 2 / 3 / 4 / 6 / 8 in flight).  With
+    // the Riemersma dither each image ends in a serial chain that occupies ONE wavefront for seconds, so many more are kept in
+    // flight (one chain per CU runs concurrently).  Both bounded by the free HBM: an engine's workspace is ~170 bytes per pixel.
+    const size_t base_flight = getenv("PAMD_BATCH_FLIGHT") ? std::max<size_t>(1, (size_t)atoll(getenv("PAMD_BATCH_FLIGHT"))) : 6;
+    size_t workers = std::min<size_t>(count, base_flight);
+    if (count > 1) {
         size_t free_b = 0, total_b = 0;
         (void)hipSetDevice(device);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t per_engine = (size_t)(170.0 * (double)width * (double)height) + ((size_t)64 << 20);
-            const size_t fit = free_b / 2 / per_engine;          // leave half of what is free alone
-            workers = std::min<size_t>(count, std::max<size_t>(3, std::min<size_t>(fit, 48)));
+            size_t idle = 0;                                     // pooled engines already hold their workspace
+            { std::lock_guard<std::mutex> lk(g_pool_mu); for (Engine *e : g_pool) if (e->device == device) idle++; }
+            const size_t fit = idle + free_b / 2 / per_engine;   // leave half of what is free alone
+            const bool chains = options->dither && !options->palette_only;
+            workers = std::min<size_t>(count, std::max<size_t>(1, std::min<size_t>(fit, chains ? 48 : base_flight)));
+            if (chains) workers = std::max(workers, std::min<size_t>(count, 3));
         }
     }
     std::atomic<size_t> next{0};
