@@ -558,6 +558,32 @@ def test_row_major_and_planar_inputs_agree(gpu, ob, tile_size):
     assert c[1].shape == a[1].shape
 
 
+def test_subsample_list_with_and_without_the_cache(gpu, native, ob):
+    """A subsampled KMeans refinement (400 x 300 pixels, 65 536 samples) with the device-side cache of the subsample list on
+    (default), off (every call makes the list again on the helper thread) and after a different image size has replaced the
+    cached list: always the oracle's palette and map."""
+    import patolette_amd as p
+    w, h, K = 400, 300, 32
+    n = w * h
+    flat = ob.image(n, 71)
+    colors = ob.unplanar(flat, n)
+    ec, pal_o, pmap_o = ob.patolette(w, h, flat, None, K, dither=False, color_space=2, kmeans_niter=3, kmeans_max_samples=65536)
+    small = ob.unplanar(ob.image(350 * 260, 72), 350 * 260)
+    L = native.lib()
+    prev = L.patolette_amd_set_subsample_cache(1)
+    try:
+        for cache, between in ((1, False), (1, False), (0, False), (0, False), (1, True), (0, True)):
+            L.patolette_amd_set_subsample_cache(cache)
+            if between:                                      # another size in between: the cached list belongs to other dimensions
+                assert p.quantize(350, 260, small, K, dither=False, tile_size=0, kmeans_niter=1, kmeans_max_samples=65536)[0]
+            ok, pal, pmap, msg = p.quantize(w, h, colors, K, dither=False, color_space=2, tile_size=0, kmeans_niter=3, kmeans_max_samples=65536)
+            assert ok and ec == 0, msg
+            assert np.allclose(pal, pal_o, rtol=0, atol=1e-9), (cache, between)
+            assert np.array_equal(pmap, pmap_o), (cache, between)
+    finally:
+        L.patolette_amd_set_subsample_cache(prev)
+
+
 @pytest.mark.parametrize("rows_major,weighted,cs,n_side", [(False, False, 2, (300, 420)), (True, False, 1, (257, 391)), (False, True, 2, (128, 96)), (True, True, 0, (64, 33))])
 def test_chunked_upload_with_overlapped_conversion(gpu, ob, monkeypatch, rows_major, weighted, cs, n_side):
     """The host entry uploads large images in eight chunks and converts each behind the next one's copy (second stream, the

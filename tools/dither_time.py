@@ -1,7 +1,10 @@
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 import patolette_amd as p
+import os
 from patolette_amd import _native
+if os.environ.get("PAMD_LIB_DIR"):                       # A/B of two builds in one gpurun call: patolette_amd/lib/<dir>/libpatolette_amd.so
+    _native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), os.environ["PAMD_LIB_DIR"], "libpatolette_amd.so")
 n = 2048
 rng = np.random.default_rng(3)
 colors = rng.random((n * n, 3))
