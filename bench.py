@@ -524,14 +524,14 @@ def main():
         _native.profile(False)
     # ---- what a FIRST call of an image size costs (the subsample list made again in every call), outside the timed region ----
     cold = None
-    if niter > 0 and S == 1:
+    if niter > 0 and S == 1 and args.steps > 0:
         prev = L.patolette_amd_set_subsample_cache(0)
         try:
             tt = []
             for i in range(min(6, max(3, args.steps))):
                 L.patolette_amd_synchronize()
                 tc = time.perf_counter()
-                run.step(args.warmup + i)
+                run.step(args.warmup + i % max(1, args.steps))         # (the result slots of the timed steps are reused)
                 L.patolette_amd_synchronize()
                 tt.append(time.perf_counter() - tc)
         finally:
