@@ -145,6 +145,18 @@ def north_star_kernels(L, native):
     tpath = os.path.join(ROOT, "profiles", "traffic_c4km.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("kernels", {})
+    # with exact candidate pruning these two kernels are HBM-bound, but not by much -- the VALU share is reported
+    # beside the HBM fraction: vector instructions per launch (SQ_INSTS_VALU of the kept rocprofv3 --pmc pass, profiles/) x 4 cycles
+    # per wave64 instruction on a 16-lane SIMD / (1024 SIMDs x the launch time measured here x the 2.4 GHz peak engine clock)
+    valu = {}
+    for tag in ("r04", "r03"):
+        sq = os.path.join(ROOT, "profiles", "%s_c4km_sq_counters.txt" % tag)
+        if os.path.exists(sq):
+            for ln in open(sq):
+                f = ln.split()
+                if len(f) >= 9 and f[0] in ("k_km_assign_mid", "k_nn_map_mid"):
+                    valu["k_km_assign" if f[0] == "k_km_assign_mid" else "k_nn_map"] = (float(f[8]), os.path.basename(sq))
+            break
     out = {"config": CONFIGS["c4km"][8], "steps": steps, "peak_GBps": HBM_PEAK_GBS}
     for name in ("k_km_assign", "k_nn_map"):
         r = prof.get(name)
@@ -155,6 +167,10 @@ def north_star_kernels(L, native):
         out[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": r["launches"], "achieved_GBps": round(gbs, 1),
                      "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"], 1),
                      "traffic": traffic.get(name, {}).get("hbm_bytes_per_launch")}
+        if name in valu:
+            out[name]["valu_frac"] = round(valu[name][0] * 4.0 / (1024.0 * avg_ms * 1e-3 * 2.4e9), 3)
+            out[name]["valu_insts_per_launch"] = valu[name][0]
+            out[name]["valu_source"] = "profiles/%s (SQ_INSTS_VALU, a separate rocprofv3 --pmc pass, not this run)" % valu[name][1]
     return out
 
 
