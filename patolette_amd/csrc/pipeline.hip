@@ -76,6 +76,25 @@ void KernelTimer::reset() { collect(); names.clear(); total_ms.clear(); total_by
 // --------------------------------------------------------------------------------------------
 // node table scatter / gather (host mirror <-> device table) in one copy + one tiny kernel
 // --------------------------------------------------------------------------------------------
+// The root's two tilings (consecutive runs of kTileA / kTileP pixels of node 0), its round list and the cleared bucket tables, made ON
+// the device in one launch: before, the host built ~10 000 tile records and sent them up in four copies followed by three fills -- 30 us
+// of host work during which the GPU had nothing queued behind the conversion, then seven 4.6-us operations in a row.
+__global__ __launch_bounds__(256) void k_gq_prepare(Tile *tA, int ntA, Tile *tP, int ntP, unsigned long long N, int *round_nodes, int *node_tile0,
+                                                    double *hist, unsigned long long nhist, unsigned long long *hsize, unsigned int *hcount) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x, t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long i = t0; i < (unsigned long long)ntA; i += stride) {
+        const unsigned long long o = i * (unsigned long long)kTileA;
+        tA[i] = Tile{o, (unsigned)(N - o < (unsigned long long)kTileA ? N - o : (unsigned long long)kTileA), 0u};
+    }
+    for (unsigned long long i = t0; i < (unsigned long long)ntP; i += stride) {
+        const unsigned long long o = i * (unsigned long long)kTileP;
+        tP[i] = Tile{o, (unsigned)(N - o < (unsigned long long)kTileP ? N - o : (unsigned long long)kTileP), 0u};
+    }
+    for (unsigned long long i = t0; i < nhist; i += stride) hist[i] = 0.0;
+    for (unsigned long long i = t0; i < (unsigned long long)kBuckets; i += stride) { hsize[i] = 0ULL; hcount[i] = 0u; }
+    if (t0 == 0) { round_nodes[0] = 0; node_tile0[0] = 0; node_tile0[1] = ntP; }
+}
+
 __global__ void k_put_nodes(NodeDev *table, const NodeIn *stage, const int *ids, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -568,24 +587,16 @@ static void gq_prepare(Engine &E, size_t N, bool weighted) {
     hipStream_t s = E.stream;
     const size_t planes = weighted ? 4 : 3;
     E.bufA.reserve(planes * N + 64); E.bufB.reserve(planes * N + 64); E.bkt.reserve(N);   // + the slack k_scatter_bin's pixel-less lanes store to
-    std::vector<HNode> hn(1);
-    hn[0].begin = 0; hn[0].n = N;
-    const std::vector<int> round = {0};
-    std::vector<Tile> tA, tP;
-    std::vector<int> tile0;
-    build_tiles(round, hn, kTileA, tA, nullptr);
-    upload_tiles(E, tA, E.tilesA, E.h_tilesA);
-    build_tiles(round, hn, kTileP, tP, &tile0);
-    upload_tiles(E, tP, E.tilesP, E.h_tilesP);
-    E.h_round.reserve(kBuckets);                                // (also receives the bucket counts later: sized once, before any copy uses it)
-    upload_ints(E, round, E.round_nodes, E.h_round);
-    upload_ints(E, tile0, E.node_tile0, E.h_tile0);
-    E.tilecnt.reserve(tP.size() * kMaxChildren); E.tileoff.reserve(tP.size() * kMaxChildren);
+    const int ntA = (int)ceil_div(N, (size_t)kTileA), ntP = (int)ceil_div(N, (size_t)kTileP);
+    E.tilesA.reserve(ntA); E.tilesP.reserve(ntP);
+    E.h_round.reserve(kBuckets);                                // (receives the bucket counts later: sized once, before any copy uses it)
+    E.round_nodes.reserve(1); E.node_tile0.reserve(2);
+    E.tilecnt.reserve((size_t)ntP * kMaxChildren); E.tileoff.reserve((size_t)ntP * kMaxChildren);
     const size_t hs = hist_slot_doubles();
     E.hist.reserve(hs); E.hsize.reserve(kBuckets); E.hcount.reserve(kBuckets); E.lut.reserve(kBuckets);
-    HIP_CHECK(hipMemsetAsync(E.hist.p, 0, hs * sizeof(double), s));
-    HIP_CHECK(hipMemsetAsync(E.hsize.p, 0, kBuckets * sizeof(unsigned long long), s));
-    HIP_CHECK(hipMemsetAsync(E.hcount.p, 0, kBuckets * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(k_gq_prepare, 64, 256, 0, s, E.tilesA.p, ntA, E.tilesP.p, ntP, (unsigned long long)N, E.round_nodes.p, E.node_tile0.p,
+                       E.hist.p, (unsigned long long)hs, E.hsize.p, E.hcount.p);
+    HIP_CHECK(hipGetLastError());
     E.prep_N = N; E.prep_planes = planes;
 }
 
