@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
     // from_end: the blocks take their runs of tiles from the end of the list -- each sweep of a split round starts where the
     // previous one stopped, on the lines that are still in the caches (k_minmax)
     const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int bid = from_end ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int bid = (from_end & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
     for (int ti = tfirst; ti < tlast; ti++) {
         const Tile t = tiles[ti];
@@ -234,6 +234,9 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
                     left &= ~m;
                 }
             }
+#ifdef PAMD_KM_TRACE
+            if (from_end & 2) { if (pv[0] == 1.2345e300) h[b] = pv[1] + pv[2] + pv[3] + pv[4] + pv[5]; direct = false; }   // diagnostic: the kernel without its LDS atomics
+#endif
             if (direct) {
                 atomicAdd(&cnt[b], 1u);
 #pragma unroll
@@ -1111,7 +1114,11 @@ static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntile
     // resident blocks per CU by LDS footprint (4 for the local quantiser's 29 KB, 1 for the global quantiser's 82+ KB);
     // each block walks its run of tiles and flushes once per node run
     const int g = std::min(ntiles, 256 * (GQ ? 1 : 4));
-    hipLaunchKernelGGL((k_hist<W, GQ>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount, from_end ? 1 : 0);
+    int fe = from_end ? 1 : 0;
+#ifdef PAMD_KM_TRACE
+    if (getenv("PAMD_HIST_NOATOMIC") && atoi(getenv("PAMD_HIST_NOATOMIC"))) fe |= 2;     // diagnostic: time the kernel without its LDS atomics (wrong results)
+#endif
+    hipLaunchKernelGGL((k_hist<W, GQ>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount, fe);
     HIP_CHECK(hipGetLastError());
 }
 
