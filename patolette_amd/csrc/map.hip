@@ -770,7 +770,10 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
         "s_nop 0" : "+v"(v));                                   // -> every lane holds its 16-lane row minimum
     const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
                    r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-    return min(min(r0, r1), min(r2, r3));
+    // three scalar minima (the compiler otherwise moves two of the values back into vector registers for a v_min3_u32)
+    unsigned m23, m;
+    asm("s_min_u32 %0, %2, %3\n\ts_min_u32 %1, %4, %5\n\ts_min_u32 %0, %0, %1" : "=&s"(m), "=&s"(m23) : "s"(r0), "s"(r1), "s"(r2), "s"(r3));
+    return m;
 }
 // lowest lane holding the minimum of a non-negative double: non-negative doubles order like their bit patterns, so the
 // high words decide (one 32-bit DPP minimum) and the low words only among lanes that tie on the high word
@@ -778,11 +781,41 @@ __device__ __forceinline__ int wave_argmin_nonneg_f64(double v) {
     const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
     const unsigned mh = wave_min_u32(hi);
     unsigned long long c = __ballot(hi == mh);
-    if (c & (c - 1)) {                                                   // several lanes share the high word (wave-uniform)
+    if (__popcll(c) != 1) {                                              // several lanes share the high word (wave-uniform)
         const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
         c = __ballot(hi == mh && lo == ml);
     }
     return (int)__builtin_ctzll(c);
+}
+
+// The dither's per-pixel search with FOUR entries per lane (K <= 256), first stage: bd = the lane's smallest distance (already taken),
+// e = which of the lane's four entries attains it (the FIRST one: ascending index with strict '<'), and the 16-lane row minima of
+// bd's high words.  One hand-scheduled block instead of two compiler-scheduled ones: a DPP instruction may read a register only two
+// wait states after it was written, and so may a select read VCC after a 64-bit compare -- the four row-minimum steps used to
+// stand behind an s_nop each, and the three compare / select pairs behind theirs; interleaved, each fills the other's gaps:
+// 14 issue slots instead of 21 on a chain whose cost is its instruction count.  Returns the row minima (every lane its row's).
+__device__ __forceinline__ unsigned dither_rows4(const double d0, const double d1, const double d2, const double d3, const double bd, int &e) {
+    const unsigned hi = (unsigned)__double2hiint(bd);
+    unsigned t; int ee;
+    asm volatile("v_cmp_eq_f64_e32 vcc, %[d2], %[bd]\n\t"
+                 "s_nop 0\n\t"
+                 "v_min_u32_dpp %[t], %[hi], %[hi] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_e64 %[e], 3, 2, vcc\n\t"                   // entry 2 if it attains the minimum, else 3
+                 "v_cmp_neq_f64_e32 vcc, %[d1], %[bd]\n\t"
+                 "v_min_u32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_cndmask_b32_e32 %[e], 1, %[e], vcc\n\t"               // entry 1 if it does
+                 "v_min_u32_dpp %[t], %[t], %[t] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cmp_neq_f64_e32 vcc, %[d0], %[bd]\n\t"
+                 "s_nop 0\n\t"
+                 "v_min_u32_dpp %[t], %[t], %[t] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_e32 %[e], 0, %[e], vcc"                     // entry 0 if it does
+                 : [t] "=&v"(t), [e] "=&v"(ee)
+                 : [hi] "v"(hi), [bd] "v"(bd), [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2)
+                 : "vcc");
+    (void)d3;
+    e = ee;
+    return t;
 }
 
 // One wavefront walks one image; every instruction of the chain is issued by that one wavefront (~2.5 ns each), so the count of
@@ -801,7 +834,10 @@ __device__ __forceinline__ int wave_argmin_nonneg_f64(double v) {
 //
 // Nearest colour: all 64 lanes share the palette (lane L owns entries [L PER, (L + 1) PER), in registers when PER <= 4), per-lane
 // best in ascending index with strict '<', then the lowest lane among the wave-wide minima = lowest index on ties.
-template <typename OutT, int PER>
+// GT: the palette tables are in global memory (K > 3200).  A template parameter and not a run-time choice of pointer: the chosen
+// colour is read once per pixel ON the serial chain, and through a pointer that may be either space the compiler issues a FLAT load
+// (both address paths, vmcnt and lgkmcnt waited for) where the LDS table needs a ds_read_b64.
+template <typename OutT, int PER, bool GT>
 __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, size_t plane_stride, unsigned width, unsigned height,
                                                const double *__restrict__ pal /* planar (k,3), linear Rec2020 */, int k,
                                                OutT *__restrict__ out, DitherWeights wts, double *gtab) {
@@ -809,10 +845,10 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
     constexpr int kRing = 128;                                       // >= 64 + 15 pending pixels
     // the two palette tables live in LDS; a palette too large for that (K > 3200; the reference takes any K,
     // riemersma.c:437-459) keeps them in the 6 k doubles of global memory at `gtab` -- correct, and as slow as it sounds
-    double *tab = gtab ? gtab : lds;
-    double *praw = tab;                                              // [3][k] raw palette
-    double *pwt = tab + 3 * k;                                       // [3][k] palette scaled by (float)-cast weights (riemersma.c:419-425)
-    double *rpx = gtab ? lds : lds + 6 * k;                          // [3][kRing] channels of the pending pixels
+    double *rpx = GT ? lds : lds + 6 * k;                            // [3][kRing] channels of the pending pixels
+    auto table = [&]() { if constexpr (GT) return gtab; else return (double *)lds; };   // (keeps the LDS address space when !GT)
+    auto praw = table();                                             // [3][k] raw palette
+    auto pwt = praw + 3 * k;                                         // [3][k] palette scaled by (float)-cast weights (riemersma.c:419-425)
     unsigned int *rpos = reinterpret_cast<unsigned int *>(rpx + 3 * kRing);   // [kRing] their linear pixel numbers
     const int lane = threadIdx.x;
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
@@ -844,8 +880,11 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
         for (int i = 0; i < 16; i++) v = (15 - ((dph - j - 1) & 15)) == i ? wts.w[i] : v;     // w_i = m^i / 16 (host libm, riemersma.c:360-373)
         wl[j] = v;
     }
+    double keep[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) keep[j] = dph == j ? 0.0 : 1.0;
     double acc = 0.0;                                                // this lane's partial sum (the queue starts as zeros: 0 + x = x)
-    const double *prw = praw + ch * k;
+    const auto prw = praw + ch * k;
 
     // nearest palette entry of the query (qx, qy, qz)
     auto nearest = [&](const double qx, const double qy, const double qz) -> int {
@@ -862,6 +901,22 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
             bd = dd[0];
 #pragma unroll
             for (int m = 1; m < PER; m++) bd = fmin(bd, dd[m]);
+            if constexpr (PER == 4) {
+                int e;
+                const unsigned t = dither_rows4(dd[0], dd[1], dd[2], dd[3], bd, e);
+                bj = e | (lane * PER);
+                const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)t, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)t, 16),
+                               r2 = (unsigned)__builtin_amdgcn_readlane((int)t, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)t, 48);
+                unsigned m23, mh;
+                asm("s_min_u32 %0, %2, %3\n\ts_min_u32 %1, %4, %5\n\ts_min_u32 %0, %0, %1" : "=&s"(mh), "=&s"(m23) : "s"(r0), "s"(r1), "s"(r2), "s"(r3));
+                const unsigned hi = (unsigned)__double2hiint(bd), lo = (unsigned)__double2loint(bd);
+                unsigned long long c = __ballot(hi == mh);
+                if (__popcll(c) != 1) {                              // several lanes share the high word (wave-uniform): the low words decide
+                    const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+                    c = __ballot(hi == mh && lo == ml);
+                }
+                return __builtin_amdgcn_readlane(bj, (int)__builtin_ctzll(c));
+            }
             bj = PER - 1;
 #pragma unroll
             for (int m = PER - 2; m >= 0; m--) bj = dd[m] == bd ? m : bj;
@@ -893,7 +948,9 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
                 const int bi = nearest(readlane_f64(qv, j), readlane_f64(qv, 16 + j), readlane_f64(qv, 32 + j));
                 res = lane == j ? bi : res;
                 const double err = pcs[j] - prw[bi];                 // original pixel - chosen colour (riemersma.c:333-340)
-                acc = (dph == j ? 0.0 : acc) + err * wl[j];          // lane (c, j) starts the sum of step + 16 with term 0
+                // lane (c, j) starts the sum of step + 16 with term 0: acc * keep + t with keep = 0 there, 1 elsewhere -- the product is
+                // exact, so the fused form rounds exactly like (keep ? acc : 0) + t, in two instructions instead of four
+                acc = __builtin_fma(acc, keep[j], err * wl[j]);
             }
         }
         if (lane < limit) out[rpos[(head + (unsigned)lane) & (kRing - 1)]] = (OutT)res;
@@ -969,8 +1026,13 @@ static void launch_dither_t(const double *d_img, size_t plane_stride, size_t wid
                             const DitherWeights &wts, size_t lds, double *gtab, hipStream_t s) {
 #define PAMD_DITHER(PER)                                                                                                       \
     do {                                                                                                                       \
-        HIP_CHECK(hipFuncSetAttribute((const void *)(k_dither<OutT, PER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_dither<OutT, PER>), 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts, gtab); \
+        if (gtab) {                                                                                                            \
+            HIP_CHECK(hipFuncSetAttribute((const void *)(k_dither<OutT, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_dither<OutT, 0, true>), 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts, gtab); \
+            break;                                                                                                             \
+        }                                                                                                                      \
+        HIP_CHECK(hipFuncSetAttribute((const void *)(k_dither<OutT, PER, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_dither<OutT, PER, false>), 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts, gtab); \
     } while (0)
     if (k <= 64) PAMD_DITHER(1);
     else if (k <= 128) PAMD_DITHER(2);
