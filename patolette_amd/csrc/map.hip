@@ -637,7 +637,7 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
             hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, l1, l2, (const unsigned char *)w.clist.p, use_mid ? w.mid.p : nullptr);
         }
         if (use_mid) {
-            constexpr int P = 4;
+            constexpr int P = sizeof(OutT) == 1 ? 4 : 2;       // (four pixels per lane with 4- or 8-byte map elements spill 70-82 registers)
             const size_t lds_mid = kMidLds;
             static PerDeviceOnce attr_mid;
             if (attr_mid.first()) {
