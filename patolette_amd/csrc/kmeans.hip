@@ -1314,7 +1314,8 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 // then runs ITS chain over the four blocks from there -- 4 bytes per sample read per chain instead of 16 from memory, and the
 // in-order replays read the same buffer.  Two barriers per super-step; the next super-step's records are in flight meanwhile.
 template <bool W>
-__device__ __forceinline__ float km_chain_coop(const float4 *__restrict__ sorted, size_t lo, size_t hi, float *coop, int lane, int wid) {
+__device__ __forceinline__ float km_chain_coop(const float4 *__restrict__ sorted, size_t lo, size_t hi, float *coop, int lane, int wid,
+                                               const bool km_quarters = true) {
     constexpr int K = 16;
     constexpr size_t BS = (size_t)64 * K, SS = 4 * BS;
     const bool wx = W && wid < 3;                                          // weighted coordinate chain: acc = fma(x, w, acc)
@@ -1345,17 +1346,17 @@ __device__ __forceinline__ float km_chain_coop(const float4 *__restrict__ sorted
                 if (pos >= hi) break;                                      // wave-uniform
                 const size_t bend = pos + BS < hi ? pos + BS : hi;
                 const float *blk = mine + d * (int)BS, *wblk = wts + d * (int)BS;
-                bool done = false;
-                const float aa = fabsf(acc);
-                if (aa >= 1e-30f && aa < 1e30f) {
+                // the exact integer form of the chain over NQ quarters (256 samples each) starting at quarter q0 of the block: true if it held
+                auto try_quarters = [&](const int q0, const int nq) -> bool {
+                    const float aa = fabsf(acc);
+                    if (!(aa >= 1e-30f && aa < 1e30f)) return false;
                     int ex;
                     (void)frexpf(aa, &ex);                                 // aa in [2^(ex-1), 2^ex)
                     const double sgn = acc < 0.f ? -1.0 : 1.0;
                     const double scale = ldexp(sgn, 24 - ex);              // +-1/u with u = 2^(ex-1-23)
                     const double M0 = (double)aa * fabs(scale);            // integer in [2^23, 2^24)
                     double tot = 0.0, mag = 0.0, dev = 0.0;                // sum r, sum |r|, max |t - r|
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {                          // 16 samples per lane; any split of the block will do
+                    for (int q = q0; q < q0 + nq; q++) {                   // 4 samples per lane and quarter; any split will do
                         const float4 xv = *reinterpret_cast<const float4 *>(blk + q * 256 + lane * 4);
                         float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
                         if (wx) wv = *reinterpret_cast<const float4 *>(wblk + q * 256 + lane * 4);
@@ -1373,12 +1374,13 @@ __device__ __forceinline__ float km_chain_coop(const float4 *__restrict__ sorted
                     const double pp = 0.5 * (tot + mag), nn = 0.5 * (tot - mag);
                     if (!__any(dev >= 0.5) && M0 + nn >= 8388609.0 && M0 + pp <= 16777215.0) {
                         acc = (float)(ldexp(M0 + tot, ex - 24) * sgn);
-                        done = true;
+                        return true;
                     }
-                }
-                if (!done) {                                               // in order, straight from the shared buffer
-                    for (size_t base = pos; base < bend; base += 64) {
-                        const int cnt = (int)(bend - base < 64 ? bend - base : 64);
+                    return false;
+                };
+                auto replay = [&](const size_t from, const size_t to) {     // in order, straight from the shared buffer
+                    for (size_t base = from; base < to; base += 64) {
+                        const int cnt = (int)(to - base < 64 ? to - base : 64);
                         const float4 *s4 = reinterpret_cast<const float4 *>(blk + (base - pos)), *w4 = reinterpret_cast<const float4 *>(wblk + (base - pos));
                         if (cnt == 64) {
                             float4 xv[16], wv[16];
@@ -1410,7 +1412,17 @@ __device__ __forceinline__ float km_chain_coop(const float4 *__restrict__ sorted
                             }
                         }
                     }
+                };
+                // the whole block at once; a block that fails (the accumulator changes binade inside it, an exact tie) is taken quarter
+                // by quarter -- the quarters before and after a binade change hold again on their own scale -- and only a failing
+                // QUARTER is replayed in order (km_quarters: 0 = replay the whole block as before)
+                bool done = try_quarters(0, 4);
+                if (!done && km_quarters && bend == pos + BS) {
+                    for (int q = 0; q < 4; q++)
+                        if (!try_quarters(q, 1)) replay(pos + (size_t)q * 256, pos + (size_t)(q + 1) * 256);
+                    done = true;
                 }
+                if (!done) replay(pos, bend);
             }
         }
         __syncthreads();                                                   // the buffer is rewritten by the next super-step
@@ -1584,7 +1596,7 @@ __device__ __forceinline__ void km_update_finish(const int kidx, const int k, co
 template <bool W, bool BIGK = false>
 __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ sorted, const unsigned int *__restrict__ rowtot, int k,
                                                   unsigned long long nx, float *cent, float *hassign, float4 *c4,
-                                                  unsigned int *ticket, DevMT *mt, unsigned long long long_min, float *hs_mem) {
+                                                  unsigned int *ticket, DevMT *mt, unsigned long long long_min, float *hs_mem, const int quarters) {
     __shared__ float4 stage[4][2][64];
     extern __shared__ __attribute__((aligned(16))) float coop[];          // km_chain_coop: [4 components][4096 samples] when launched with it
     __shared__ float res[4];
@@ -1598,7 +1610,7 @@ __global__ __launch_bounds__(256) void k_km_update(const float4 *__restrict__ so
     const size_t lo = pre, hi = lo + rowtot[kidx];
     float acc = 0.f;
     if ((size_t)(hi - lo) >= long_min) {                                  // block-uniform (long_min is huge without the LDS buffer)
-        acc = km_chain_coop<W>(sorted, lo, hi, coop, lane, wid);
+        acc = km_chain_coop<W>(sorted, lo, hi, coop, lane, wid, quarters != 0);
     } else {
         if (wid == 0) acc = km_chain<W, 0>(sorted, lo, hi, stage[0], lane);
         else if (wid == 1) acc = km_chain<W, 1>(sorted, lo, hi, stage[1], lane);
@@ -2245,6 +2257,7 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     if (use_mid) w.mid.reserve(32 * 32 * 32);
     // clusters of at least this many samples take the block-parallel exact chain (km_chain_coop)
     const unsigned long long long_min = getenv("PAMD_KM_LONG_MIN") ? (unsigned long long)atoll(getenv("PAMD_KM_LONG_MIN")) : 8192ULL;
+    static const int km_quarters = (getenv("PAMD_KM_QUARTERS") && atoi(getenv("PAMD_KM_QUARTERS")) == 0) ? 0 : 1;   // A/B of the quarter-wise retry
     for (int it = 0; it < niter; it++) {
         if (use_direct) {
             unsigned short *offs = (unsigned short *)w.table.p;              // 257 x blocks x 2 bytes
@@ -2320,8 +2333,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
                     HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
                     HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4096 * 4));
                 }
-                if (weighted) hipLaunchKernelGGL((k_km_update<true, true>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, w.hs.p);
-                else hipLaunchKernelGGL((k_km_update<false, true>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, w.hs.p);
+                if (weighted) hipLaunchKernelGGL((k_km_update<true, true>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, w.hs.p, km_quarters);
+                else hipLaunchKernelGGL((k_km_update<false, true>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, w.hs.p, km_quarters);
             }
             continue;
         }
@@ -2352,8 +2365,8 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             const bool coop_on = nx >= long_min;
             const size_t lds_up = coop_on ? (size_t)4 * 4096 * sizeof(float) : 0;
             const unsigned long long lm = coop_on ? long_min : ~0ULL;
-            if (weighted) hipLaunchKernelGGL((k_km_update<true, false>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, (float *)nullptr);
-            else hipLaunchKernelGGL((k_km_update<false, false>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, (float *)nullptr);
+            if (weighted) hipLaunchKernelGGL((k_km_update<true, false>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, (float *)nullptr, km_quarters);
+            else hipLaunchKernelGGL((k_km_update<false, false>), k, 256, lds_up, s, w.sorted.p, w.rowtot.p, k, (unsigned long long)nx, w.cent.p, w.hassign.p, w.c4.p, w.ticket.p, w.mt.p, lm, (float *)nullptr, km_quarters);
         }
     }
     HIP_CHECK(hipGetLastError());
