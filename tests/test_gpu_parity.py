@@ -467,6 +467,30 @@ def test_batch_equals_individual_calls(gpu, ob):
         assert np.array_equal(batch[i][1], one[1]) and np.array_equal(batch[i][2], one[2])
 
 
+def test_batch_of_large_images_six_in_flight(gpu, ob):
+    """Eight images of 1536 x 1408 (2.16 Mpx: above the size from which the host entry uploads in pieces and converts behind the
+    copies on a second stream, and from which KMeans subsamples on the helper thread) through the batch entry -- six engines in
+    flight, each with its own streams, helper thread and workspace -- against separate calls, one of them against the oracle."""
+    import os
+    import patolette_amd as p
+    w, h, K, count = 1536, 1408, 64, 8
+    n = w * h
+    imgs = [np.asfortranarray(ob.unplanar(ob.image(n, 400 + i), n)) if i % 2 else ob.unplanar(ob.image(n, 400 + i), n) for i in range(count)]   # planar and row-major
+    wts = [ob.weights(n, 400 + i) if i % 3 == 0 else None for i in range(count)]
+    kw = dict(dither=False, tile_size=0, kmeans_niter=3, kmeans_max_samples=512 ** 2)
+    batch = p.quantize_batch(w, h, imgs, K, weights=wts, **kw)
+    for i in range(count):
+        one = p.quantize(w, h, imgs[i], K, weights=wts[i], **kw)
+        assert batch[i][0] and one[0]
+        assert np.array_equal(batch[i][1], one[1]) and np.array_equal(batch[i][2], one[2]), i
+    ob.set_threads(os.cpu_count() or 1)
+    try:
+        ec, pal_o, map_o = ob.patolette(w, h, ob.planar(np.ascontiguousarray(imgs[3])), wts[3], K, dither=False, color_space=2, kmeans_niter=3, kmeans_max_samples=512 ** 2)
+    finally:
+        ob.set_threads(1)
+    assert ec == 0 and np.allclose(batch[3][1], pal_o, rtol=0, atol=1e-9) and np.array_equal(batch[3][2], map_o)
+
+
 @pytest.mark.parametrize("channels,K,dither,cs", [(3, 64, False, 2), (4, 64, True, 1), (3, 300, False, 0), (3, 16, True, 2)])
 def test_u8_adaptor_equals_by_hand_steps(gpu, ob, channels, K, dither, cs):
     """quantize_u8 == what README.md:147-194 does by hand around quantize(), and == the oracle fed with img/255."""
