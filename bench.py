@@ -699,9 +699,25 @@ def main():
         dt_one, st_one, res_one = cpu_run(1)
         if sn == n and weighted != "saliency":
             parity = parity_record(L, _native, cfg, d_imgs[0], d_wts[0] if weighted is True else None, pal_timed, res_all, res_one, ob)
+        elif weighted != "saliency":
+            # the CPU sample is smaller than the workload: the HIP path quantises the SAME sample (seed 0, same options) once, untimed,
+            # and that result is held to the oracle's
+            sub_cfg = (sw, sh) + tuple(cfg[2:])
+            d_s = L.patolette_amd_malloc(3 * sn * 8)
+            d_sw = L.patolette_amd_malloc(sn * 8) if weighted is True else None
+            try:
+                assert d_s and L.patolette_amd_fill_image(d_s, sn, 0) == 0
+                if d_sw:
+                    assert L.patolette_amd_fill_weights(d_sw, sn, 0) == 0
+                parity = parity_record(L, _native, sub_cfg, d_s, d_sw, None, res_all, res_one, ob)
+                if isinstance(parity, dict) and "image" in parity:
+                    parity["image"] = "the cpu_baseline sample: %dx%d, seed 0, same options as the workload (the full %dx%d image would take the oracle %.0fx as long)" % (sw, sh, width, height, n / sn)
+            finally:
+                for q_ in (d_s, d_sw):
+                    if q_:
+                        L.patolette_amd_free(q_)
         else:
-            parity = {"note": "the CPU sample is smaller than the workload (or derives its own weights): no full-size comparison in this run; "
-                              "see tests/test_gpu_parity.py"}
+            parity = {"note": "the oracle derives its own saliency weights (unpinned restatement): no comparison in this run; see tests/test_gpu_saliency.py"}
         scale = "the full %dx%d workload" % (sw, sh) if sn == n else "%dx%d of the same workload (the %dx%d image would take %.0fx as long)" % (sw, sh, width, height, n / sn)
         if dither:
             # the stage that is 99.8 % of this configuration, side by side: the GPU's one-wavefront chain against the oracle's
