@@ -818,6 +818,28 @@ __device__ __forceinline__ unsigned dither_rows4(const double d0, const double d
     return t;
 }
 
+// The same stage with two entries per lane (K <= 128): one compare / select pair fills two of the wait states.
+__device__ __forceinline__ unsigned dither_rows2(const double d0, const double bd, int &e) {
+    const unsigned hi = (unsigned)__double2hiint(bd);
+    unsigned t; int ee;
+    asm volatile("v_cmp_neq_f64_e32 vcc, %[d0], %[bd]\n\t"
+                 "s_nop 0\n\t"
+                 "v_min_u32_dpp %[t], %[hi], %[hi] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_e64 %[e], 0, 1, vcc\n\t"                   // entry 0 if it attains the minimum, else 1
+                 "s_nop 0\n\t"
+                 "v_min_u32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %[t], %[t], %[t] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %[t], %[t], %[t] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : [t] "=&v"(t), [e] "=&v"(ee)
+                 : [hi] "v"(hi), [bd] "v"(bd), [d0] "v"(d0)
+                 : "vcc");
+    e = ee;
+    return t;
+}
+
 // One wavefront walks one image; every instruction of the chain is issued by that one wavefront (~2.5 ns each), so the count of
 // instructions per pixel is what matters.
 //
@@ -901,9 +923,11 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
             bd = dd[0];
 #pragma unroll
             for (int m = 1; m < PER; m++) bd = fmin(bd, dd[m]);
-            if constexpr (PER == 4) {
+            if constexpr (PER == 4 || PER == 2) {
                 int e;
-                const unsigned t = dither_rows4(dd[0], dd[1], dd[2], dd[3], bd, e);
+                unsigned t;
+                if constexpr (PER == 4) t = dither_rows4(dd[0], dd[1], dd[2], dd[3], bd, e);
+                else t = dither_rows2(dd[0], bd, e);
                 bj = e | (lane * PER);
                 const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)t, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)t, 16),
                                r2 = (unsigned)__builtin_amdgcn_readlane((int)t, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)t, 48);

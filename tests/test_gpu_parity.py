@@ -361,7 +361,7 @@ def test_nn_map_lds_table_path_is_exact(gpu, ob):
 def test_dither_bit_exact(gpu, ob, wh):
     w, h = wh
     n = w * h
-    for k in (5, 64, 256):
+    for k in (5, 64, 100, 128, 130, 256):           # one, two and four entries per lane (100 and 130: lanes with padding entries)
         flat = ob.convert("srgb_to_rec2020", ob.image(n, 7))
         pal = ob.convert("srgb_to_rec2020", ob.image(k, 9)).reshape(3, k).T.copy()
         want = ob.dither(flat, w, h, pal)
