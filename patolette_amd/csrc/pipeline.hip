@@ -808,6 +808,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             fval[j] = fkn[j] ? benefit(h) : h.ub;
         };
         for (size_t j = 0; j < count; j++) refresh(j);
+        static const bool lq_times = getenv("PAMD_LQ_TIMES") != nullptr;       // diagnostic: where the host's turn between two rounds goes
+        double tm_greedy = 0, tm_select = 0, tm_axes = 0, tm_packet = 0, tm_enqueue = 0, tm_wait = 0, tm_children = 0, tm_mark = now_ms();
+        auto lap = [&](double &acc) { if (lq_times) { const double t = now_ms(); acc += t - tm_mark; tm_mark = t; } };
         for (;;) {
             if (count >= K) break;
             // one greedy step, exact whenever every undecided node is provably not the arg-max
@@ -850,6 +853,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                     thr = std::max(thr, kb[R - 1] * (1.0 - 1e-9));
                 }
             }
+            lap(tm_greedy);
             round.clear();
             {
                 std::vector<int> keep;
@@ -863,6 +867,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             if (round.empty()) {                                // every blocking node is a leaf with dist >= ref_b >= thr
                 throw HipError("patolette_amd: split loop blocked without candidates");
             }
+            lap(tm_select);
             // axes on the host (dsyev semantics), children ids, device records
             HIP_CHECK(hipStreamSynchronize(s));
             E.nodes.grow(hn.size() + 2 * round.size() + 2, hn.size());
@@ -881,6 +886,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 todo.push_back(id); ids.push_back(id); recs.push_back(d);
             }
             for (size_t j = 0; j < count; j++) refresh(j);      // a failed eigen-solve above makes a node known (no split)
+            lap(tm_axes);
             if (todo.empty()) continue;
             const int nr = (int)todo.size();
             size_t rpx = 0;
@@ -907,6 +913,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             std::memcpy(E.h_packet.p + o_tA0, tA0.data(), (size_t)(nr + 1) * sizeof(int));
             std::memcpy(E.h_packet.p + o_tP0, tP0.data(), (size_t)(nr + 1) * sizeof(int));
             std::memcpy(E.h_packet.p + o_cids, cids.data(), cids.size() * sizeof(int));
+            lap(tm_packet);
             HIP_CHECK(hipMemcpyAsync(E.packet.p, E.h_packet.p, pk_bytes, hipMemcpyHostToDevice, s));
             const size_t lqs = (size_t)kNQ_LQ * 2 * kBuckets;
             E.hist.reserve(std::max(hs, lqs * nr)); E.hsize.reserve((size_t)nr * kBuckets); E.hcount.reserve((size_t)nr * kBuckets);
@@ -939,7 +946,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 HIP_CHECK(hipGetLastError());
                 shard_exchange_acc(E, (const int *)(E.packet.p + o_cids), (int)cids.size());
             }
+            lap(tm_enqueue);
             get_nodes_dev(E, (const int *)(E.packet.p + o_cids), (int)cids.size(), got);
+            lap(tm_wait);
             for (size_t i = 0; i < cids.size(); i++) {
                 HNode &c = hn[cids[i]];
                 const NodeOut &d = got[i];
@@ -952,7 +961,10 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             for (int id : cids) leaves.push_back(id);
             for (size_t j = 0; j < count; j++) refresh(j);      // the round's nodes are known now
             E.stats.lq_rounds++;
+            lap(tm_children);
         }
+        if (lq_times) fprintf(stderr, "patolette_amd: split loop host ms: greedy %.3f select %.3f axes %.3f packet %.3f enqueue %.3f wait(gpu) %.3f children %.3f\n",
+                              tm_greedy, tm_select, tm_axes, tm_packet, tm_enqueue, tm_wait, tm_children);
         result.resize(count);
     }
     len = count;
