@@ -244,6 +244,14 @@ int patolette_amd_nn_map(const double *colors, size_t n, const double *palette, 
 int patolette_amd_dither(const double *colors, size_t width, size_t height, const double *palette,
                          size_t k, size_t *map);
 
+/* Test / tuning knob of the segment-parallel dither (process-wide): `segments` runs (0 = chosen from the image size, 1 = the
+ * single serial chain) and `warm` in-image pixels of speculative warm-up per run (< 0 = default; 0 forces every boundary to be
+ * repaired).  The map is the reference's chain bit for bit for every setting. */
+void patolette_amd_dither_config(int segments, int warm);
+/* Where the dither cuts the curve (host-side copy of the kernel's function, runs without a GPU): *d = first curve position of the
+ * aligned 64-position block that holds in-image pixel number t (curve order, 0-based), *c = in-image pixels before that block. */
+void patolette_amd_debug_dither_locate(size_t width, size_t height, unsigned long long t, unsigned long long *d, unsigned long long *c);
+
 /* ---- statistics of the last full-path call on this thread -------------------------------- */
 typedef struct patolette_amd__Stats {
     double ms_total, ms_upload, ms_convert, ms_gq, ms_lq, ms_kmeans, ms_map, ms_download, ms_saliency;
@@ -253,6 +261,9 @@ typedef struct patolette_amd__Stats {
     size_t split_px;          /* sum of their sizes: D_eff = split_px / (width*height) */
     size_t lq_rounds;         /* host<->device round trips of the split loop */
     size_t kmeans_samples;    /* samples clustered per KMeans iteration */
+    size_t dither_segments;   /* runs the Hilbert curve was cut into (walked side by side, one wavefront each) */
+    size_t dither_repairs;    /* runs walked again because their speculative starting state was not the chain's */
+    size_t dither_rounds;     /* boundary-verification passes (the last one found nothing to repair) */
 } patolette_amd__Stats;
 void patolette_amd_last_stats(patolette_amd__Stats *out);
 /* The palette exactly as the mapping stage of the last full-path call on this thread used it: linear Rec2020 when dithering

@@ -24,7 +24,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_total", "ms_upload", "ms_convert", "ms_gq", "ms_lq",
                                           "ms_kmeans", "ms_map", "ms_download", "ms_saliency")] + \
                [(n, C.c_size_t) for n in ("n_base_clusters", "n_clusters", "split_evals", "split_px",
-                                          "lq_rounds", "kmeans_samples")]
+                                          "lq_rounds", "kmeans_samples", "dither_segments", "dither_repairs",
+                                          "dither_rounds")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -98,6 +99,9 @@ SYMBOLS = {
     "patolette_amd_kmeans_refine": (C.c_int, [dp, dp, C.c_size_t, dp, C.c_size_t, C.c_int, C.c_size_t]),
     "patolette_amd_nn_map": (C.c_int, [dp, C.c_size_t, dp, C.c_size_t, zp]),
     "patolette_amd_dither": (C.c_int, [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp]),
+    "patolette_amd_dither_config": (None, [C.c_int, C.c_int]),
+    "patolette_amd_debug_dither_locate": (None, [C.c_size_t, C.c_size_t, C.c_ulonglong, C.POINTER(C.c_ulonglong),
+                                                 C.POINTER(C.c_ulonglong)]),
     "patolette_amd_last_stats": (None, [C.POINTER(Stats)]),
     "patolette_amd_last_map_palette": (C.c_size_t, [dp, C.c_size_t]),
     "patolette_amd_profile_enable": (None, [C.c_int]),

@@ -7,14 +7,16 @@
 // 4 B/px written; brute force at K = 256 is f64-VALU-bound, the palette comes
 // through the scalar cache (wave-uniform index -> s_load).
 //
-// k_dither replaces patolette__DITHER_riemersma (lib/src/dither/riemersma.c:437-459): the chain
-// of W*H steps is serial by construction (each choice feeds the 16-entry error queue), so one
-// wavefront walks one image: per 64-step batch the lanes decode 64 curve positions and prefetch
-// their pixels in parallel, then the steps run in order -- error sum in reference order, K/64
-// palette entries per lane, wave arg-min with the lowest-index tie rule.  Latency-bound; batch
-// parallelism (one wavefront per image) is where throughput comes from.
+// k_dither replaces patolette__DITHER_riemersma (lib/src/dither/riemersma.c:437-459): a chain of
+// W*H steps, each choice feeding the 16-entry error queue.  One wavefront walks one chain: per
+// 64-step batch the lanes decode 64 curve positions and prefetch their pixels in parallel, then
+// the steps run in order -- error sum in reference order, K/64 palette entries per lane, wave
+// arg-min with the lowest-index tie rule.  The chain's state is a function of its last sixteen
+// choices, so the curve is cut into ~2000 runs that are walked side by side from speculative
+// warm-ups, verified at every boundary and repaired where the speculation missed (DitherSeg).
 #include "map.h"
 
+#include <algorithm>
 #include <cmath>
 
 #include "devutil.h"
@@ -714,7 +716,7 @@ void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const 
 // --------------------------------------------------------------------------------------------
 // Hilbert index -> (x, y) on the 2^L square; visiting order identical to traverse_level(L, UP)
 // from (0,0) (riemersma.c:176-257), checked against the oracle's recorded walk.
-__device__ __forceinline__ void hilbert_d2xy(int L, unsigned long long d, unsigned &xo, unsigned &yo) {
+__host__ __device__ __forceinline__ void hilbert_d2xy(int L, unsigned long long d, unsigned &xo, unsigned &yo) {
     unsigned x = 0, y = 0;
     unsigned long long t = d;
     for (int lv = 0; lv < L; lv++) {
@@ -840,7 +842,54 @@ __device__ __forceinline__ unsigned dither_rows2(const double d0, const double b
     return t;
 }
 
-// One wavefront walks one image; every instruction of the chain is issued by that one wavefront (~2.5 ns each), so the count of
+// Where the t-th in-image pixel (0-based, in curve order) lies: d = first curve position of the aligned block of 64 positions
+// (an 8 x 8 sub-square) that holds it, c = in-image pixels before that block.  t >= width * height: d = 4^L, c = width * height.
+// A descent through the curve's quadrants; a quadrant's share of the image is a rectangle, so its count is a product.
+__host__ __device__ __forceinline__ void dither_locate(int L, unsigned width, unsigned height, unsigned long long t,
+                                              unsigned long long &d_out, unsigned long long &c_out) {
+    unsigned long long d0 = 0, c = 0;
+    for (int j = L; j > 3; j--) {                                    // children are 2^(j-1) squares of 4^(j-1) curve positions
+        const unsigned side = 1u << (j - 1);
+        const unsigned long long span = 1ULL << (2 * (j - 1));
+        bool found = false;
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long dq = d0 + (unsigned long long)q * span;
+            unsigned x0, y0;
+            hilbert_d2xy(L, dq, x0, y0);
+            x0 &= ~(side - 1u); y0 &= ~(side - 1u);
+            const unsigned long long nx = x0 >= width ? 0u : (width - x0 < side ? width - x0 : side);
+            const unsigned long long ny = y0 >= height ? 0u : (height - y0 < side ? height - y0 : side);
+            const unsigned long long cnt = nx * ny;
+            if (t < c + cnt) { d0 = dq; found = true; break; }
+            c += cnt;
+        }
+        if (!found) { d_out = 1ULL << (2 * L); c_out = c; return; }
+    }
+    d_out = d0; c_out = c;
+}
+
+// Segment-parallel form of the chain (DitherSeg::S > 1).  The reference pushes `original pixel - chosen colour` into its queue
+// (riemersma.c:333-340): the state of the chain after any step is a pure function of the last sixteen (pixel, choice) pairs.  A
+// chain started from a ZERO queue somewhere on the curve is therefore bit-identical to the true chain from the moment it has made
+// the true chain's choice sixteen times in a row (measured with the oracle, tests/test_dither_lockon.py: 16 .. ~800 steps).
+//   MODE 0, block b of S: the curve's in-image pixels are cut into S runs of equal length (boundaries moved to the start of the
+//       aligned 64-position block, dither_locate).  The wavefront starts `warm` in-image pixels before its run from a zero queue,
+//       keeps the choices of the last sixteen warm-up steps in side[b][0..16) and writes the choices of its own run to the map.
+//   MODE 1, block b (>= 1): the run is final once the state it was started from is the true one, i.e. once the sixteen choices in
+//       side[b] equal what the map holds at the sixteen in-image positions before the run.  If they differ, the wavefront rebuilds the
+//       queue from the map and the image (the very subtractions the chain performs), records those choices in side[b], bumps
+//       *repairs and walks the run again -- only until sixteen consecutive choices of one group equal the entries already
+//       there: from that point the old chain was in the same state, and everything it wrote after is what this one would write.
+// The host repeats MODE 1 until a launch repairs nothing: in such a launch nothing was written, every side[b] equalled the map,
+// and by induction over b (run 0 starts from the true zero queue) the map is the reference's chain.  Exact by construction.
+struct DitherSeg {
+    unsigned S;                      // runs (1 = the whole image in one chain, no warm-up, no side records)
+    unsigned warm;                   // in-image pixels of warm-up
+    unsigned *side;                  // [S][16] choices the run's starting state was built from (0xFFFFFFFF = no record)
+    unsigned *repairs;               // bumped by every MODE-1 wavefront that had to walk its run again
+};
+
+// One wavefront walks one chain; every instruction of the chain is issued by that one wavefront (~2.5 ns each), so the count of
 // instructions per pixel is what matters.
 //
 // Error sums, systolic: the reference forms, for every pixel, e = q[0] w[0] + ... + q[15] w[15] in that order over the last sixteen
@@ -849,7 +898,8 @@ __device__ __forceinline__ unsigned dither_rows2(const double d0, const double b
 // (term 0, weight w[0]) and takes one term per step, as each later error vector appears, so that after step d - 1 all sixteen
 // terms are in, added in the reference's order.  Every step is then ONE multiply and ONE add in all lanes at once (each lane
 // with the weight of its own phase), and the finished sum of the current pixel is read from the lane whose turn it is.
-// Sixteen steps are unrolled so that phases and lanes are compile-time constants.
+// Sixteen steps are unrolled so that phases and lanes are compile-time constants.  (Step numbers are the chain's own: a chain that
+// starts mid-curve counts from its first pixel, and drops up to fifteen pixels so that its warm-up is whole groups of sixteen.)
 //
 // Pixels: blocks of 64 curve positions are decoded and loaded by the 64 lanes in parallel; the in-image ones are appended, in
 // order, to a ring in LDS and consumed sixteen at a time (the last group may be short), so edges need no second code path.
@@ -859,10 +909,10 @@ __device__ __forceinline__ unsigned dither_rows2(const double d0, const double b
 // GT: the palette tables are in global memory (K > 3200).  A template parameter and not a run-time choice of pointer: the chosen
 // colour is read once per pixel ON the serial chain, and through a pointer that may be either space the compiler issues a FLAT load
 // (both address paths, vmcnt and lgkmcnt waited for) where the LDS table needs a ds_read_b64.
-template <typename OutT, int PER, bool GT>
+template <typename OutT, int PER, bool GT, int MODE>
 __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, size_t plane_stride, unsigned width, unsigned height,
                                                const double *__restrict__ pal /* planar (k,3), linear Rec2020 */, int k,
-                                               OutT *__restrict__ out, DitherWeights wts, double *gtab) {
+                                               OutT *out, DitherWeights wts, double *gtab, DitherSeg sg) {
     extern __shared__ double lds[];
     constexpr int kRing = 128;                                       // >= 64 + 15 pending pixels
     // the two palette tables live in LDS; a palette too large for that (K > 3200; the reference takes any K,
@@ -874,6 +924,7 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
     unsigned int *rpos = reinterpret_cast<unsigned int *>(rpx + 3 * kRing);   // [kRing] their linear pixel numbers
     const int lane = threadIdx.x;
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
+    // (GT: every block stores the same values to the shared tables -- a benign race)
     for (int j = lane; j < k; j += 64)
         for (int c = 0; c < 3; c++) { const double a = pal[c * k + j]; praw[c * k + j] = a; pwt[c * k + j] = a * fw[c]; }
     __threadfence_block();                                           // (the tables may be global memory)
@@ -958,12 +1009,40 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
         return __builtin_amdgcn_readlane(bj, wave_argmin_nonneg_f64(bd));
     };
 
-    unsigned head = 0, count = 0;                                    // ring positions (absolute); head is a multiple of 16
+    // ---- this wavefront's stretch of the curve: [d_begin, d_start) warm-up, [d_start, d_end) its own run ----
+    const unsigned long long total = 1ULL << (2 * L);
+    const unsigned long long npix = (unsigned long long)width * height;
+    const unsigned b = MODE == 0 ? blockIdx.x : blockIdx.x + 1u;
+    unsigned long long d_begin = 0, d_start = 0, d_end = total;
+    unsigned head = 16, count = 16;                                  // ring positions (absolute); head is a multiple of 16
+    unsigned *const side = sg.S > 1 ? sg.side + 16u * b : nullptr;
+    if (sg.S > 1) {
+        unsigned long long c_start = 0, c_begin = 0, cc;
+        if (b > 0) dither_locate(L, width, height, npix * b / sg.S, d_start, c_start);
+        if (b + 1 < sg.S) dither_locate(L, width, height, npix * (b + 1) / sg.S, d_end, cc);
+        d_begin = d_start;
+        if (b > 0) {
+            // MODE 0: the warm-up; MODE 1: just the sixteen pixels before the run (their positions end up in the ring)
+            const unsigned long long back = MODE == 0 ? sg.warm : 16u;
+            dither_locate(L, width, height, c_start > back ? c_start - back : 0, d_begin, c_begin);
+            const unsigned cw = (unsigned)(c_start - c_begin);
+            if constexpr (MODE == 0) {
+                count = 16u - (cw & 15u);                            // drop cw mod 16 pixels: the warm-up ends with a whole group
+                if (lane < 16) side[lane] = 0xFFFFFFFFu;             // (stays if the warm-up is shorter than one group)
+            } else {
+                count = 0; head = 0;
+            }
+        }
+    }
+
+    bool done = false;                                               // MODE 1: the old chain has been met
     // up to sixteen pending pixels, in order; `limit` < 16 only for the very last group
-    auto group = [&](const int limit) {
+    auto group = [&](const int limit, const bool warmup) {
         double pcs[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) pcs[j] = rpx[ch * kRing + ((head + (unsigned)j) & (kRing - 1))];
+        unsigned was = 0, wpos = 0;
+        if (MODE == 1 && lane < limit) { wpos = rpos[(head + (unsigned)lane) & (kRing - 1)]; was = (unsigned)out[wpos]; }
         int res = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -977,30 +1056,33 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
                 acc = __builtin_fma(acc, keep[j], err * wl[j]);
             }
         }
-        if (lane < limit) out[rpos[(head + (unsigned)lane) & (kRing - 1)]] = (OutT)res;
+        if constexpr (MODE == 0) {
+            if (warmup) { if (lane < 16) side[lane] = (unsigned)res; }                           // the last group's stay
+            else if (lane < limit) out[rpos[(head + (unsigned)lane) & (kRing - 1)]] = (OutT)res;
+        } else {
+            if (lane < limit) out[wpos] = (OutT)res;
+            if (limit == 16 && __all(lane >= 16 || was == (unsigned)res)) done = true;
+        }
         head += 16;
     };
 
-    const unsigned long long total = 1ULL << (2 * L);
     const double *pr = img, *pg = img + plane_stride, *pb = img + 2 * plane_stride;
     // A block of 64 aligned curve positions is an 8 x 8 sub-square: the lane's place inside it (levels 0..2 of the curve) never
     // changes, and the levels above act on it as ONE signed permutation + offset per block, worked out on scalars.
     unsigned xl = 0, yl = 0;
     hilbert_d2xy(3, (unsigned long long)lane, xl, yl);
     const bool needs_skip = width < (1u << L) || height < (1u << L);
-    unsigned long long d0 = 0;
-    while (d0 < total) {
+    // decode the block of 64 positions at d0 and append its in-image pixels to the ring; false = an empty aligned square was skipped
+    auto load_block = [&](unsigned long long &d0) -> bool {
         if (L >= 3 && needs_skip) {                                  // skip whole out-of-image aligned sub-squares
-            bool skipped = false;
             for (int j = L; j >= 3; j--) {
                 const unsigned long long span = 1ULL << (2 * j);
                 if ((d0 & (span - 1)) != 0) continue;
                 unsigned x0, y0;
                 hilbert_d2xy(L, d0, x0, y0);
                 x0 &= ~((1u << j) - 1u); y0 &= ~((1u << j) - 1u);
-                if (x0 >= width || y0 >= height) { d0 += span; skipped = true; break; }
+                if (x0 >= width || y0 >= height) { d0 += span; return false; }
             }
-            if (skipped) continue;
         }
         const unsigned long long dl = d0 + (unsigned long long)lane;
         unsigned x = 0, y = 0;
@@ -1039,35 +1121,66 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
         }
         count += (unsigned)__popcll(mask);
         __builtin_amdgcn_wave_barrier();
-        while (count - head >= 16u) group(16);
         d0 += 64;
+        return true;
+    };
+
+    unsigned long long d0 = d_begin;
+    if constexpr (MODE == 1) {
+        // the sixteen in-image pixels before the run: at most 16 + 63 pixels lie between d_begin and d_start
+        while (d0 < d_start) load_block(d0);
+        const unsigned slot = (count - 16u + (unsigned)dph) & (kRing - 1);
+        const unsigned cur = (unsigned)out[rpos[slot]];              // every lane: the choice the map holds for predecessor dph
+        const bool same = __all(lane >= 16 || cur == side[lane & 15]);
+        if (same) return;                                            // the run was started from the true state
+        if (lane < 16) side[lane] = cur;
+        if (lane == 0) atomicAdd(sg.repairs, 1u);
+        // the queue as the chain holds it after those sixteen steps: their error vectors pushed in order into zero sums -- lane
+        // (c, d) restarts at step d, so whatever it summed before never reaches a pixel
+        const double ev = rpx[ch * kRing + slot] - prw[cur];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double e = __shfl(ev, (lane & 48) | j, 64);
+            acc = __builtin_fma(acc, keep[j], e * wl[j]);
+        }
+        head = count = 16;
+        __builtin_amdgcn_wave_barrier();
     }
-    if (count != head) group((int)(count - head));
+    while (d0 < d_end && !done) {
+        const bool warmup = d0 < d_start;
+        if (!load_block(d0)) continue;
+        while ((int)(count - head) >= 16 && !done) group(16, warmup);
+    }
+    if (count != head && !done) group((int)(count - head), false);
 }
 
+struct DitherConfig { int segments = 0, warm = -1; };                // 0 / -1 = chosen by launch_dither
+static DitherConfig g_dither_cfg;
+void dither_config(int segments, int warm) { g_dither_cfg.segments = segments; g_dither_cfg.warm = warm; }
+
 template <typename OutT>
-static void launch_dither_t(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k, OutT *out,
-                            const DitherWeights &wts, size_t lds, double *gtab, hipStream_t s) {
-#define PAMD_DITHER(PER)                                                                                                       \
+static void launch_dither_t(int mode, unsigned blocks, const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal,
+                            int k, OutT *out, const DitherWeights &wts, size_t lds, double *gtab, const DitherSeg &sg, hipStream_t s) {
+#define PAMD_DITHER1(PER, GT, MODE)                                                                                            \
     do {                                                                                                                       \
-        if (gtab) {                                                                                                            \
-            HIP_CHECK(hipFuncSetAttribute((const void *)(k_dither<OutT, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((k_dither<OutT, 0, true>), 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts, gtab); \
-            break;                                                                                                             \
-        }                                                                                                                      \
-        HIP_CHECK(hipFuncSetAttribute((const void *)(k_dither<OutT, PER, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_dither<OutT, PER, false>), 1, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts, gtab); \
+        HIP_CHECK(hipFuncSetAttribute((const void *)(k_dither<OutT, PER, GT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_dither<OutT, PER, GT, MODE>), blocks, 64, lds, s, d_img, plane_stride, (unsigned)width, (unsigned)height, d_pal, k, out, wts, gtab, sg); \
     } while (0)
-    if (k <= 64) PAMD_DITHER(1);
-    else if (k <= 128) PAMD_DITHER(2);
-    else if (k <= 256) PAMD_DITHER(4);
-    else PAMD_DITHER(0);
+#define PAMD_DITHER(PER, GT)                                                                                                   \
+    do { if (mode == 0) PAMD_DITHER1(PER, GT, 0); else PAMD_DITHER1(PER, GT, 1); } while (0)
+    if (gtab) PAMD_DITHER(0, true);
+    else if (k <= 64) PAMD_DITHER(1, false);
+    else if (k <= 128) PAMD_DITHER(2, false);
+    else if (k <= 256) PAMD_DITHER(4, false);
+    else PAMD_DITHER(0, false);
 #undef PAMD_DITHER
+#undef PAMD_DITHER1
 }
 
 void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
                    void *d_out, int elem_bytes, NNWork &w, hipStream_t s) {
     if (width * height >> 32) throw HipError("patolette_amd: the dither kernel numbers pixels with 32 bits");
+    if (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8) throw HipError("patolette_amd: map element size must be 1, 4 or 8");
     size_t lds = ((size_t)6 * k + 3 * 128) * sizeof(double) + 128 * sizeof(unsigned int);      // palette (raw + weighted) + the ring of pending pixels
     double *gtab = nullptr;
     if (lds > 150 * 1024) {                                      // K > 3200: the tables in global memory (workspace kept with the engine)
@@ -1081,15 +1194,65 @@ void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_
         double v = 1;
         for (int i = 0; i < 16; i++) { wts.w[i] = v / 16.0; v *= m; }
     }
-    KTIME("k_dither", s, (24.0 + elem_bytes) * width * height);
-    if (elem_bytes == 1) launch_dither_t<unsigned char>(d_img, plane_stride, width, height, d_pal, k, (unsigned char *)d_out, wts, lds, gtab, s);
-    else if (elem_bytes == 4) launch_dither_t<unsigned int>(d_img, plane_stride, width, height, d_pal, k, (unsigned int *)d_out, wts, lds, gtab, s);
-    else if (elem_bytes == 8) launch_dither_t<unsigned long long>(d_img, plane_stride, width, height, d_pal, k, (unsigned long long *)d_out, wts, lds, gtab, s);
-    else throw HipError("patolette_amd: map element size must be 1, 4 or 8");
-    HIP_CHECK(hipGetLastError());
+    // Runs: two wavefronts per SIMD fill the issue slots of the chip (one chain alone uses ~2/3 of its SIMD's); never shorter than
+    // the warm-up -- below that the speculative steps outnumber the useful ones.
+    const size_t npix = width * height;
+    DitherConfig cfg = g_dither_cfg;
+    if (const char *e = getenv("PAMD_DITHER_SEGMENTS")) cfg.segments = atoi(e);
+    if (const char *e = getenv("PAMD_DITHER_WARM")) cfg.warm = atoi(e);
+    DitherSeg sg{};
+    sg.warm = cfg.warm >= 0 ? (unsigned)cfg.warm : 1024u;
+    size_t S = cfg.segments > 0 ? (size_t)cfg.segments : (size_t)num_cus() * 8;
+    if (cfg.segments <= 0) S = std::min(S, npix / std::max<size_t>(sg.warm, 256));
+    S = std::min(S, npix / 128);                                 // every run after the first has its sixteen predecessors
+    if (std::max(width, height) < 16) S = 1;
+    if (S < 1) S = 1;
+    sg.S = (unsigned)S;
+    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0;
+    if (S > 1) {
+        w.dside.reserve(16 * S + 16);
+        w.hrep.reserve(1);
+        sg.side = w.dside.p;
+        sg.repairs = w.dside.p + 16 * S;
+        HIP_CHECK(hipMemsetAsync(sg.repairs, 0, sizeof(unsigned), s));
+    }
+    auto launch = [&](int mode, unsigned blocks) {
+        if (elem_bytes == 1) launch_dither_t<unsigned char>(mode, blocks, d_img, plane_stride, width, height, d_pal, k, (unsigned char *)d_out, wts, lds, gtab, sg, s);
+        else if (elem_bytes == 4) launch_dither_t<unsigned int>(mode, blocks, d_img, plane_stride, width, height, d_pal, k, (unsigned int *)d_out, wts, lds, gtab, sg, s);
+        else launch_dither_t<unsigned long long>(mode, blocks, d_img, plane_stride, width, height, d_pal, k, (unsigned long long *)d_out, wts, lds, gtab, sg, s);
+        HIP_CHECK(hipGetLastError());
+    };
+    {
+        KTIME("k_dither", s, (24.0 + elem_bytes) * width * height);
+        launch(0, (unsigned)S);
+    }
+    if (S == 1 || std::max(width, height) <= 1) return;
+    // verify every boundary, walk the runs whose starting state was not the true one again, until a pass finds nothing to do
+    for (size_t round = 0;; round++) {
+        if (round > S) throw HipError("patolette_amd: the dither's boundary repairs did not settle");
+        {
+            KTIME("k_dither_fix", s, 0.0);
+            launch(1, (unsigned)S - 1);
+        }
+        HIP_CHECK(hipMemcpyAsync(w.hrep.p, sg.repairs, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        const unsigned r = *w.hrep.p;
+        w.dither_rounds = round + 1;
+        if (r == 0) break;
+        w.dither_repairs += r;
+        HIP_CHECK(hipMemsetAsync(sg.repairs, 0, sizeof(unsigned), s));
+    }
 }
 
 }  // namespace pamd
+
+// host-side view of the run boundaries (the same function the kernel calls), for the CPU tests
+extern "C" void patolette_amd_debug_dither_locate(size_t width, size_t height, unsigned long long t, unsigned long long *d, unsigned long long *c) {
+    const size_t mxd = width > height ? width : height;
+    int L = 0;
+    while (((size_t)1 << L) < mxd) L++;
+    pamd::dither_locate(L, (unsigned)width, (unsigned)height, t, *d, *c);
+}
 
 #ifdef PAMD_KM_TRACE
 extern "C" int patolette_amd_debug_nn_trace(unsigned long long *out) {
