@@ -432,8 +432,6 @@ def main():
     n = width * height
     S = max(1, args.streams)
     S2 = max(0, args.extra_streams)
-    if dither and n > (1 << 24):
-        S2 = 0                                  # the serial dither chain of a 67 MP image takes tens of seconds
     pool = max(S, min(S2, 3), min(3, args.steps))        # distinct images; more in flight than that re-use them (read-only)
     d_imgs, d_wts = [], []
     for i in range(pool):
@@ -674,11 +672,9 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         from oracle import binding as ob
         ncores = os.cpu_count() or 1
-        sw, sh = width, height                                # the full workload for the default config (~10 + ~17 s)
-        if n > 4096 * 4096:
-            sw, sh = 4096, 4096
-        if dither and n > 1024 * 1024:
-            sw, sh = 1024, 1024
+        sw, sh = width, height                                # the full workload (default config: ~10 + ~17 s; c4 / c4map: ~1 min a run)
+        if n > 4096 * 4096 and niter > 0 and max_samples > 512 ** 2:
+            sw, sh = 4096, 4096                               # c4km: eight Lloyd iterations over 67 M samples take the CPU many minutes
         sn = sw * sh
         flat = ob.image(sn, 0)
         wt = ob.weights(sn, 0) if weighted is True else None
@@ -720,13 +716,16 @@ def main():
             parity = {"note": "the oracle derives its own saliency weights (unpinned restatement): no comparison in this run; see tests/test_gpu_saliency.py"}
         scale = "the full %dx%d workload" % (sw, sh) if sn == n else "%dx%d of the same workload (the %dx%d image would take %.0fx as long)" % (sw, sh, width, height, n / sn)
         if dither:
-            # the stage that is 99.8 % of this configuration, side by side: the GPU's one-wavefront chain against the oracle's
-            # chain on one host core.  The oracle searches the palette by brute force (exact, 256 f64 distances per pixel); the
-            # reference's FLANN kd-tree (nearest.c:115-148) is not in this image and would be faster on the CPU side.
-            dither_cmp = {"gpu_ns_per_px": round(1e6 * stats["ms_map"] / n, 2), "gpu_pixels": n,
+            # the mapping stage side by side: the GPU's chain cut into runs walked by one wavefront each (speculative warm-up,
+            # verified boundaries, repairs: map.hip DitherSeg) against the oracle's one chain on one host core.  The oracle
+            # searches the palette by brute force (exact, 256 f64 distances per pixel); the reference's FLANN kd-tree
+            # (nearest.c:115-148) is not in this image and would be faster on the CPU side.
+            dither_cmp = {"gpu_ns_per_px": round(1e6 * stats["ms_map"] / n, 3), "gpu_pixels": n, "gpu_ms_map": round(stats["ms_map"], 3),
+                          "runs": stats.get("dither_segments"), "repairs": stats.get("dither_repairs"), "verification_passes": stats.get("dither_rounds"),
                           "cpu_ns_per_px_one_core": round(1e9 * st_one["map"] / sn, 2), "cpu_pixels": sn,
-                          "note": "GPU: ms_map of the last timed step / pixels (palette conversion + Riemersma chain); CPU: the oracle's map stage "
-                                  "(brute-force exact nearest colour, single thread, serial by construction) on a %dx%d crop-sized image" % (sw, sh)}
+                          "note": "GPU: ms_map of the last timed step / pixels (pixel + palette conversion to linear Rec2020, the Riemersma runs and their "
+                                  "boundary checks); CPU: the oracle's map stage (brute-force exact nearest colour, single thread, serial by construction) "
+                                  "on the %dx%d image" % (sw, sh)}
         cpu = {"value": round(sn / dt_all / 1e6, 4), "unit": "Mpx/s", "cores": ncores, "kind": "port",
                "sample": "oracle (plain-C restatement of the reference path; KMeans assign/update and the NN map on %d threads as faiss / FLANN "
                          "thread them, everything else single-threaded as in the reference) on %s, %.1f s; stages %s" % (ncores, scale, dt_all, st_all),

@@ -1867,9 +1867,9 @@ static void batch_run(size_t count, size_t width, size_t height, const patolette
     if (hipGetDevice(&device) != hipSuccess) { for (size_t i = 0; i < count; i++) exit_codes[i] = -1; return; }
     if (engine().device >= 0) device = engine().device;
     // Images in flight: six keep the GPU busy through the host round trips between an image's split rounds (device-resident
-    // 4096^2 images, one MI355X: 2960 Mpx/s one at a time, 3330 / 3410 / 3740 / 3990 / 3880 with 2 / 3 / 4 / 6 / 8 in flight).  With
-    // the Riemersma dither each image ends in a serial chain that occupies ONE wavefront for seconds, so many more are kept in
-    // flight (one chain per CU runs concurrently).  Both bounded by the free HBM: an engine's workspace is ~170 bytes per pixel.
+    // 4096^2 images, one MI355X: 2960 Mpx/s one at a time, 3330 / 3410 / 3740 / 3990 / 3880 with 2 / 3 / 4 / 6 / 8 in flight).  The
+    // Riemersma dither fills the GPU by itself since it is cut into runs (map.hip DitherSeg), so dithered batches keep the same
+    // number in flight.  Bounded by the free HBM: an engine's workspace is ~170 bytes per pixel.
     const size_t base_flight = getenv("PAMD_BATCH_FLIGHT") ? std::max<size_t>(1, (size_t)atoll(getenv("PAMD_BATCH_FLIGHT"))) : 6;
     size_t workers = std::min<size_t>(count, base_flight);
     if (count > 1) {
@@ -1877,12 +1877,13 @@ static void batch_run(size_t count, size_t width, size_t height, const patolette
         (void)hipSetDevice(device);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t per_engine = (size_t)(170.0 * (double)width * (double)height) + ((size_t)64 << 20);
-            size_t idle = 0;                                     // pooled engines already hold their workspace
-            { std::lock_guard<std::mutex> lk(g_pool_mu); for (Engine *e : g_pool) if (e->device == device) idle++; }
+            size_t idle = 0;                                     // pooled engines whose workspace already covers this image size
+            {
+                std::lock_guard<std::mutex> lk(g_pool_mu);
+                for (Engine *e : g_pool) if (e->device == device && e->cvt.cap >= 3 * width * height) idle++;
+            }
             const size_t fit = idle + free_b / 2 / per_engine;   // leave half of what is free alone
-            const bool chains = options->dither && !options->palette_only;
-            workers = std::min<size_t>(count, std::max<size_t>(1, std::min<size_t>(fit, chains ? 48 : base_flight)));
-            if (chains) workers = std::max(workers, std::min<size_t>(count, 3));
+            workers = std::min<size_t>(count, std::max<size_t>(1, std::min<size_t>(fit, base_flight)));
         }
     }
     std::atomic<size_t> next{0};
