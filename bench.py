@@ -137,6 +137,29 @@ def north_star_kernels(L, native):
         L.patolette_amd_synchronize()
         prof = native.profile_results()
         native.profile(False)
+        # the palette-map kernel once more on BASELINE configs[3]'s own geometry (`c4map`: CIELuv + weights, no KMeans): its palette
+        # leaves more cells of the kernel's 32^3 table with five or more candidates than a KMeans-refined ICtCp palette does
+        prof_c4map = None
+        wt = L.patolette_amd_malloc(n * 8)
+        if wt:
+            try:
+                assert L.patolette_amd_fill_weights(wt, n, 77) == 0
+                _, _, K2, cs2, niter2, ms2, dither2, _, _ = CONFIGS["c4map"]
+                opts2 = native.QuantizationOptions(dither2, False, cs2, niter2, ms2, False)
+
+                def two():
+                    L.patolette_amd_device(width, height, img, wt, K2, C.byref(opts2), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+                    if code.value != 0:
+                        raise RuntimeError("bench.py: c4map step failed: %s" % native.last_error())
+                two()
+                native.profile(True)
+                for _ in range(steps):
+                    two()
+                L.patolette_amd_synchronize()
+                prof_c4map = native.profile_results()
+                native.profile(False)
+            finally:
+                L.patolette_amd_free(wt)
     finally:
         L.patolette_amd_free(img)
         L.patolette_amd_free(dmap)
@@ -149,8 +172,10 @@ def north_star_kernels(L, native):
     # beside the HBM fraction: vector instructions per launch (SQ_INSTS_VALU of the kept rocprofv3 --pmc pass, profiles/) x 4 cycles
     # per wave64 instruction on a 16-lane SIMD / (1024 SIMDs x the launch time measured here x the 2.4 GHz peak engine clock)
     valu = {}
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         sq = os.path.join(ROOT, "profiles", "%s_c4km_sq_counters.txt" % tag)
+        if not os.path.exists(sq):
+            continue
         if os.path.exists(sq):
             for ln in open(sq):
                 f = ln.split()
@@ -171,17 +196,25 @@ def north_star_kernels(L, native):
             out[name]["valu_frac"] = round(valu[name][0] * 4.0 / (1024.0 * avg_ms * 1e-3 * 2.4e9), 3)
             out[name]["valu_insts_per_launch"] = valu[name][0]
             out[name]["valu_source"] = "profiles/%s (SQ_INSTS_VALU, a separate rocprofv3 --pmc pass, not this run)" % valu[name][1]
+    r = (prof_c4map or {}).get("k_nn_map")
+    if r and r["launches"]:
+        avg_ms = r["total_ms"] / r["launches"]
+        gbs = r["bytes"] / r["launches"] / (avg_ms * 1e-3) / 1e9
+        out["k_nn_map_c4map"] = {"config": CONFIGS["c4map"][8], "avg_us": round(avg_ms * 1e3, 2), "launches": r["launches"],
+                                 "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"], 1)}
     return out
 
 
-def content_times(L, native, cfg):
-    """The timed region runs on uniform noise (what BASELINE.json asks for) -- the best case of the LDS histograms and of the
-    centroid chains.  Here the SAME configuration once each on content a photograph is closer to, device-resident like `value`,
-    outside the timed region and never part of `value`: a smooth synthetic scene with saturated blobs and mild noise, the same
-    scene posterised to eight levels per channel (a handful of distinct colours: 64 lanes adding to one histogram bucket), and
-    noise with one colour covering 30 % of the image (one very long centroid chain)."""
+CONTENT_PARITY_SIZE = (1536, 1024)          # the size at which the content workloads are held to the oracle (seconds of CPU each)
+
+
+def content_images(width, height):
+    """The three non-noise workloads of the `content` record, as planar f64 host arrays (name, pixels), one at a time: a smooth
+    synthetic scene with saturated blobs and mild noise, the same scene posterised to eight levels per channel (a handful of
+    distinct colours: 64 lanes adding to one histogram bucket), and noise with one colour covering 30 % of the image (one very
+    long centroid chain).  tests/test_gpu_content.py holds the same generator's images to the oracle."""
     import numpy as np
-    width, height, K, cs, niter, max_samples, dither, weighted, _ = cfg
     n = width * height
     rng = np.random.default_rng(4)
     yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
@@ -198,6 +231,87 @@ def content_times(L, native, cfg):
     for j, pl in enumerate(planes):
         scene[j * n:(j + 1) * n] = np.clip(pl.reshape(-1).astype(np.float64) + rng.normal(0.0, 0.02, n), 0.0, 1.0)
     del planes
+    yield "scene", scene
+    yield "posterised", np.round(scene * 7.0) / 7.0
+    del scene
+    noise = rng.random(3 * n)
+    m = int(0.3 * n)
+    for j, v in enumerate((0.1, 0.2, 0.7)):
+        noise[j * n:j * n + m] = v + 0.004 * rng.standard_normal(m)
+    yield "dominant30", np.clip(noise, 0.0, 1.0)
+
+
+def content_parity(L, native, ob, cfg, host, width, height):
+    """One content image through the HIP path (device-resident entry, the configuration's options) and through the oracle.
+    What is asserted in tests/test_gpu_content.py is reported here: palette rows (max relative difference, or the rows as a set
+    when their order differs), index-map mismatches, and -- the weakest form -- whether the two quantised IMAGES agree."""
+    import numpy as np
+    _, _, K, cs, niter, max_samples, dither, weighted, _ = cfg
+    n = width * height
+    d = L.patolette_amd_malloc(3 * n * 8)
+    dmap = L.patolette_amd_malloc(n)
+    if not d or not dmap:
+        return None
+    try:
+        assert L.patolette_amd_memcpy_h2d(d, host.ctypes.data_as(C.c_void_p), host.nbytes) == 0
+        opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+        pal = np.zeros((K, 3), dtype=np.float64, order="F")
+        code = C.c_int(0)
+        L.patolette_amd_device(width, height, d, None, K, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+        L.patolette_amd_synchronize()
+        if code.value != 0:
+            return {"note": "HIP path exit code %d" % code.value}
+        m8 = np.empty(n, dtype=np.uint8)
+        assert L.patolette_amd_memcpy_d2h(m8.ctypes.data_as(C.c_void_p), dmap, n) == 0
+    finally:
+        L.patolette_amd_free(d)
+        L.patolette_amd_free(dmap)
+    ob.set_threads(os.cpu_count() or 1)
+    try:
+        ec, pal_o, map_o = ob.patolette(width, height, host, None, K, dither=dither, color_space=cs, kmeans_niter=niter, kmeans_max_samples=max_samples)
+    finally:
+        ob.set_threads(1)
+    if ec != 0:
+        return {"note": "oracle exit code %d" % ec}
+    return compare_results(pal, m8.astype(np.int64), np.asarray(pal_o), np.asarray(map_o).astype(np.int64), "%dx%d" % (width, height))
+
+
+def compare_results(pal, pmap, pal_o, map_o, size):
+    """HIP result against the oracle's, strongest statement first."""
+    import numpy as np
+    used, used_o = pal[:, 0] != -1.0, pal_o[:, 0] != -1.0
+    rec = {"size": size, "palette_rows": int(used.sum()), "palette_rows_oracle": int(used_o.sum())}
+    same_rows = bool(np.array_equal(used, used_o))
+    scale = max(1e-300, float(np.max(np.abs(pal_o[used_o])))) if used_o.any() else 1.0
+    rec["palette_max_rel"] = float(np.max(np.abs(pal[used] - pal_o[used_o])) / scale) if same_rows and used.any() else None
+    rec["map_mismatches"] = int(np.count_nonzero(pmap != map_o))
+    if rec["palette_max_rel"] is not None and rec["palette_max_rel"] <= 1e-9 and rec["map_mismatches"] == 0:
+        rec["verdict"] = "identical: palette rows in the reference's order within 1e-9 relative, index map bit for bit"
+        return rec
+    rows_g = sorted(map(tuple, np.round(pal[used], 9).tolist()))
+    rows_o = sorted(map(tuple, np.round(pal_o[used_o], 9).tolist()))
+    rec["palette_equal_as_a_set"] = rows_g == rows_o
+    rec["palette_rows_differing"] = int(len(set(rows_g) ^ set(rows_o)) // 2) if len(rows_g) == len(rows_o) else None
+    img_diff = float(np.max(np.abs(pal[pmap] - pal_o[map_o])))
+    rec["quantised_image_max_abs_diff"] = img_diff
+    rec["quantised_image_mean_sq_diff"] = float(np.mean((pal[pmap] - pal_o[map_o]) ** 2))
+    if rows_g == rows_o and img_diff <= 1e-9:
+        rec["verdict"] = "same palette as a set and same quantised image; the ORDER of the rows differs"
+    elif img_diff <= 1e-9:
+        rec["verdict"] = "same quantised image; palette rows differ where clusters are empty or tied"
+    else:
+        rec["verdict"] = "differs: see DESIGN.md 2 (cut decisions of the reference that hinge on the rounding of sequential f64 sums)"
+    return rec
+
+
+def content_times(L, native, cfg, ob=None):
+    """The timed region runs on uniform noise (what BASELINE.json asks for) -- the best case of the LDS histograms and of the
+    centroid chains.  Here the SAME configuration once each on content a photograph is closer to (content_images), device-resident
+    like `value`, outside the timed region and never part of `value`.  With the oracle at hand each workload also carries a
+    `parity` record taken at CONTENT_PARITY_SIZE, where the oracle needs seconds."""
+    import numpy as np
+    width, height, K, cs, niter, max_samples, dither, weighted, _ = cfg
+    n = width * height
     d = L.patolette_amd_malloc(3 * n * 8)
     dmap = L.patolette_amd_malloc(n)
     if not d or not dmap:
@@ -240,17 +354,17 @@ def content_times(L, native, cfg):
             finally:
                 L.patolette_amd_set_kmeans_update(before)
     try:
-        run(scene, "scene")
-        run(np.round(scene * 7.0) / 7.0, "posterised")
-        del scene
-        noise = rng.random(3 * n)
-        m = int(0.3 * n)
-        for j, v in enumerate((0.1, 0.2, 0.7)):
-            noise[j * n:j * n + m] = v + 0.004 * rng.standard_normal(m)
-        run(np.clip(noise, 0.0, 1.0), "dominant30")
+        for name, host in content_images(width, height):
+            run(host, name)
+            del host
     finally:
         L.patolette_amd_free(d)
         L.patolette_amd_free(dmap)
+    if ob is not None:
+        pw, ph = CONTENT_PARITY_SIZE
+        for name, host in content_images(pw, ph):
+            if name in out:
+                out[name]["parity"] = content_parity(L, native, ob, cfg, host, pw, ph)
     return out
 
 
@@ -300,6 +414,76 @@ def host_to_host(L, native, cfg, reps=3):
     return {"value": round(n / best / 1e6, 2), "unit": "Mpx/s", "ms_per_image": round(best * 1e3, 3), "reps": reps,
             "entry": "patolette() (include/patolette.h), pageable host buffers, f64 planar in, size_t map out",
             "ms_upload": round(st["ms_upload"], 3), "ms_download": round(st["ms_download"], 3)}
+
+
+def small_image(L, native, reps=7):
+    """BASELINE configs[1] (1920x1080, 256 colours, ICtCp, KMeans off, dither off) device-resident like `value`: the size people
+    actually quantise, where the split loop's nine host round trips and ~70 launches weigh as much as its sweeps."""
+    import numpy as np
+    width, height, K, cs, niter, max_samples, dither, weighted, desc = CONFIGS["c2"]
+    n = width * height
+    d = L.patolette_amd_malloc(3 * n * 8)
+    dmap = L.patolette_amd_malloc(n)
+    if not d or not dmap:
+        return None
+    try:
+        assert L.patolette_amd_fill_image(d, n, 0) == 0
+        opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+        pal = np.zeros((K, 3), dtype=np.float64, order="F")
+        code = C.c_int(0)
+        times = []
+        for i in range(reps + 2):
+            L.patolette_amd_synchronize()
+            t0 = time.perf_counter()
+            L.patolette_amd_device(width, height, d, None, K, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+            L.patolette_amd_synchronize()
+            if code.value != 0:
+                return None
+            if i >= 2:
+                times.append(time.perf_counter() - t0)
+        st = native.last_stats()
+    finally:
+        L.patolette_amd_free(d)
+        L.patolette_amd_free(dmap)
+    med = sorted(times)[len(times) // 2]
+    return {"config": desc, "ms": round(1e3 * med, 3), "value": round(n / med / 1e6, 1), "unit": "Mpx/s", "reps": reps,
+            "stages_ms": {k: round(v, 3) for k, v in st.items() if k.startswith("ms_") and v}, "lq_rounds": st["lq_rounds"]}
+
+
+def host_to_host_u8(L, native, cfg, reps=3):
+    """The path a caller of the reference actually takes (README.md:147-158, 184-194: an 8-bit image in, an indexed image out)
+    through the 8-bit adaptor `patolette_amd_u8`: pageable (H, W, 3) u8 pixels in, u8 index map + u8 palette
+    out, PCIe copies included -- 3 B/px up and 1 B/px down instead of 24 + 8.  Without saliency weights (tile_size = 0, what
+    `value` computes) and with them derived on the device (tile_size = 512, the reference's Python default).  Never `value`."""
+    import numpy as np
+    width, height, K, cs, niter, max_samples, dither, weighted, _ = cfg
+    n = width * height
+    img = np.random.default_rng(55).integers(0, 256, size=(height, width, 3), dtype=np.uint8)
+    opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
+    pal = np.zeros((K, 3), dtype=np.float64, order="F")
+    pal8 = np.zeros((K, 3), dtype=np.uint8)
+    pmap = np.zeros(n, dtype=np.uint8 if K <= 256 else np.uint32)
+    code = C.c_int(0)
+    out = {"entry": "patolette_amd_u8() (include/patolette_amd.h), pageable host buffers, (H,W,3) u8 in, %s index map + u8 palette out" % pmap.dtype,
+           "reps": reps}
+    for tile in (0.0, 512.0):
+        times = []
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            L.patolette_amd_u8(width, height, img.ctypes.data_as(C.c_void_p), 3, None, C.c_double(tile), K, C.byref(opts),
+                               pal.ctypes.data_as(native.dp), pal8.ctypes.data_as(C.c_void_p), pmap.ctypes.data_as(C.c_void_p),
+                               pmap.dtype.itemsize, None, C.byref(code))
+            dt = time.perf_counter() - t0
+            if code.value != 0:
+                return None
+            if i > 0:
+                times.append(dt)
+        st = native.last_stats()
+        best = sorted(times)[len(times) // 2]
+        out["tile_size_%d" % int(tile)] = {"value": round(n / best / 1e6, 2), "unit": "Mpx/s", "ms_per_image": round(best * 1e3, 3),
+                                           "ms_upload": round(st["ms_upload"], 3), "ms_download": round(st["ms_download"], 3),
+                                           "ms_saliency": round(st["ms_saliency"], 3)}
+    return out
 
 
 def parity_record(L, native, cfg, d_img, d_wt, pal_timed, res_all, res_one, ob):
@@ -657,10 +841,15 @@ def main():
                     "time_share": round(kernels.get(dom, {"ms_per_step": 0.0})["ms_per_step"] / max(1e-9, sum(v["ms_per_step"] for v in kernels.values())), 3)}
 
     # ---- extras of the default run, all outside the timed region ----
-    ns_kernels = h2h = content = None
+    ns_kernels = h2h = h2h_u8 = content = small = None
     if not args.no_extras and world == 1 and args.config == "c3":
+        small = small_image(L, _native)
         h2h = host_to_host(L, _native, cfg)
-        content = content_times(L, _native, cfg)
+        h2h_u8 = host_to_host_u8(L, _native, cfg)
+        ob_c = None
+        if not args.no_cpu_baseline:                          # the oracle as the checker of the content workloads (never timed here)
+            from oracle import binding as ob_c
+        content = content_times(L, _native, cfg, ob_c)
         ns_kernels = north_star_kernels(L, _native)
 
     # ---- CPU baseline: the oracle (plain-C restatement of the reference path) on this host, same workload ----
@@ -754,7 +943,7 @@ def main():
                                     "TEST MODE --oversubscribe: %d ranks on %d device(s), gloo gather through host copies -- the N > 1 code path, not a scaling figure" % (world, L.patolette_amd_device_count())
                                     if args.oversubscribe else
                                     "RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region")},
-        "first_call": cold, "dither": dither_cmp, "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "host_to_host": h2h, "content": content, "throughput_concurrent": conc,
+        "first_call": cold, "dither": dither_cmp, "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "small_image": small, "host_to_host": h2h, "host_to_host_u8": h2h_u8, "content": content, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},

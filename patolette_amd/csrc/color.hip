@@ -182,11 +182,11 @@ void launch_convert_rows(int which, const double *rows, double *dst, size_t n, C
 }
 
 void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
-                       hipStream_t s, BinK sumk, BinK momk) {
-    if (stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
-    int g = stream_grid(n);
-    const size_t begin = 0, end = n;
-    KTIME("k_convert_u8", s, (24.0 + channels) * n);
+                       hipStream_t s, BinK sumk, BinK momk, size_t begin, size_t end, bool init_stats) {
+    if (end > n) end = n;
+    if (stats && init_stats) hipLaunchKernelGGL(k_init_stats, 1, 64, 0, s, stats);
+    int g = stream_grid(end - begin);
+    KTIME("k_convert_u8", s, (24.0 + channels) * (end - begin));
     const SrcU8 src{pixels, channels};
     switch (which) {
         case PAMD_SRGB_TO_ICTCP: hipLaunchKernelGGL((k_convert<PAMD_SRGB_TO_ICTCP, SrcU8>), g, 256, 0, s, src, dst, n, stats, sumk, momk, begin, end); break;

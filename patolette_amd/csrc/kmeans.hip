@@ -63,10 +63,22 @@ __device__ __forceinline__ float4 make_c4(float v0, float v1, float v2) {
 // The centroid table the assignment kernels read: c4[j] = (y0, y1, y2, |y|^2), and behind it (c4 + k) the same numbers pair by
 // pair -- entry p = {y0 of 2p, y0 of 2p+1, y1.., y1.., y2.., y2.., |y|^2.., |y|^2..} -- for the packed-f32 full scan.
 __device__ __forceinline__ void km_store_c4(float4 *c4, const int k, const int j, const float v0, const float v1, const float v2) {
+    // Write-through (agent-scope) stores: in the update kernels every centroid's block writes its own record, and after
+    // split_clusters the last block writes records again that another block -- possibly on another XCD, behind another L2 --
+    // wrote moments before.  Plain stores would leave two dirty copies of one line whose write-back order at the end of the
+    // kernel decides what the next assignment reads; these go to memory in program order (each block drains its stores before
+    // it takes its ticket, the last block writes after the last ticket).
     const float4 r = make_c4(v0, v1, v2);
-    c4[j] = r;
+    float *q = reinterpret_cast<float *>(c4 + j);
+    __hip_atomic_store(q, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 3, r.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float *pp = reinterpret_cast<float *>(c4 + k) + 8 * (j >> 1) + (j & 1);
-    pp[0] = r.x; pp[2] = r.y; pp[4] = r.z; pp[6] = r.w;
+    __hip_atomic_store(pp, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pp + 2, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pp + 4, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pp + 6, r.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // flags (kKmFlagWords words, the list path of the default 512^2 samples): [0] = the iterations have reached a fixed point (no sample
 // changed its centroid in the last assignment and no cluster was re-seeded: every later iteration reproduces the same centroids bit
@@ -2186,6 +2198,10 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
     const size_t list_longest = getenv("PAMD_KM_LIST_LONGEST") ? (size_t)atoll(getenv("PAMD_KM_LIST_LONGEST")) : (size_t)16384;
     const bool use_direct = !sums && !use_lut && k <= 256 && nx <= direct_max && nx < ((size_t)1 << 32) && expect_longest < list_longest;
     if (use_direct) {
+        // k_km_assign_sort keeps each sample's previous centroid as ONE BYTE in w.assign (k <= 256 on this path, above) and marks
+        // flags[1 + old] / flags[1 + new] when it changes.  k_km_prep has just set every flag (nothing is known about the first
+        // assignment), so the first iteration's `old` only has to be a valid byte: zeroed here rather than left as found.
+        HIP_CHECK(hipMemsetAsync(w.assign.p, 0, nx, s));
         static PerDeviceOnce attr4;
         if (attr4.first()) {
             HIP_CHECK(hipFuncSetAttribute((const void *)k_km_update_lists<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kKmDirectCap * 20));

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "devutil.h"
 
@@ -67,10 +68,36 @@ struct NNGrid {
 // 20-40 of the 256 entries.  A coarse cell keeps up to kCoarseMax entries; more than that marks it "all".
 constexpr int kCoarseMax = 96;
 template <typename CandT>
-__global__ __launch_bounds__(64) void k_nn_lut_coarse(const double *__restrict__ pal, int k, NNGrid g, CandT *__restrict__ clist /* [cells][1 + kCoarseMax] */) {
+__global__ __launch_bounds__(64) void k_nn_lut_coarse(const double *__restrict__ pal, int k, NNGrid g, CandT *__restrict__ clist /* [cells][1 + kCoarseMax] */,
+                                                       float4 *__restrict__ rec32 /* nullptr, or [257] for k_nn_map_mid */) {
     // one wavefront per coarse cell, lanes across the palette entries
     const int Gc = g.G / 4;
     const int cell = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (rec32 != nullptr && cell == 0) {
+        // the f32 records of k_nn_map_mid's first pass and its margin (see the table's comment): entry 256 = {M, 0, 0, 0}
+        double wmax = 0.0;
+        for (int j = lane; j < 256; j += 64) {
+            float4 r = make_float4(0.f, 0.f, 0.f, 3.0e38f);
+            if (j < k) {
+                const double a = pal[j] - g.lo[0], b = pal[k + j] - g.lo[1], c = pal[2 * k + j] - g.lo[2];
+                const double w = (a * a + b * b) + c * c;
+                wmax = fmax(wmax, w);
+                r = make_float4((float)(-2.0 * a), (float)(-2.0 * b), (float)(-2.0 * c), (float)w);
+            }
+            rec32[j] = r;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, o, 64));
+        if (lane == 0) {
+            double r2 = 0.0;
+            for (int a = 0; a < 3; a++) { const double r = g.cw[a] * g.G; r2 += r * r; }
+            const double M = 2.5 * 1.001 * 0x1.0p-24 * (9.0 * wmax + 5.0 * r2);
+            float Mf = (float)M;
+            if ((double)Mf < M) Mf = __uint_as_float(__float_as_uint(Mf) + 1u);       // rounded up
+            if (!(M < 3.0e38)) Mf = INFINITY;                                           // everything ambiguous: the exact loop decides
+            rec32[256] = make_float4(Mf, 0.f, 0.f, 0.f);
+        }
+    }
     const int idx[3] = {cell % Gc, (cell / Gc) % Gc, cell / (Gc * Gc)};
     double cl[3], ch[3];
 #pragma unroll
@@ -114,14 +141,23 @@ __global__ __launch_bounds__(64) void k_nn_lut_coarse(const double *__restrict__
 // --------------------------------------------------------------------------------------------
 // Large images: a (G/2)^3 table of FOUR-BYTE entries lives in LDS (32^3 x 4 B = 128 KB of the CU's 160 KB), so the
 // per-pixel lookup never leaves the CU -- on unsorted input the 16-byte records of the G^3 table are one random L2 line
-// per pixel and that gather, not HBM, bounded the kernel.  An entry holds up to four candidates in ascending order
-// (padded by repeating the last one; re-evaluating an entry cannot change a strict-'<' arg-min).  The rule that fills it
-// is the G^3 rule plus a bisector test against q* = the entry with the smallest maxdist: p is dropped when
-// |x-p|^2 - |x-q*|^2 > 0 on the whole (widened) box -- linear in x, so its minimum sits in a corner -- with a 1e-12
-// relative margin; a dropped entry is strictly farther than q* everywhere in the cell, so it can neither win nor tie.
-// About 90 % of the pixels of a noise image resolve there.  Cells with more than four survivors carry a marker
-// (byte 0 > byte 1, impossible for an ascending list); their pixels are queued per wavefront in LDS and taken 64 at a
-// time through the G^3 records, so that path runs with full wavefronts too.
+// per pixel and that gather, not HBM, bounded the kernel.  An entry holds FOUR DISTINCT candidates in ascending order.
+// The rule that fills it is the G^3 rule plus a bisector test against q* = the entry with the smallest maxdist: p is
+// dropped when |x-p|^2 - |x-q*|^2 > 0 on the whole (widened) box -- linear in x, so its minimum sits in a corner -- with
+// a 1e-12 relative margin; a dropped entry is strictly farther than q* everywhere in the cell, so it can neither win nor
+// tie.  A cell with fewer than four survivors is filled up with palette entries FAR from it (more candidates never change
+// an exact arg-min; distinct ones let the map kernel read "second smallest" off a 4-input min / max network).  About 90 %
+// of the pixels of a noise image resolve there.  Cells with more than four survivors carry a marker (byte 0 > byte 1,
+// impossible for an ascending list); their pixels are queued per wavefront in LDS and taken through the G^3 records.
+// The boxes of THIS table are widened by 1e-5 of the range: the map kernel finds its cell in f32 (below).
+//
+// Round 5: the first pass of k_nn_map_mid is f32.  Behind the table sit 256 records {-2 (p - lo), |p - lo|^2} rounded to
+// f32 (lo = the pixel box's corner: shifted coordinates keep the rounding relative to the box, not to the origin), and the
+// pixel's four candidates cost t_j = fma(xf0, q0, fma(xf1, q1, fma(xf2, q2, w))) = |x - p_j|^2 - |x - lo|^2 up to
+// E = 2^-24 (9 max_j |p_j - lo|^2 + 5 |hi - lo|^2) (1 + 1e-3): three instructions instead of eight f64 ones, one
+// ds_read_b128 instead of three ds_read_b64.  The smallest t names the winner of the f64 expression whenever the second
+// smallest lies more than M = 2.5 E above it (2 E would do; the reference's own f64 rounding is 1e-9 of that); otherwise
+// -- about one pixel in a thousand -- the pixel is parked like an overflow pixel and decided by the exact f64 loop.
 // --------------------------------------------------------------------------------------------
 constexpr int kMidSurv = 48;                                   // survivors of the first rule listed per cell of the (G/2)^3 table
 constexpr unsigned kMidOverflow = 0x00000001u;                 // bytes {1, 0, 0, 0}
@@ -131,13 +167,42 @@ constexpr unsigned kMidOverflow = 0x00000001u;                 // bytes {1, 0, 0
 __device__ __forceinline__ void nn_mid_entries(const double *__restrict__ pal, const int k, const NNGrid &g, const unsigned char *__restrict__ cand,
                                                const int cidx0, const int cidx1, const int cidx2, unsigned int *__restrict__ mid) {
     const int lane = (int)threadIdx.x, m = lane >> 3, sl = lane & 7;
+    // the seven palette entries farthest from the centre of this block of cells (wave-uniform): what short lists are filled up with
+    int far7[7];
+    {
+        const double *qx = pal, *qy = pal + k, *qz = pal + 2 * k;
+        const double ctr[3] = {g.lo[0] + (4 * cidx0 + 2) * g.cw[0], g.lo[1] + (4 * cidx1 + 2) * g.cw[1], g.lo[2] + (4 * cidx2 + 2) * g.cw[2]};
+        double dv[4]; bool taken[4] = {false, false, false, false};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = lane + 64 * q;
+            dv[q] = -1.0;
+            if (j < k) { const double a = qx[j] - ctr[0], b = qy[j] - ctr[1], c = qz[j] - ctr[2]; dv[q] = (a * a + b * b) + c * c; }
+        }
+#pragma unroll
+        for (int f = 0; f < 7; f++) {
+            double bv = -2.0; int bj = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (!taken[q] && dv[q] > bv) { bv = dv[q]; bj = lane + 64 * q; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double v2 = __shfl_xor(bv, o, 64); const int j2 = __shfl_xor(bj, o, 64);
+                if (v2 > bv || (v2 == bv && j2 < bj)) { bv = v2; bj = j2; }
+            }
+            far7[f] = bj;
+#pragma unroll
+            for (int q = 0; q < 4; q++) taken[q] = taken[q] || (lane + 64 * q == bj);
+        }
+    }
     const bool all = cand[0] == 0xff;
     const int ntest = all ? k : (int)cand[0];
     const int idx[3] = {2 * cidx0 + (m & 1), 2 * cidx1 + ((m >> 1) & 1), 2 * cidx2 + (m >> 2)};
     double cl[3], ch[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const double mg = 1e-9 * (g.cw[a] * g.G) + 1e-300;
+        // the map kernel's cell index is (unsigned)(fl32(x - lo) * fl32(32 / range * (1 - 2^-18))): off by at most 32 (2^-18 + 3 * 2^-24)
+        // = 1.3e-4 of a cell = 4e-6 of the range
+        const double mg = 1e-5 * (g.cw[a] * g.G) + 1e-300;
         cl[a] = g.lo[a] + (2 * idx[a]) * g.cw[a] - mg;
         ch[a] = g.lo[a] + (2 * idx[a] + 2) * g.cw[a] + mg;
     }
@@ -216,8 +281,24 @@ __device__ __forceinline__ void nn_mid_entries(const double *__restrict__ pal, c
     for (int o = 1; o < 8; o <<= 1) entry |= (unsigned)__shfl_xor((int)entry, o, 64);
     if (cnt > 4 || ns > kMidSurv) entry = kMidOverflow;
     else {
-        const unsigned last = (entry >> (8 * (cnt - 1))) & 0xffu;
-        for (int t = cnt; t < 4; t++) entry |= last << (8 * t);
+        // fill up with far entries that are not in the list, then put the four in ascending order (distinct: byte 0 < byte 1)
+        int c = cnt;
+        unsigned b[4] = {entry & 0xffu, (entry >> 8) & 0xffu, (entry >> 16) & 0xffu, entry >> 24};
+#pragma unroll
+        for (int f = 0; f < 7; f++) {
+            const unsigned j = (unsigned)far7[f];
+            bool dup = j >= (unsigned)k;
+#pragma unroll
+            for (int t = 0; t < 4; t++) dup = dup || (t < c && b[t] == j);
+            if (!dup && c < 4) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) if (t == c) b[t] = j;
+                c++;
+            }
+        }
+        auto cswap = [](unsigned &u, unsigned &v) { const unsigned lo = u < v ? u : v, hi = u < v ? v : u; u = lo; v = hi; };
+        cswap(b[0], b[1]); cswap(b[2], b[3]); cswap(b[0], b[2]); cswap(b[1], b[3]); cswap(b[1], b[2]);
+        entry = c == 4 ? (b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24)) : kMidOverflow;     // (c < 4: fewer than four palette entries in all)
     }
     const int Gm = g.G / 2;
     if (sl == 0) mid[(idx[2] * Gm + idx[1]) * Gm + idx[0]] = entry;
@@ -399,15 +480,20 @@ __global__ __launch_bounds__(256) void k_nn_map_lut(const double *__restrict__ c
 // palette as three f64 arrays in LDS (6 KB): leaves room for the overflow queues next to the 128 KB table
 struct PalSoA { const double *x, *y, *z; };
 
-constexpr int kMidQueue = 56;                                  // overflow pixels parked per wavefront (28 B each)
-constexpr size_t kMidLds = 131072 + 3 * 256 * 8 + 16 * kMidQueue * 28;
+// LDS of k_nn_map_mid: table, f32 records, f64 palette, and what is left of the CU's 160 KB for the wavefronts' overflow queues
+constexpr size_t kMidLdsFixed = 131072 + 256 * 16 + 3 * 256 * 8;
+constexpr int mid_queue(const int waves) { const int q = (int)((163840 - kMidLdsFixed) / ((size_t)waves * 28)); return q > 64 ? 64 : (q & ~3); }   // parked pixels per wavefront (28 B each)
+constexpr size_t mid_lds(const int waves) { return kMidLdsFixed + (size_t)waves * mid_queue(waves) * 28; }
 
 // One parked pixel through its record of the G^3 table: the first eight entries unconditionally in two groups of four (a record is
 // padded with its last entry, and re-evaluating an entry cannot change a strict-'<' arg-min), the second group only when some lane
 // of the wavefront holds more than four; longer lists and overflowed cells (rare) take the general loop.
-__device__ __forceinline__ int nn_drain_one(const double x, const double y, const double z, const size_t cell, const unsigned char *__restrict__ lut,
-                                            const unsigned char *__restrict__ lut2, const PalSoA sp, const int k) {
-    const uint4 r = *reinterpret_cast<const uint4 *>(lut + cell * 16);
+// (r = the first twelve bytes of the pixel's record lut[cell]; the cell itself is worked out again on the rare paths that need the
+// rest of the record)
+struct uint3r { unsigned x, y, z; };
+__device__ __forceinline__ int nn_drain_one(const double x, const double y, const double z, const uint3r r, const unsigned char *__restrict__ lut,
+                                            const unsigned char *__restrict__ lut2, const PalSoA sp, const int k, const int G, const double lo0,
+                                            const double lo1, const double lo2, const double in0, const double in1, const double in2) {
     const int cnt = (int)(r.x & 0xffu);
     double bd = INFINITY; int best = 0;
     auto test = [&](const int j) {
@@ -421,6 +507,7 @@ __device__ __forceinline__ int nn_drain_one(const double x, const double y, cons
         if (__any(cnt > 8)) {
             if (cnt == 255) { bd = INFINITY; best = 0; for (int j = 0; j < k; j++) test(j); }
             else if (cnt > 8) {
+                const size_t cell = nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2);
                 LutRec<unsigned char> rec;
                 rec.load(lut + cell * 16);
                 bd = INFINITY; best = 0;
@@ -443,11 +530,15 @@ __device__ __forceinline__ int nn_drain_one(const double x, const double y, cons
 // loads in flight while this one is evaluated, one packed store per pair.
 #ifdef PAMD_KM_TRACE
 __device__ unsigned long long g_nn_trace[256][2];          // diagnostic build: when each block of k_nn_map_mid started and ended
+// ... and what its drains met: [0] drains, [1] pixels drained, [2] drains with a list of more than four, [3] of more than eight,
+// [4] pixels with more than eight, [5] pixels parked because the f32 pass could not tell first from second
+__device__ unsigned long long g_nn_stats[8];
+__device__ unsigned g_nn_flags;                             // timing experiments (wrong maps): 1 = drains evaluate nothing, 2 = nothing is parked
 #endif
-template <typename OutT, int P>
-__global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ c, size_t N, size_t n, const double *__restrict__ pal, int k,
-                                                     NNGrid g, const unsigned int *__restrict__ mid, const unsigned char *__restrict__ lut,
-                                                     const unsigned char *__restrict__ lut2, OutT *__restrict__ out) {
+template <typename OutT, int P, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nn_map_mid(const double *__restrict__ c, size_t N, size_t n, const double *__restrict__ pal, int k,
+                                                     NNGrid g, const unsigned int *__restrict__ mid, const float4 *__restrict__ rec32,
+                                                     const unsigned char *__restrict__ lut, const unsigned char *__restrict__ lut2, OutT *__restrict__ out) {
     extern __shared__ unsigned char smem_mid[];
     constexpr int Gm = 32, ncell = Gm * Gm * Gm;                                  // g.G == 64
     static_assert(P % 2 == 0, "pairs of pixels");
@@ -455,15 +546,17 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
     if (threadIdx.x == 0) g_nn_trace[blockIdx.x & 255][0] = wall_clock64();
 #endif
     unsigned int *T = (unsigned int *)smem_mid;                                  // [ncell]
-    double *spx = (double *)(smem_mid + (size_t)ncell * 4), *spy = spx + 256, *spz = spy + 256;
+    float4 *R = (float4 *)(smem_mid + (size_t)ncell * 4);                        // [256] {-2 (p - lo), |p - lo|^2} in f32
+    double *spx = (double *)(R + 256), *spy = spx + 256, *spz = spy + 256;       // the f64 palette (the exact loop of the parked pixels)
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // this wavefront's overflow queue: coordinates and pixel index of up to kMidQueue pixels
+    constexpr int kMidQueue = mid_queue(WAVES);
     double *qx = spz + 256 + wid * 3 * kMidQueue, *qy = qx + kMidQueue, *qz = qy + kMidQueue;
-    unsigned int *qi = (unsigned int *)(spz + 256 + 16 * 3 * kMidQueue) + wid * kMidQueue;
+    unsigned int *qi = (unsigned int *)(spz + 256 + WAVES * 3 * kMidQueue) + wid * kMidQueue;
     const PalSoA sp{spx, spy, spz};
 
     constexpr size_t tile = (size_t)64 * P;
-    const size_t step = (size_t)gridDim.x * 16 * tile;
+    const size_t step = (size_t)gridDim.x * WAVES * tile;
     double nx[P], ny[P], nz[P];
     auto fetch = [&](const size_t base) {                                         // wave-uniform base
         const double *cb = c + base;
@@ -484,16 +577,20 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
             for (int p = 0; p < P; p++) { const unsigned t = min(128u * (unsigned)(p >> 1) + 2u * (unsigned)lane + (unsigned)(p & 1), last); nx[p] = cb[t]; ny[p] = cb[N + t]; nz[p] = cb[2 * N + t]; }
         }
     };
-    size_t base = ((size_t)blockIdx.x * 16 + wid) * tile;
+    size_t base = ((size_t)blockIdx.x * WAVES + wid) * tile;
     if (base < n) fetch(base);                                                    // in flight while the table is copied in
-    for (int i = threadIdx.x; i < ncell / 4; i += 1024) ((uint4 *)T)[i] = ((const uint4 *)mid)[i];
-    for (int j = threadIdx.x; j < 256; j += 1024) {
+    for (int i = threadIdx.x; i < ncell / 4; i += 64 * WAVES) ((uint4 *)T)[i] = ((const uint4 *)mid)[i];
+    for (int j = threadIdx.x; j < 256; j += 64 * WAVES) {
         const bool in = j < k;
         spx[j] = in ? pal[j] : 0.0; spy[j] = in ? pal[k + j] : 0.0; spz[j] = in ? pal[2 * k + j] : 0.0;
+        R[j] = rec32[j];
     }
     __syncthreads();
     const int G = g.G;
     const double lo0 = g.lo[0], lo1 = g.lo[1], lo2 = g.lo[2], in0 = g.inv[0], in1 = g.inv[1], in2 = g.inv[2];
+    // cell of the 32^3 table from the shifted f32 coordinates: 0 <= fl32(x - lo) * im < 32 (the factor 1 - 2^-18 absorbs the roundings)
+    const float im0 = (float)(in0 * 0.5 * (1.0 - 0x1.0p-18)), im1 = (float)(in1 * 0.5 * (1.0 - 0x1.0p-18)), im2 = (float)(in2 * 0.5 * (1.0 - 0x1.0p-18));
+    const float Mamb = rec32[256].x;                                              // wave-uniform: a scalar load
     const unsigned long long ltmask = (1ULL << lane) - 1ULL;
     int qn = 0;                                                                   // wave-uniform
     const bool out_even = (reinterpret_cast<size_t>(out) & 1) == 0;               // packed two-byte stores need an even address
@@ -506,36 +603,39 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
         const unsigned left = (unsigned)min((size_t)tile, n - base);
         OutT *ob = out + base;
         unsigned e[P];
+        float xf[P], yf[P], zf[P];
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            int ix = (int)((x[p] - lo0) * in0), iy = (int)((y[p] - lo1) * in1), iz = (int)((z[p] - lo2) * in2);
-            ix = max(0, min(ix, G - 1));
-            iy = max(0, min(iy, G - 1));
-            iz = max(0, min(iz, G - 1));
-            e[p] = T[((iz >> 1) * Gm + (iy >> 1)) * Gm + (ix >> 1)];
+            xf[p] = (float)(x[p] - lo0); yf[p] = (float)(y[p] - lo1); zf[p] = (float)(z[p] - lo2);
+            const unsigned ix = (unsigned)(xf[p] * im0), iy = (unsigned)(yf[p] * im1), iz = (unsigned)(zf[p] * im2);
+            e[p] = T[(((iz << 5) | iy) << 5) | ix];
         }
         unsigned ovbits = 0, bests[P];
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const unsigned t = 128u * (unsigned)(p >> 1) + 2u * (unsigned)lane + (unsigned)(p & 1);
             const bool ok = t < left;
-            const int j0 = (int)(e[p] & 0xffu), j1 = (int)((e[p] >> 8) & 0xffu), j2 = (int)((e[p] >> 16) & 0xffu), j3 = (int)(e[p] >> 24);
-            const bool ov = ok && j0 > j1;
-            int best = j0;
-            {
-                double d0 = x[p] - spx[j0], d1 = y[p] - spy[j0], d2 = z[p] - spz[j0];
-                double bd = (d0 * d0 + d1 * d1) + d2 * d2;
-                d0 = x[p] - spx[j1]; d1 = y[p] - spy[j1]; d2 = z[p] - spz[j1];
-                double d = (d0 * d0 + d1 * d1) + d2 * d2;
-                if (d < bd) { bd = d; best = j1; }
-                d0 = x[p] - spx[j2]; d1 = y[p] - spy[j2]; d2 = z[p] - spz[j2];
-                d = (d0 * d0 + d1 * d1) + d2 * d2;
-                if (d < bd) { bd = d; best = j2; }
-                d0 = x[p] - spx[j3]; d1 = y[p] - spy[j3]; d2 = z[p] - spz[j3];
-                d = (d0 * d0 + d1 * d1) + d2 * d2;
-                if (d < bd) { bd = d; best = j3; }
-            }
-            bests[p] = (unsigned)best;
+            const unsigned j0 = e[p] & 0xffu, j1 = (e[p] >> 8) & 0xffu, j2 = (e[p] >> 16) & 0xffu, j3 = e[p] >> 24;
+            const float4 r0 = R[j0], r1 = R[j1], r2 = R[j2], r3 = R[j3];
+            // t_j = |x - p_j|^2 - |x - lo|^2 within E; the four candidates are distinct (the table's rule)
+            const float t0 = __builtin_fmaf(xf[p], r0.x, __builtin_fmaf(yf[p], r0.y, __builtin_fmaf(zf[p], r0.z, r0.w)));
+            const float t1 = __builtin_fmaf(xf[p], r1.x, __builtin_fmaf(yf[p], r1.y, __builtin_fmaf(zf[p], r1.z, r1.w)));
+            const float t2 = __builtin_fmaf(xf[p], r2.x, __builtin_fmaf(yf[p], r2.y, __builtin_fmaf(zf[p], r2.z, r2.w)));
+            const float t3 = __builtin_fmaf(xf[p], r3.x, __builtin_fmaf(yf[p], r3.y, __builtin_fmaf(zf[p], r3.z, r3.w)));
+            const float lo01 = __builtin_fminf(t0, t1), hi01 = __builtin_fmaxf(t0, t1), lo23 = __builtin_fminf(t2, t3), hi23 = __builtin_fmaxf(t2, t3);
+            const float m1 = __builtin_fminf(lo01, lo23);                                        // smallest
+            const float m2 = __builtin_fminf(__builtin_fmaxf(lo01, lo23), __builtin_fminf(hi01, hi23));   // second smallest
+            const bool clear = (m2 - m1) > Mamb;                                                 // (a NaN anywhere: not clear)
+            const unsigned best = t0 == m1 ? j0 : (t1 == m1 ? j1 : (t2 == m1 ? j2 : j3));
+#ifdef PAMD_KM_TRACE
+            const bool ov = ok && (j0 > j1 || !clear) && !(g_nn_flags & 2u);
+#else
+            const bool ov = ok && (j0 > j1 || !clear);
+#endif
+#ifdef PAMD_NN_STATS
+            { const unsigned long long ma = __ballot(ok && j0 < j1 && !clear); if (lane == 0 && ma) atomicAdd(&g_nn_stats[5], (unsigned long long)__popcll(ma)); }
+#endif
+            bests[p] = best;
             ovbits |= ov ? (1u << p) : 0u;
         }
         // results: parked pixels get a 0 for now, the drain writes theirs later (same wavefront, program order)
@@ -575,10 +675,26 @@ __global__ __launch_bounds__(1024) void k_nn_map_mid(const double *__restrict__ 
                     // a parked pixel's provisional result was stored above by ANOTHER lane of this wavefront: the fence orders
                     // the two stores (wavefront scope: no instruction, the wave's stores to one address already leave in order)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef PAMD_NN_STATS
+                    {
+                        unsigned c8 = 0;
+                        if (lane < qn) c8 = lut[nn_cell(qx[lane], qy[lane], qz[lane], G, lo0, lo1, lo2, in0, in1, in2) * 16];
+                        const unsigned long long m4 = __ballot(lane < qn && c8 > 4), m8 = __ballot(lane < qn && c8 > 8);
+                        if (lane == 0) {
+                            atomicAdd(&g_nn_stats[0], 1ULL); atomicAdd(&g_nn_stats[1], (unsigned long long)qn);
+                            if (m4) atomicAdd(&g_nn_stats[2], 1ULL);
+                            if (m8) { atomicAdd(&g_nn_stats[3], 1ULL); atomicAdd(&g_nn_stats[4], (unsigned long long)__popcll(m8)); }
+                        }
+                    }
+#endif
+#ifdef PAMD_KM_TRACE
+                    if (lane < qn && !(g_nn_flags & 1u)) {
+#else
                     if (lane < qn) {
+#endif
                         const double px = qx[lane], py = qy[lane], pz = qz[lane];
                         const size_t cell = nn_cell(px, py, pz, G, lo0, lo1, lo2, in0, in1, in2);
-                        out[qi[lane]] = (OutT)nn_drain_one(px, py, pz, cell, lut, lut2, sp, k);
+                        out[qi[lane]] = (OutT)nn_drain_one(px, py, pz, *reinterpret_cast<const uint3r *>(lut + cell * 16), lut, lut2, sp, k, G, lo0, lo1, lo2, in0, in1, in2);
                     }
                     qn = 0;
                 }
@@ -630,26 +746,33 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
         unsigned char *l1 = w.lut.p, *l2 = w.lut.p + (size_t)ncell * 16;
         static const bool mid_enabled = !(getenv("PAMD_NN_MID") && atoi(getenv("PAMD_NN_MID")) == 0);
         const bool use_mid = g.G == 64 && mid_enabled;                      // large images: four-candidate table in LDS
-        if (use_mid) w.mid.reserve((size_t)(ncell / 8));
+        if (use_mid) w.mid.reserve((size_t)(ncell / 8) + 257 * 4);        // the 32^3 table + the f32 records and margin behind it
         const int ncoarse = ncell / 64;
         w.clist.reserve((size_t)ncoarse * (1 + kCoarseMax) * 2);
         {
             KTIME("k_nn_lut_build", s, 32.0 * ncell);
-            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, w.clist.p);
+            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, w.clist.p, use_mid ? (float4 *)(w.mid.p + ncell / 8) : (float4 *)nullptr);
             hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncoarse, 64, 0, s, d_pal, k, g, l1, l2, (const unsigned char *)w.clist.p, use_mid ? w.mid.p : nullptr);
         }
         if (use_mid) {
-            constexpr int P = sizeof(OutT) == 1 ? 4 : 2;       // (four pixels per lane with 4- or 8-byte map elements spill 70-82 registers)
-            const size_t lds_mid = kMidLds;
-            static PerDeviceOnce attr_mid;
-            if (attr_mid.first()) {
-                HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_mid<OutT, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
-            }
             if (n >> 32) throw HipError("patolette_amd: the LDS-table map kernel indexes pixels with 32 bits");
-            const int blocks = (int)std::min<size_t>((size_t)num_cus(), ceil_div(n, (size_t)1024 * P));
-            KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
-            hipLaunchKernelGGL((k_nn_map_mid<OutT, P>), blocks, 1024, lds_mid, s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned int *)w.mid.p,
-                               (const unsigned char *)l1, (const unsigned char *)l2, out);
+            // one-byte maps: sixteen wavefronts per CU with four pixels per lane; PAMD_NN_WAVES=12 = twelve with six (9 KB of loads in
+            // flight per wavefront, 168 registers each): 294 against 281 us on the KMeans palette, level on the CIELuv one (interleaved
+            // launches, tools/diag/nn_ab.py).  (Four pixels per lane with 4- or 8-byte map elements spill.)
+            const int waves_env = getenv("PAMD_NN_WAVES") ? atoi(getenv("PAMD_NN_WAVES")) : 16;      // (read per call: an A/B alternates it)
+            auto go = [&](auto pc, auto wc) {
+                constexpr int P = decltype(pc)::value, WAVES = decltype(wc)::value;
+                static PerDeviceOnce attr_mid;
+                if (attr_mid.first()) HIP_CHECK(hipFuncSetAttribute((const void *)(k_nn_map_mid<OutT, P, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds(WAVES)));
+                const int blocks = (int)std::min<size_t>((size_t)num_cus(), ceil_div(n, (size_t)64 * WAVES * P));
+                KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
+                hipLaunchKernelGGL((k_nn_map_mid<OutT, P, WAVES>), blocks, 64 * WAVES, mid_lds(WAVES), s, d_colors, plane_stride, n, d_pal, k, g, (const unsigned int *)w.mid.p,
+                                   (const float4 *)(w.mid.p + ncell / 8), (const unsigned char *)l1, (const unsigned char *)l2, out);
+            };
+            if constexpr (sizeof(OutT) == 1) {
+                if (waves_env == 12) go(std::integral_constant<int, 6>{}, std::integral_constant<int, 12>{});
+                else go(std::integral_constant<int, 4>{}, std::integral_constant<int, 16>{});
+            } else go(std::integral_constant<int, 2>{}, std::integral_constant<int, 16>{});
             return;
         }
         KTIME("k_nn_map", s, (24.0 + sizeof(OutT)) * n);
@@ -661,7 +784,7 @@ static void launch_nn_lut(const double *d_colors, size_t plane_stride, size_t n,
         w.clist.reserve((size_t)ncoarse * (1 + kCoarseMax) * 2);
         {
             KTIME("k_nn_lut_build", s, 64.0 * ncell);
-            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, (unsigned short *)w.clist.p);
+            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, (unsigned short *)w.clist.p, (float4 *)nullptr);
             hipLaunchKernelGGL(k_nn_lut_build<unsigned short>, ncoarse, 64, 0, s, d_pal, k, g, l16, l16b, (const unsigned short *)w.clist.p, (unsigned int *)nullptr);
         }
         static PerDeviceOnce attr;
@@ -796,6 +919,11 @@ __device__ __forceinline__ int wave_argmin_nonneg_f64(double v) {
 // wait states after it was written, and so may a select read VCC after a 64-bit compare -- the four row-minimum steps used to
 // stand behind an s_nop each, and the three compare / select pairs behind theirs; interleaved, each fills the other's gaps:
 // 14 issue slots instead of 21 on a chain whose cost is its instruction count.  Returns the row minima (every lane its row's).
+// (The wait states inside these two blocks are counted by hand for the CDNA3 / CDNA4 issue rules -- the hazard recogniser does not
+// look inside inline asm -- and the K = 100 / 128 / 130 / 256 dither parity tests are their check after every toolchain change.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "map.hip: the hand-scheduled DPP blocks of the dither are written for gfx950 (MI355X); see the Makefile's ARCH"
+#endif
 __device__ __forceinline__ unsigned dither_rows4(const double d0, const double d1, const double d2, const double d3, const double bd, int &e) {
     const unsigned hi = (unsigned)__double2hiint(bd);
     unsigned t; int ee;
@@ -1257,5 +1385,13 @@ extern "C" void patolette_amd_debug_dither_locate(size_t width, size_t height, u
 #ifdef PAMD_KM_TRACE
 extern "C" int patolette_amd_debug_nn_trace(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pamd::g_nn_trace), sizeof(pamd::g_nn_trace)) == hipSuccess ? 0 : -1;
+}
+extern "C" int patolette_amd_debug_nn_flags(unsigned flags) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(pamd::g_nn_flags), &flags, sizeof flags) == hipSuccess ? 0 : -1;
+}
+extern "C" int patolette_amd_debug_nn_stats(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pamd::g_nn_stats), sizeof(pamd::g_nn_stats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pamd::g_nn_stats), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
 }
 #endif

@@ -33,7 +33,8 @@ void launch_convert_rows(int which, const double *rows, double *dst, size_t n, C
                          BinK sumk = BinK{0.0, 0.0}, BinK momk = BinK{0.0, 0.0}, size_t begin = 0, size_t end = ~(size_t)0,
                          bool init_stats = true);
 void launch_convert_u8(int which, const unsigned char *pixels, int channels, double *dst, size_t n, ConvertStats *stats,
-                       hipStream_t s, BinK sumk = BinK{0.0, 0.0}, BinK momk = BinK{0.0, 0.0});
+                       hipStream_t s, BinK sumk = BinK{0.0, 0.0}, BinK momk = BinK{0.0, 0.0}, size_t begin = 0, size_t end = ~(size_t)0,
+                       bool init_stats = true);
 void launch_reconstruct(const void *map, int map_elem, size_t n, const unsigned char *pal_u8, int k, unsigned char *out,
                         hipStream_t s);
 void launch_weight_stats(const double *w, size_t n, ConvertStats *stats, hipStream_t s);
@@ -991,7 +992,9 @@ std::atomic<int> g_perm_cache{1};
 // Call entry: if this image will be subsampled (assuming the quantisers deliver all K clusters; fewer only shorten the list),
 // start making the list on a helper thread.  take = the longest list any cluster count <= K can ask for: min(ms, N).
 static void subsample_start(Engine &E, size_t Nt, size_t K, size_t max_samples) {
-    if (E.perm_job.valid()) E.perm_job.wait();                                  // a job left behind by a call that threw
+    if (E.perm_job.valid()) {                                                   // a job left behind by a call that threw
+        try { E.perm_job.get(); } catch (...) { E.hperm_N = 0; E.hperm_nx = 0; }   // ... and that may itself have failed: its list is void then
+    }
     const size_t ms = std::max(max_samples, (size_t)(256 * 256));                // refine.c:21
     if (K == 0 || Nt < K) return;
     const size_t nxK = K * (size_t)(int)(ms / K);
@@ -1009,7 +1012,9 @@ static void subsample_start(Engine &E, size_t Nt, size_t K, size_t max_samples) 
 }
 // The KMeans stage: the first nx entries of rand_perm(Nt) on the device; no stream synchronisation (pinned staging)
 static const int *subsample_list(Engine &E, size_t Nt, size_t nx, hipStream_t s) {
-    if (E.perm_job.valid()) E.perm_job.get();
+    if (E.perm_job.valid()) {
+        try { E.perm_job.get(); } catch (...) { E.hperm_N = 0; E.hperm_nx = 0; throw; }
+    }
     if (E.perm_N == Nt && E.perm_nx >= nx) return E.perm_dev.p;
     if (!(E.hperm_N == Nt && E.hperm_nx >= nx)) {                                // no helper was started (a stage-level call, fewer clusters than K)
         E.h_perm.reserve(nx);
@@ -1479,10 +1484,38 @@ static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *
     double t0 = now_ms();
     const unsigned char *d_px = pixels;
     const double *d_w = weights;
+    bool converted = false;
     if (!on_device) {
         E.src8.reserve(N * (size_t)channels);
-        HIP_CHECK(hipMemcpyAsync(E.src8.p, pixels, N * (size_t)channels, hipMemcpyHostToDevice, s));
         d_px = E.src8.p;
+        // as run_host: a large image goes up in four pieces of whole pixels, each converted (second stream) while the next is on the link
+        const size_t chunk_min = getenv("PAMD_UPLOAD_CHUNK_MIN") ? (size_t)atoll(getenv("PAMD_UPLOAD_CHUNK_MIN")) : ((size_t)1 << 21);
+        const bool derive = !weights && tile_size > 0.0;             // the saliency stage reads the whole sRGB image first
+        if (N >= chunk_min && !derive && !E.shard) {
+            if (!E.stream2) {
+                HIP_CHECK(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
+                for (hipEvent_t *e : {&E.ev_up[0], &E.ev_up[1], &E.ev_join}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
+            const ConvertPlan cp = convert_plan(E, opt, N);
+            E.cvt.reserve((weights ? 4 : 3) * N);
+            E.cstats.reserve(1);
+            HIP_CHECK(hipEventRecord(E.ev_join, E.stream));
+            HIP_CHECK(hipStreamWaitEvent(E.stream2, E.ev_join, 0));
+            const size_t nch = 4, per = ((N + nch - 1) / nch + 255) & ~(size_t)255;
+            size_t c = 0;
+            for (size_t lo = 0; lo < N; lo += per, c++) {
+                const size_t cnt = std::min(per, N - lo);
+                HIP_CHECK(hipMemcpyAsync(E.src8.p + lo * (size_t)channels, pixels + lo * (size_t)channels, cnt * (size_t)channels, hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipEventRecord(E.ev_up[c & 1], s));
+                HIP_CHECK(hipStreamWaitEvent(E.stream2, E.ev_up[c & 1], 0));
+                launch_convert_u8(cp.which, E.src8.p, channels, E.cvt.p, N, E.cstats.p, E.stream2, cp.sumk, cp.momk, lo, lo + cnt, c == 0);
+            }
+            HIP_CHECK(hipEventRecord(E.ev_join, E.stream2));
+            HIP_CHECK(hipStreamWaitEvent(s, E.ev_join, 0));
+            converted = true;
+        } else {
+            HIP_CHECK(hipMemcpyAsync(E.src8.p, pixels, N * (size_t)channels, hipMemcpyHostToDevice, s));
+        }
         if (weights) {
             E.wsrc.reserve(N);
             HIP_CHECK(hipMemcpyAsync(E.wsrc.p, weights, N * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1501,7 +1534,9 @@ static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *
         else { E.dmap.reserve(N * (size_t)me); d_map = E.dmap.p; }
     }
     std::vector<double> pal(3 * K);
-    run_device(E, width, height, Pixels{nullptr, d_px, channels}, d_w, K, opt, pal.data(), d_map, me);
+    Pixels px8{nullptr, d_px, channels};
+    px8.converted = converted;
+    run_device(E, width, height, px8, d_w, K, opt, pal.data(), d_map, me);
     E.stats.ms_saliency = E.ms_saliency;
     E.stats.ms_total += E.ms_saliency;
     t0 = now_ms();
