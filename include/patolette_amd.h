@@ -248,6 +248,9 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
  * single serial chain) and `warm` in-image pixels of speculative warm-up per run (< 0 = default; 0 forces every boundary to be
  * repaired).  The map is the reference's chain bit for bit for every setting. */
 void patolette_amd_dither_config(int segments, int warm);
+/* ... and which layout walks the runs (process-wide): 1 / -1 = one LANE per run wherever it applies (8 <= palette rows <= 256,
+ * images of 65 536 pixels and more: the default), 0 = one WAVEFRONT per run everywhere.  Same map either way. */
+void patolette_amd_dither_layout(int lanes);
 /* Where the dither cuts the curve (host-side copy of the kernel's function, runs without a GPU): *d = first curve position of the
  * aligned 64-position block that holds in-image pixel number t (curve order, 0-based), *c = in-image pixels before that block. */
 void patolette_amd_debug_dither_locate(size_t width, size_t height, unsigned long long t, unsigned long long *d, unsigned long long *c);

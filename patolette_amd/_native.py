@@ -100,6 +100,7 @@ SYMBOLS = {
     "patolette_amd_nn_map": (C.c_int, [dp, C.c_size_t, dp, C.c_size_t, zp]),
     "patolette_amd_dither": (C.c_int, [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp]),
     "patolette_amd_dither_config": (None, [C.c_int, C.c_int]),
+    "patolette_amd_dither_layout": (None, [C.c_int]),
     "patolette_amd_debug_dither_locate": (None, [C.c_size_t, C.c_size_t, C.c_ulonglong, C.POINTER(C.c_ulonglong),
                                                  C.POINTER(C.c_ulonglong)]),
     "patolette_amd_last_stats": (None, [C.POINTER(Stats)]),

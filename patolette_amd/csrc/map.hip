@@ -1282,9 +1282,289 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
     if (count != head && !done) group((int)(count - head), false);
 }
 
-struct DitherConfig { int segments = 0, warm = -1; };                // 0 / -1 = chosen by launch_dither
+// --------------------------------------------------------------------------------------------
+// Riemersma dither, one LANE per run (round 5)
+//
+// The run-parallel form above spends a whole wavefront on one chain: 64 lanes share the palette search of one pixel, ~85
+// instructions per step.  With runs plentiful (the chain's state is its last sixteen choices: any number of runs can be walked
+// side by side and verified afterwards) the other layout pays: every LANE walks its own run, the error queue in its registers,
+// the nearest colour through the exact-pruning records of the NN map (k_nn_lut_build over the weighted palette: a handful of
+// candidates per query instead of K), ~300 instructions per step of a WAVEFRONT = 64 steps.  A run is a few hundred pixels,
+// the warm-up as long again -- twice the steps, a thirtieth of the instructions each.
+//   k_dither_gather   pixels (and their linear numbers) into curve order: the only place that knows the Hilbert curve;
+//                     a run is then a range of ranks, a warm-up the ranks before it
+//   k_dither_lanes<0> run b: zero queue at rank t_b - warm, choices of ranks [t_b - 16, t_b) -> side[b], of [t_b, t_b+1) -> smap
+//   k_dither_lane_check  boundary b is good iff side[b] equals smap[t_b - 16 .. t_b); the others are listed
+//   k_dither_lanes<1> a listed run again from the queue rebuilt out of smap and the pixels (side[b] := the sixteen choices it
+//                     read), until sixteen consecutive choices equal what is there (the old chain met: the rest stands)
+//   ... check / repair until a check lists nothing: nothing was written since the previous repair, every side[b] equals the
+//       map, and by induction over b (run 0 starts from the true zero queue) smap is the reference's chain
+//   k_dither_unpermute  out[pixel number of rank r] = smap[r]
+// Arithmetic per step exactly as riemersma.c:275-341 orders it: e = ((0 + q[0] w[0]) + q[1] w[1]) + ... per channel, query =
+// W (pixel + e) with the double weights, squared distance ((d0 d0 + d1 d1) + d2 d2) to the palette scaled by the float-cast
+// weights, ascending index with strict '<', pushed error = pixel - chosen colour.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dither_gather(const double *__restrict__ img, size_t plane_stride, unsigned width, unsigned height, unsigned parts,
+                                                      double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz, unsigned *__restrict__ spos) {
+    const unsigned mxd = width > height ? width : height;
+    int L = 0;
+    while ((1u << L) < mxd) L++;
+    const int lane = threadIdx.x;
+    const unsigned long long total = 1ULL << (2 * L), npix = (unsigned long long)width * height;
+    const unsigned g = blockIdx.x;
+    unsigned long long d0 = 0, c = 0, d_end = total, cc;
+    if (g > 0) dither_locate(L, width, height, npix * g / parts, d0, c);
+    if (g + 1 < parts) dither_locate(L, width, height, npix * (g + 1) / parts, d_end, cc);
+    const bool needs_skip = width < (1u << L) || height < (1u << L);
+    const double *pr = img, *pg = img + plane_stride, *pb = img + 2 * plane_stride;
+    while (d0 < d_end) {
+        if (needs_skip) {                                            // whole out-of-image aligned sub-squares
+            bool skipped = false;
+            for (int j = L; j >= 3; j--) {
+                const unsigned long long span = 1ULL << (2 * j);
+                if ((d0 & (span - 1)) != 0) continue;
+                unsigned x0, y0;
+                hilbert_d2xy(L, d0, x0, y0);
+                x0 &= ~((1u << j) - 1u); y0 &= ~((1u << j) - 1u);
+                if (x0 >= width || y0 >= height) { d0 += span; skipped = true; break; }
+            }
+            if (skipped) continue;
+        }
+        unsigned x, y;
+        hilbert_d2xy(L, d0 + (unsigned long long)lane, x, y);
+        const bool inb = x < width && y < height;
+        const unsigned long long mask = __ballot(inb);
+        if (inb) {
+            const size_t p = (size_t)y * width + x;
+            const unsigned long long r = c + (unsigned long long)__popcll(mask & ((1ULL << lane) - 1ULL));
+            sx[r] = pr[p]; sy[r] = pg[p]; sz[r] = pb[p];
+            spos[r] = (unsigned)p;
+        }
+        c += (unsigned long long)__popcll(mask);
+        d0 += 64;
+    }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_dither_unpermute(const unsigned char *__restrict__ smap, const unsigned *__restrict__ spos, size_t n, OutT *__restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) out[spos[r]] = (OutT)smap[r];
+}
+
+struct DitherLanes {
+    const double *sx, *sy, *sz;          // pixels in curve order
+    unsigned char *smap;                 // choices in curve order
+    unsigned short *side;                // [S][16] the choices a run's starting queue was built from (0xFFFF = none: the run is walked again)
+    unsigned *list;                      // runs whose boundary check failed; list[-1] = how many
+    unsigned long long N;
+    unsigned S, warm;
+    const unsigned char *lut;            // 16-byte records of the G^3 grid over the weighted palette (k_nn_lut_build)
+    NNGrid g;
+    double hi[3];                        // upper corner of the grid: queries outside [lo, hi] take the full scan
+};
+
+__global__ __launch_bounds__(256) void k_dither_lane_check(DitherLanes a) {
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x + 1u;
+    if (b >= a.S) return;
+    const unsigned long long t = a.N * b / a.S;
+    bool same = true;
+    for (int i = 0; i < 16; i++) same = same && a.side[16ull * b + i] == (unsigned short)a.smap[t - 16 + i];
+    if (!same) a.list[atomicAdd(a.list - 1, 1u)] = b;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const double *__restrict__ pal /* planar (k,3), linear Rec2020 */, int k, DitherWeights wts) {
+    extern __shared__ double lds[];
+    double *praw = lds, *pwt = lds + 3 * k;                        // [3][k] raw palette; [3][k] scaled by the (float)-cast weights (riemersma.c:419-425)
+    const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
+    for (int j = threadIdx.x; j < k; j += blockDim.x)
+        for (int c = 0; c < 3; c++) { const double v = pal[c * k + j]; praw[c * k + j] = v; pwt[c * k + j] = v * fw[c]; }
+    __syncthreads();
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active;
+    unsigned b = 0;
+    if constexpr (MODE == 0) { active = gid < a.S; b = active ? gid : 0u; }
+    else { const unsigned nl = a.list[-1]; active = gid < nl; b = active ? a.list[gid] : 1u; }
+    const unsigned long long t_b = a.N * b / a.S, t_e = b + 1 < a.S ? a.N * (b + 1) / a.S : a.N;
+    unsigned long long r = MODE == 0 ? (t_b > a.warm ? t_b - a.warm : 0ULL) : t_b;
+    if constexpr (MODE == 0) {
+        if (active && b > 0 && t_b - r < 16) {                      // a warm-up of fewer than sixteen steps leaves no record to pass the check
+            for (int i = 0; i < 16; i++) a.side[16ull * b + i] = 0xFFFFu;
+        }
+    }
+    double q0[16], q1[16], q2[16];                                  // the error queue: slot s = the error of the run's step s (mod 16)
+#pragma unroll
+    for (int s = 0; s < 16; s++) { q0[s] = 0.0; q1[s] = 0.0; q2[s] = 0.0; }
+    if constexpr (MODE == 1) {
+        if (active) {
+            // the queue as the chain holds it after ranks t_b - 16 .. t_b - 1: original pixel - chosen colour, oldest first
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const unsigned long long rr = t_b - 16 + s;
+                const unsigned c = a.smap[rr];
+                a.side[16ull * b + s] = (unsigned short)c;
+                q0[s] = a.sx[rr] - praw[c]; q1[s] = a.sy[rr] - praw[k + c]; q2[s] = a.sz[rr] - praw[2 * k + c];
+            }
+        }
+    }
+    const int G = a.g.G;
+    const double lo0 = a.g.lo[0], lo1 = a.g.lo[1], lo2 = a.g.lo[2], in0 = a.g.inv[0], in1 = a.g.inv[1], in2 = a.g.inv[2];
+    const double hi0 = a.hi[0], hi1 = a.hi[1], hi2 = a.hi[2];
+    auto nearest = [&](const double x, const double y, const double z, const bool on) -> int {
+        double bd = INFINITY; int best = 0;
+        auto test = [&](const int j) {
+            const double d0 = x - pwt[j], d1 = y - pwt[k + j], d2 = z - pwt[2 * k + j];
+            const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+            if (d < bd) { bd = d; best = j; }                       // ascending j + strict '<' = lowest index on ties
+        };
+        const bool inside = x >= lo0 && x <= hi0 && y >= lo1 && y <= hi1 && z >= lo2 && z <= hi2;   // (a NaN: not inside)
+        int cnt = 0;
+        unsigned long long w0 = 0, w1 = 0;
+        if (on && inside) {
+            const uint4 rec = *reinterpret_cast<const uint4 *>(a.lut + nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2) * 16);
+            cnt = (int)(rec.x & 0xffu);
+            w0 = ((unsigned long long)rec.y << 32) | rec.x; w1 = ((unsigned long long)rec.w << 32) | rec.z;
+            w0 = (w0 >> 8) | (w1 << 56); w1 >>= 8;
+        }
+        const bool slow = on && (!inside || cnt > 15);              // outside the grid, or a cell whose list runs past one record
+        const int n = slow ? 0 : cnt;
+        for (int t = 0; __any(t < n); t++) {
+            const int j = (int)(w0 & 0xffULL);
+            w0 = (w0 >> 8) | (w1 << 56); w1 >>= 8;
+            if (t < n) test(j);
+        }
+        if (__any(slow)) { if (slow) for (int j = 0; j < k; j++) test(j); }
+        return best;
+    };
+    double c0 = 0, c1 = 0, c2 = 0;                                  // the pixel of rank r, fetched one step ahead
+    int cm = 0;                                                     // MODE 1: and the choice smap holds for it
+    bool on = active && r < t_e;
+    if (on) { c0 = a.sx[r]; c1 = a.sy[r]; c2 = a.sz[r]; if constexpr (MODE == 1) cm = (int)a.smap[r]; }
+    int streak = 0;                                                 // MODE 1: consecutive choices equal to what smap holds
+    while (__any(on)) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double p0 = c0, p1 = c1, p2 = c2;
+            const int was = cm;
+            const bool nxt = on && r + 1 < t_e;
+            if (nxt) { c0 = a.sx[r + 1]; c1 = a.sy[r + 1]; c2 = a.sz[r + 1]; if constexpr (MODE == 1) cm = (int)a.smap[r + 1]; }
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;                    // riemersma.c:282-296, in that order
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int s = (j + i) & 15;
+                e0 += q0[s] * wts.w[i]; e1 += q1[s] * wts.w[i]; e2 += q2[s] * wts.w[i];
+            }
+            const int bi = nearest(kRw * (p0 + e0), kGw * (p1 + e1), kBw * (p2 + e2), on);
+            if (on) {
+                q0[j] = p0 - praw[bi]; q1[j] = p1 - praw[k + bi]; q2[j] = p2 - praw[2 * k + bi];       // riemersma.c:333-340
+                if constexpr (MODE == 0) {
+                    if (r >= t_b) a.smap[r] = (unsigned char)bi;
+                    else if (r + 16 >= t_b) a.side[16ull * b + (unsigned)(r + 16 - t_b)] = (unsigned short)bi;
+                } else {
+                    if (was == bi) streak++;
+                    else { streak = 0; a.smap[r] = (unsigned char)bi; }
+                }
+            }
+            r++;
+            on = nxt && (MODE == 0 || streak < 16);
+        }
+    }
+}
+
+struct DitherConfig { int segments = 0, warm = -1, lanes = -1; };    // 0 / -1 = chosen by launch_dither
 static DitherConfig g_dither_cfg;
 void dither_config(int segments, int warm) { g_dither_cfg.segments = segments; g_dither_cfg.warm = warm; }
+void dither_layout(int lanes) { g_dither_cfg.lanes = lanes; }
+
+// One lane per run (k_dither_lanes): K in [8, 256], images of 2^16 pixels and more.  h_pal: the palette on the host, planar (k,3).
+static void launch_dither_lanes(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, const double *h_pal,
+                                int k, void *d_out, int elem_bytes, NNWork &w, const DitherConfig &cfg, const DitherWeights &wts, hipStream_t s) {
+    const size_t npix = width * height;
+    DitherLanes a{};
+    a.N = npix;
+    a.warm = cfg.warm >= 0 ? (unsigned)cfg.warm : 512u;
+    // runs: eight wavefronts of 64 per CU (two per SIMD), none shorter than 256 pixels unless asked for
+    size_t S = cfg.segments > 0 ? (size_t)cfg.segments : std::min<size_t>((size_t)num_cus() * 8 * 64, npix / 256);
+    S = std::max<size_t>(1, std::min(S, npix / 64));
+    a.S = (unsigned)S;
+    // the grid of the exact-pruning records: the weighted palette's bounding box, half its extent wider on every side -- error
+    // diffusion pushes queries beyond the palette's hull; what still falls outside takes the full scan
+    std::vector<double> wp(3 * (size_t)k);
+    const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
+    NNGrid g;
+    g.G = npix >= ((size_t)1 << 20) ? 64 : 32;
+    for (int c = 0; c < 3; c++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int j = 0; j < k; j++) { const double v = h_pal[(size_t)c * k + j] * fw[c]; wp[(size_t)c * k + j] = v; lo = std::min(lo, v); hi = std::max(hi, v); }
+        double r = hi - lo;
+        if (!(r > 0) || !std::isfinite(r)) r = 0;
+        const double m = 0.5 * r + 1e-3;
+        g.lo[c] = lo - m;
+        const double R = r + 2 * m;
+        g.cw[c] = R / g.G;
+        g.inv[c] = g.G / R;
+        a.hi[c] = g.lo[c] + R;
+    }
+    const int ncell = g.G * g.G * g.G;
+    w.dtab.reserve(3 * (size_t)k);
+    w.lut.reserve((size_t)ncell * 32);
+    w.clist.reserve((size_t)(ncell / 64) * (1 + kCoarseMax) * 2);
+    w.dsort.reserve(3 * npix);
+    w.dpos.reserve(npix);
+    w.dsmap.reserve(npix + 32 * S + 128);
+    w.dside.reserve(S + 16);
+    w.hrep.reserve(1);
+    HIP_CHECK(hipMemcpyAsync(w.dtab.p, wp.data(), wp.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));                               // (wp is a local: the copy must have left the host)
+    unsigned char *l1 = w.lut.p, *l2 = w.lut.p + (size_t)ncell * 16;
+    {
+        KTIME("k_nn_lut_build", s, 32.0 * ncell);
+        hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncell / 64, 64, 0, s, (const double *)w.dtab.p, k, g, w.clist.p, (float4 *)nullptr);
+        hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncell / 64, 64, 0, s, (const double *)w.dtab.p, k, g, l1, l2, (const unsigned char *)w.clist.p, (unsigned int *)nullptr);
+    }
+    double *sx = w.dsort.p, *sy = sx + npix, *sz = sy + npix;
+    {
+        KTIME("k_dither_gather", s, 52.0 * npix);
+        const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(16384, npix / 4096));
+        hipLaunchKernelGGL(k_dither_gather, parts, 64, 0, s, d_img, plane_stride, (unsigned)width, (unsigned)height, parts, sx, sy, sz, w.dpos.p);
+    }
+    a.sx = sx; a.sy = sy; a.sz = sz;
+    a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((npix + 63) & ~(size_t)63));
+    a.list = w.dside.p + 1;
+    a.lut = l1; a.g = g;
+    const size_t lds = (size_t)6 * k * sizeof(double);
+    {
+        KTIME("k_dither", s, 25.0 * npix);
+        hipLaunchKernelGGL(k_dither_lanes<0>, (unsigned)ceil_div(S, 256), 256, lds, s, a, d_pal, k, wts);
+    }
+    HIP_CHECK(hipGetLastError());
+    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0;
+    for (size_t round = 0; S > 1; round++) {
+        if (round > S) throw HipError("patolette_amd: the dither's boundary repairs did not settle");
+        HIP_CHECK(hipMemsetAsync(w.dside.p, 0, sizeof(unsigned), s));
+        {
+            KTIME("k_dither_fix", s, 0.0);
+            hipLaunchKernelGGL(k_dither_lane_check, (unsigned)ceil_div(S - 1, 256), 256, 0, s, a);
+        }
+        HIP_CHECK(hipMemcpyAsync(w.hrep.p, w.dside.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        const unsigned nf = *w.hrep.p;
+        w.dither_rounds = round + 1;
+        if (nf == 0) break;
+        w.dither_repairs += nf;
+        KTIME("k_dither_fix", s, 0.0);
+        hipLaunchKernelGGL(k_dither_lanes<1>, (unsigned)ceil_div((size_t)nf, 256), 256, lds, s, a, d_pal, k, wts);
+        HIP_CHECK(hipGetLastError());
+    }
+    {
+        KTIME("k_dither_unpermute", s, (5.0 + elem_bytes) * npix);
+        const int gb = stream_blocks(npix, 16);
+        if (elem_bytes == 1) hipLaunchKernelGGL(k_dither_unpermute<unsigned char>, gb, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, npix, (unsigned char *)d_out);
+        else if (elem_bytes == 4) hipLaunchKernelGGL(k_dither_unpermute<unsigned int>, gb, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, npix, (unsigned int *)d_out);
+        else hipLaunchKernelGGL(k_dither_unpermute<unsigned long long>, gb, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, npix, (unsigned long long *)d_out);
+    }
+    HIP_CHECK(hipGetLastError());
+}
 
 template <typename OutT>
 static void launch_dither_t(int mode, unsigned blocks, const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal,
@@ -1305,10 +1585,33 @@ static void launch_dither_t(int mode, unsigned blocks, const double *d_img, size
 #undef PAMD_DITHER1
 }
 
-void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
+void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,
                    void *d_out, int elem_bytes, NNWork &w, hipStream_t s) {
     if (width * height >> 32) throw HipError("patolette_amd: the dither kernel numbers pixels with 32 bits");
     if (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8) throw HipError("patolette_amd: map element size must be 1, 4 or 8");
+    {
+        DitherConfig cfg = g_dither_cfg;
+        if (const char *e = getenv("PAMD_DITHER_SEGMENTS")) cfg.segments = atoi(e);
+        if (const char *e = getenv("PAMD_DITHER_WARM")) cfg.warm = atoi(e);
+        if (const char *e = getenv("PAMD_DITHER_LANES")) cfg.lanes = atoi(e);
+        // one lane per run where the pruned search applies and the image is worth it; one wavefront per run (below) otherwise
+        const bool can = k >= 8 && k <= 256 && width * height >= 65536 && cfg.segments != 1;
+        if (can && cfg.lanes != 0) {
+            DitherWeights wts;
+            const double m = std::exp(std::log(16.0) / (16.0 - 1));
+            double v = 1;
+            for (int i = 0; i < 16; i++) { wts.w[i] = v / 16.0; v *= m; }
+            std::vector<double> hp;
+            if (!h_pal) {
+                hp.resize(3 * (size_t)k);
+                HIP_CHECK(hipMemcpyAsync(hp.data(), d_pal, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                h_pal = hp.data();
+            }
+            launch_dither_lanes(d_img, plane_stride, width, height, d_pal, h_pal, k, d_out, elem_bytes, w, cfg, wts, s);
+            return;
+        }
+    }
     size_t lds = ((size_t)6 * k + 3 * 128) * sizeof(double) + 128 * sizeof(unsigned int);      // palette (raw + weighted) + the ring of pending pixels
     double *gtab = nullptr;
     if (lds > 150 * 1024) {                                      // K > 3200: the tables in global memory (workspace kept with the engine)
