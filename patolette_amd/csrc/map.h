@@ -16,15 +16,18 @@ struct NNWork {                        // scratch of the pruned NN map
     DevBuf<unsigned int> dside;        // segment-parallel dither: [S][16] boundary choices + the repair counter
     PinBuf<unsigned int> hrep;         // ... the counter's landing place on the host
     DevBuf<double> dsort;              // lane-per-run dither: the pixels in curve order (3 planes)
-    DevBuf<unsigned int> dpos;         // ... their linear pixel numbers
+    DevBuf<unsigned int> dpos;         // ... their linear pixel numbers (a function of width and height: kept between calls)
+    size_t order_w = 0, order_h = 0; int order_dev = -1;
     DevBuf<unsigned char> dsmap;       // ... the choices in curve order, and behind them the [S][16] boundary records
     size_t dither_segments = 0, dither_repairs = 0, dither_rounds = 0;   // of the last launch_dither
 };
 // lo/hi: exact per-plane min/max of the colours if known (else nullptr: computed with one more pass)
 void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k,
                    void *d_out, int elem_bytes, const double *lo, const double *hi, NNWork &w, hipStream_t s);
-// h_pal: the same palette on the host if the caller has it (else it is read back)
-void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,
+// which: the conversion the pixels still need on their way into linear Rec2020 (PAMD_COPY: none) -- only the lane-per-run layout
+// (dither_lane_layout) converts on the fly; h_pal: the same palette on the host if the caller has it (else it is read back)
+bool dither_lane_layout(size_t width, size_t height, int k);
+void launch_dither(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,
                    void *d_out, int elem_bytes, NNWork &w, hipStream_t s);
 
 // test / tuning knob: runs the curve is cut into (0 = chosen from the image size) and in-image pixels of warm-up (< 0 = default)

@@ -20,6 +20,8 @@
 #include <cmath>
 #include <type_traits>
 
+#define PAMD_POW_TABLES_IN_LDS
+#include "color_device.h"
 #include "devutil.h"
 
 namespace pamd {
@@ -1289,23 +1291,35 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
 // instructions per step.  With runs plentiful (the chain's state is its last sixteen choices: any number of runs can be walked
 // side by side and verified afterwards) the other layout pays: every LANE walks its own run, the error queue in its registers,
 // the nearest colour through the exact-pruning records of the NN map (k_nn_lut_build over the weighted palette: a handful of
-// candidates per query instead of K), ~300 instructions per step of a WAVEFRONT = 64 steps.  A run is a few hundred pixels,
-// the warm-up as long again -- twice the steps, a thirtieth of the instructions each.
-//   k_dither_gather   pixels (and their linear numbers) into curve order: the only place that knows the Hilbert curve;
-//                     a run is then a range of ranks, a warm-up the ranks before it
-//   k_dither_lanes<0> run b: zero queue at rank t_b - warm, choices of ranks [t_b - 16, t_b) -> side[b], of [t_b, t_b+1) -> smap
-//   k_dither_lane_check  boundary b is good iff side[b] equals smap[t_b - 16 .. t_b); the others are listed
-//   k_dither_lanes<1> a listed run again from the queue rebuilt out of smap and the pixels (side[b] := the sixteen choices it
-//                     read), until sixteen consecutive choices equal what is there (the old chain met: the rest stands)
+// candidates per query instead of K), ~450 instructions per step of a WAVEFRONT = 64 steps.  A run is a few hundred pixels,
+// the warm-up as long again -- twice the steps, a twelfth of the instructions each.
+//
+// Layout: run b covers the ranks (positions along the curve among the in-image pixels) [t_b, t_b+1), t_b = N b / S.  Lanes of a
+// wavefront walk 64 consecutive runs in lock step, so the pixels are stored TRANSPOSED: position p of run b at
+// ((b / 64) Lmax + p) 64 + b % 64 -- the 64 lanes' loads of one step are 512 consecutive bytes per plane (first version: every
+// lane its own cache line, 320 line requests per step, and the kernel was bound by exactly that).  The choices are stored the
+// same way.  The warm-up of run b is the last `warm` pixels of run b - 1: the neighbouring column, no copy (warm <= run length).
+//   k_dither_order    rank -> linear pixel number: the only place that knows the Hilbert curve
+//   k_dither_streams  pixels into the transposed layout (tiles of 64 runs x 64 positions through LDS)
+//   k_dither_lanes<0> run b: zero queue `warm` pixels before t_b, the choices of the last sixteen warm-up steps -> side[b], of the run -> smap
+//   k_dither_lane_check  boundary b is good iff side[b] equals the last sixteen choices of run b - 1; the others are listed
+//   k_dither_lanes<1> a listed run again from the queue rebuilt out of those choices and pixels (side[b] := what it read), until
+//                     sixteen consecutive choices equal what is there (the old chain met: the rest stands)
 //   ... check / repair until a check lists nothing: nothing was written since the previous repair, every side[b] equals the
 //       map, and by induction over b (run 0 starts from the true zero queue) smap is the reference's chain
-//   k_dither_unpermute  out[pixel number of rank r] = smap[r]
+//   k_dither_unpermute  out[pixel number of rank t_b + p] = smap(b, p)
 // Arithmetic per step exactly as riemersma.c:275-341 orders it: e = ((0 + q[0] w[0]) + q[1] w[1]) + ... per channel, query =
 // W (pixel + e) with the double weights, squared distance ((d0 d0 + d1 d1) + d2 d2) to the palette scaled by the float-cast
 // weights, ascending index with strict '<', pushed error = pixel - chosen colour.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dither_gather(const double *__restrict__ img, size_t plane_stride, unsigned width, unsigned height, unsigned parts,
-                                                      double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz, unsigned *__restrict__ spos) {
+struct DitherRuns {                      // the cut of the curve and the transposed layout built on it
+    unsigned long long N;
+    unsigned S, Lmax;
+    __host__ __device__ unsigned long long t(const unsigned b) const { return N * b / S; }
+    __host__ __device__ size_t idx(const unsigned b, const unsigned p) const { return ((size_t)(b >> 6) * Lmax + p) * 64 + (b & 63u); }
+};
+
+__global__ __launch_bounds__(64) void k_dither_order(unsigned width, unsigned height, unsigned parts, unsigned *__restrict__ spos) {
     const unsigned mxd = width > height ? width : height;
     int L = 0;
     while ((1u << L) < mxd) L++;
@@ -1316,7 +1330,6 @@ __global__ __launch_bounds__(64) void k_dither_gather(const double *__restrict__
     if (g > 0) dither_locate(L, width, height, npix * g / parts, d0, c);
     if (g + 1 < parts) dither_locate(L, width, height, npix * (g + 1) / parts, d_end, cc);
     const bool needs_skip = width < (1u << L) || height < (1u << L);
-    const double *pr = img, *pg = img + plane_stride, *pb = img + 2 * plane_stride;
     while (d0 < d_end) {
         if (needs_skip) {                                            // whole out-of-image aligned sub-squares
             bool skipped = false;
@@ -1334,30 +1347,85 @@ __global__ __launch_bounds__(64) void k_dither_gather(const double *__restrict__
         hilbert_d2xy(L, d0 + (unsigned long long)lane, x, y);
         const bool inb = x < width && y < height;
         const unsigned long long mask = __ballot(inb);
-        if (inb) {
-            const size_t p = (size_t)y * width + x;
-            const unsigned long long r = c + (unsigned long long)__popcll(mask & ((1ULL << lane) - 1ULL));
-            sx[r] = pr[p]; sy[r] = pg[p]; sz[r] = pb[p];
-            spos[r] = (unsigned)p;
-        }
+        if (inb) spos[c + (unsigned long long)__popcll(mask & ((1ULL << lane) - 1ULL))] = y * width + x;
         c += (unsigned long long)__popcll(mask);
         d0 += 64;
     }
 }
 
+// tile (pt, w): runs 64 w .. 64 w + 63, positions 16 pt .. 16 pt + 15, the three planes together.  Read side: a wavefront takes four
+// runs x sixteen consecutive ranks (pieces of the curve: a few cache lines each); write side: 64 consecutive runs = 512 bytes.
+// WHICH: the conversion into linear Rec2020 the pixels still need (patolette.c:268-299; PAMD_COPY = none), done on the way -- the
+// same device routine k_convert applies, so the same bits, without a pass of its own over the image
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_dither_streams(const double *__restrict__ img, size_t plane_stride, const unsigned *__restrict__ spos, DitherRuns R,
+                                                       double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz) {
+    __shared__ unsigned long long t0[65];
+    __shared__ double tile[3][64][17];
+    const unsigned w = blockIdx.y, p0 = blockIdx.x * 16u, tid = threadIdx.x;
+    if (tid < 65) { const unsigned b = 64u * w + tid; t0[tid] = b <= R.S ? R.t(b) : R.N; }
+    if constexpr (WHICH != PAMD_COPY) pow_tables_to_lds();
+    __syncthreads();
+    unsigned pix[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                                    // consecutive threads: consecutive ranks of one run
+        const unsigned e = tid + 256u * i, l = e >> 4, p = p0 + (e & 15u);
+        const bool ok = 64u * w + l < R.S && t0[l] + p < t0[l + 1];
+        pix[i] = ok ? spos[t0[l] + p] : 0xFFFFFFFFu;
+    }
+    double v[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[i][c] = pix[i] != 0xFFFFFFFFu ? img[(size_t)c * plane_stride + pix[i]] : 0.0;
+    if constexpr (WHICH != PAMD_COPY) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (pix[i] != 0xFFFFFFFFu) dev_convert<WHICH>(v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned e = tid + 256u * i;
+#pragma unroll
+        for (int c = 0; c < 3; c++) tile[c][e >> 4][e & 15u] = v[i][c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                                    // consecutive threads: consecutive runs = consecutive addresses
+        const unsigned e = tid + 256u * i, pp = e >> 6, l = e & 63u;
+        if (p0 + pp < R.Lmax) {
+            const size_t at = R.idx(64u * w + l, p0 + pp);
+            sx[at] = tile[0][l][pp]; sy[at] = tile[1][l][pp]; sz[at] = tile[2][l][pp];
+        }
+    }
+}
+
+// tile (pt, w): runs 64 w .. 64 w + 63, positions 64 pt .. 64 pt + 63 of the choices, back to the image's pixel order
 template <typename OutT>
-__global__ __launch_bounds__(256) void k_dither_unpermute(const unsigned char *__restrict__ smap, const unsigned *__restrict__ spos, size_t n, OutT *__restrict__ out) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) out[spos[r]] = (OutT)smap[r];
+__global__ __launch_bounds__(256) void k_dither_unpermute(const unsigned char *__restrict__ smap, const unsigned *__restrict__ spos, DitherRuns R, OutT *__restrict__ out) {
+    __shared__ unsigned long long t0[65];
+    __shared__ unsigned char sm[64][65];
+    const unsigned w = blockIdx.y, p0 = blockIdx.x * 64u, tid = threadIdx.x;
+    if (tid < 65) { const unsigned b = 64u * w + tid; t0[tid] = b <= R.S ? R.t(b) : R.N; }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {                                   // consecutive threads: consecutive runs = consecutive bytes
+        const unsigned e = tid + 256u * i, pp = e >> 6, l = e & 63u;
+        sm[l][pp] = p0 + pp < R.Lmax ? smap[R.idx(64u * w + l, p0 + pp)] : (unsigned char)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {                                   // consecutive threads: consecutive ranks of one run
+        const unsigned e = tid + 256u * i, l = e >> 6, p = p0 + (e & 63u);
+        if (64u * w + l < R.S && t0[l] + p < t0[l + 1]) out[spos[t0[l] + p]] = (OutT)sm[l][e & 63u];
+    }
 }
 
 struct DitherLanes {
-    const double *sx, *sy, *sz;          // pixels in curve order
-    unsigned char *smap;                 // choices in curve order
+    DitherRuns R;
+    const double *sx, *sy, *sz;          // pixels, transposed layout
+    unsigned char *smap;                 // choices, transposed layout
     unsigned short *side;                // [S][16] the choices a run's starting queue was built from (0xFFFF = none: the run is walked again)
     unsigned *list;                      // runs whose boundary check failed; list[-1] = how many
-    unsigned long long N;
-    unsigned S, warm;
+    unsigned warm;                       // <= the shortest run
     const unsigned char *lut;            // 16-byte records of the G^3 grid over the weighted palette (k_nn_lut_build)
     NNGrid g;
     double hi[3];                        // upper corner of the grid: queries outside [lo, hi] take the full scan
@@ -1365,10 +1433,10 @@ struct DitherLanes {
 
 __global__ __launch_bounds__(256) void k_dither_lane_check(DitherLanes a) {
     const unsigned b = blockIdx.x * blockDim.x + threadIdx.x + 1u;
-    if (b >= a.S) return;
-    const unsigned long long t = a.N * b / a.S;
+    if (b >= a.R.S) return;
+    const unsigned lp = (unsigned)(a.R.t(b) - a.R.t(b - 1));        // length of run b - 1
     bool same = true;
-    for (int i = 0; i < 16; i++) same = same && a.side[16ull * b + i] == (unsigned short)a.smap[t - 16 + i];
+    for (unsigned i = 0; i < 16; i++) same = same && a.side[16ull * b + i] == (unsigned short)a.smap[a.R.idx(b - 1, lp - 16 + i)];
     if (!same) a.list[atomicAdd(a.list - 1, 1u)] = b;
 }
 
@@ -1383,12 +1451,16 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
     const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
     bool active;
     unsigned b = 0;
-    if constexpr (MODE == 0) { active = gid < a.S; b = active ? gid : 0u; }
+    if constexpr (MODE == 0) { active = gid < a.R.S; b = active ? gid : 0u; }
     else { const unsigned nl = a.list[-1]; active = gid < nl; b = active ? a.list[gid] : 1u; }
-    const unsigned long long t_b = a.N * b / a.S, t_e = b + 1 < a.S ? a.N * (b + 1) / a.S : a.N;
-    unsigned long long r = MODE == 0 ? (t_b > a.warm ? t_b - a.warm : 0ULL) : t_b;
+    const unsigned len = (unsigned)(a.R.t(b + 1) - a.R.t(b));       // this run
+    const unsigned lp = b > 0 ? (unsigned)(a.R.t(b) - a.R.t(b - 1)) : 0u;   // the one before it
+    // steps [0, wu) read the end of run b - 1 (the neighbouring column), steps [wu, wu + len) this run
+    const unsigned wu = MODE == 0 ? (b > 0 ? a.warm : 0u) : 0u;
+    const size_t own = a.R.idx(b, 0);
+    size_t at = wu ? a.R.idx(b - 1, lp - wu) : own;                // where step 0 reads
     if constexpr (MODE == 0) {
-        if (active && b > 0 && t_b - r < 16) {                      // a warm-up of fewer than sixteen steps leaves no record to pass the check
+        if (active && b > 0 && wu < 16) {                           // a warm-up of fewer than sixteen steps leaves no record to pass the check
             for (int i = 0; i < 16; i++) a.side[16ull * b + i] = 0xFFFFu;
         }
     }
@@ -1397,10 +1469,10 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
     for (int s = 0; s < 16; s++) { q0[s] = 0.0; q1[s] = 0.0; q2[s] = 0.0; }
     if constexpr (MODE == 1) {
         if (active) {
-            // the queue as the chain holds it after ranks t_b - 16 .. t_b - 1: original pixel - chosen colour, oldest first
+            // the queue as the chain holds it after the last sixteen pixels of run b - 1: original pixel - chosen colour, oldest first
 #pragma unroll
             for (int s = 0; s < 16; s++) {
-                const unsigned long long rr = t_b - 16 + s;
+                const size_t rr = a.R.idx(b - 1, lp - 16 + s);
                 const unsigned c = a.smap[rr];
                 a.side[16ull * b + s] = (unsigned short)c;
                 q0[s] = a.sx[rr] - praw[c]; q1[s] = a.sy[rr] - praw[k + c]; q2[s] = a.sz[rr] - praw[2 * k + c];
@@ -1436,18 +1508,22 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
         if (__any(slow)) { if (slow) for (int j = 0; j < k; j++) test(j); }
         return best;
     };
-    double c0 = 0, c1 = 0, c2 = 0;                                  // the pixel of rank r, fetched one step ahead
+    const unsigned nsteps = wu + len;
+    unsigned st = 0;                                                // step number
+    double c0 = 0, c1 = 0, c2 = 0;                                  // the pixel of step st, fetched one step ahead
     int cm = 0;                                                     // MODE 1: and the choice smap holds for it
-    bool on = active && r < t_e;
-    if (on) { c0 = a.sx[r]; c1 = a.sy[r]; c2 = a.sz[r]; if constexpr (MODE == 1) cm = (int)a.smap[r]; }
+    bool on = active && nsteps > 0;
+    if (on) { c0 = a.sx[at]; c1 = a.sy[at]; c2 = a.sz[at]; if constexpr (MODE == 1) cm = (int)a.smap[at]; }
     int streak = 0;                                                 // MODE 1: consecutive choices equal to what smap holds
     while (__any(on)) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const double p0 = c0, p1 = c1, p2 = c2;
             const int was = cm;
-            const bool nxt = on && r + 1 < t_e;
-            if (nxt) { c0 = a.sx[r + 1]; c1 = a.sy[r + 1]; c2 = a.sz[r + 1]; if constexpr (MODE == 1) cm = (int)a.smap[r + 1]; }
+            const size_t cur = at;
+            const bool nxt = on && st + 1 < nsteps;
+            at = (st + 1 == wu) ? own : at + 64;                    // the run starts where the neighbour's column ends
+            if (nxt) { c0 = a.sx[at]; c1 = a.sy[at]; c2 = a.sz[at]; if constexpr (MODE == 1) cm = (int)a.smap[at]; }
             double e0 = 0.0, e1 = 0.0, e2 = 0.0;                    // riemersma.c:282-296, in that order
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -1458,14 +1534,14 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
             if (on) {
                 q0[j] = p0 - praw[bi]; q1[j] = p1 - praw[k + bi]; q2[j] = p2 - praw[2 * k + bi];       // riemersma.c:333-340
                 if constexpr (MODE == 0) {
-                    if (r >= t_b) a.smap[r] = (unsigned char)bi;
-                    else if (r + 16 >= t_b) a.side[16ull * b + (unsigned)(r + 16 - t_b)] = (unsigned short)bi;
+                    if (st >= wu) a.smap[cur] = (unsigned char)bi;
+                    else if (st + 16 >= wu) a.side[16ull * b + (st + 16 - wu)] = (unsigned short)bi;
                 } else {
                     if (was == bi) streak++;
-                    else { streak = 0; a.smap[r] = (unsigned char)bi; }
+                    else { streak = 0; a.smap[cur] = (unsigned char)bi; }
                 }
             }
-            r++;
+            st++;
             on = nxt && (MODE == 0 || streak < 16);
         }
     }
@@ -1476,17 +1552,19 @@ static DitherConfig g_dither_cfg;
 void dither_config(int segments, int warm) { g_dither_cfg.segments = segments; g_dither_cfg.warm = warm; }
 void dither_layout(int lanes) { g_dither_cfg.lanes = lanes; }
 
+static int current_device() { int d = -1; (void)hipGetDevice(&d); return d; }
+
 // One lane per run (k_dither_lanes): K in [8, 256], images of 2^16 pixels and more.  h_pal: the palette on the host, planar (k,3).
-static void launch_dither_lanes(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, const double *h_pal,
+static void launch_dither_lanes(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal,
                                 int k, void *d_out, int elem_bytes, NNWork &w, const DitherConfig &cfg, const DitherWeights &wts, hipStream_t s) {
     const size_t npix = width * height;
     DitherLanes a{};
-    a.N = npix;
-    a.warm = cfg.warm >= 0 ? (unsigned)cfg.warm : 512u;
     // runs: eight wavefronts of 64 per CU (two per SIMD), none shorter than 256 pixels unless asked for
     size_t S = cfg.segments > 0 ? (size_t)cfg.segments : std::min<size_t>((size_t)num_cus() * 8 * 64, npix / 256);
-    S = std::max<size_t>(1, std::min(S, npix / 64));
-    a.S = (unsigned)S;
+    S = std::max<size_t>(1, std::min(std::min(S, npix / 64), (size_t)64 * 65535));   // (a tile row per 64 runs: grid.y)
+    a.R.N = npix; a.R.S = (unsigned)S; a.R.Lmax = (unsigned)ceil_div(npix, S);
+    a.warm = (unsigned)std::min<size_t>(cfg.warm >= 0 ? (size_t)cfg.warm : 512, npix / S);     // (the warm-up of a run is the end of its predecessor)
+    const size_t nw = ceil_div(S, 64), cells = nw * a.R.Lmax * 64;
     // the grid of the exact-pruning records: the weighted palette's bounding box, half its extent wider on every side -- error
     // diffusion pushes queries beyond the palette's hull; what still falls outside takes the full scan
     std::vector<double> wp(3 * (size_t)k);
@@ -1500,18 +1578,19 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, size_t
         if (!(r > 0) || !std::isfinite(r)) r = 0;
         const double m = 0.5 * r + 1e-3;
         g.lo[c] = lo - m;
-        const double R = r + 2 * m;
-        g.cw[c] = R / g.G;
-        g.inv[c] = g.G / R;
-        a.hi[c] = g.lo[c] + R;
+        const double Rg = r + 2 * m;
+        g.cw[c] = Rg / g.G;
+        g.inv[c] = g.G / Rg;
+        a.hi[c] = g.lo[c] + Rg;
     }
     const int ncell = g.G * g.G * g.G;
     w.dtab.reserve(3 * (size_t)k);
     w.lut.reserve((size_t)ncell * 32);
     w.clist.reserve((size_t)(ncell / 64) * (1 + kCoarseMax) * 2);
-    w.dsort.reserve(3 * npix);
+    w.dsort.reserve(3 * cells);
+    if (w.dpos.cap < npix) { w.order_w = 0; w.order_h = 0; }
     w.dpos.reserve(npix);
-    w.dsmap.reserve(npix + 32 * S + 128);
+    w.dsmap.reserve(cells + 32 * S + 128);
     w.dside.reserve(S + 16);
     w.hrep.reserve(1);
     HIP_CHECK(hipMemcpyAsync(w.dtab.p, wp.data(), wp.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1522,14 +1601,28 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, size_t
         hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncell / 64, 64, 0, s, (const double *)w.dtab.p, k, g, w.clist.p, (float4 *)nullptr);
         hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncell / 64, 64, 0, s, (const double *)w.dtab.p, k, g, l1, l2, (const unsigned char *)w.clist.p, (unsigned int *)nullptr);
     }
-    double *sx = w.dsort.p, *sy = sx + npix, *sz = sy + npix;
+    double *sx = w.dsort.p, *sy = sx + cells, *sz = sy + cells;
+    const dim3 tiles((unsigned)ceil_div((size_t)a.R.Lmax, 64), (unsigned)nw), tiles16((unsigned)ceil_div((size_t)a.R.Lmax, 16), (unsigned)nw);
+    if (!(w.order_w == width && w.order_h == height && w.order_dev == current_device())) {
+        // rank -> pixel number is a function of the image's dimensions alone: kept between calls on images of one size
+        KTIME("k_dither_order", s, 4.0 * npix);
+        const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(8192, npix / 16384));
+        hipLaunchKernelGGL(k_dither_order, parts, 64, 0, s, (unsigned)width, (unsigned)height, parts, w.dpos.p);
+        w.order_w = width; w.order_h = height; w.order_dev = current_device();
+    }
     {
         KTIME("k_dither_gather", s, 52.0 * npix);
-        const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(16384, npix / 4096));
-        hipLaunchKernelGGL(k_dither_gather, parts, 64, 0, s, d_img, plane_stride, (unsigned)width, (unsigned)height, parts, sx, sy, sz, w.dpos.p);
+        const unsigned *sp = (const unsigned *)w.dpos.p;
+        switch (which) {
+            case PAMD_COPY: hipLaunchKernelGGL(k_dither_streams<PAMD_COPY>, tiles16, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
+            case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_SRGB_TO_REC2020>, tiles16, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
+            case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_CIELUV_TO_REC2020>, tiles16, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
+            case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_ICTCP_TO_REC2020>, tiles16, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
+            default: throw HipError("patolette_amd: the dither takes its pixels as linear Rec2020, sRGB, CIELuv or ICtCp");
+        }
     }
     a.sx = sx; a.sy = sy; a.sz = sz;
-    a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((npix + 63) & ~(size_t)63));
+    a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((cells + 63) & ~(size_t)63));
     a.list = w.dside.p + 1;
     a.lut = l1; a.g = g;
     const size_t lds = (size_t)6 * k * sizeof(double);
@@ -1558,10 +1651,9 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, size_t
     }
     {
         KTIME("k_dither_unpermute", s, (5.0 + elem_bytes) * npix);
-        const int gb = stream_blocks(npix, 16);
-        if (elem_bytes == 1) hipLaunchKernelGGL(k_dither_unpermute<unsigned char>, gb, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, npix, (unsigned char *)d_out);
-        else if (elem_bytes == 4) hipLaunchKernelGGL(k_dither_unpermute<unsigned int>, gb, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, npix, (unsigned int *)d_out);
-        else hipLaunchKernelGGL(k_dither_unpermute<unsigned long long>, gb, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, npix, (unsigned long long *)d_out);
+        if (elem_bytes == 1) hipLaunchKernelGGL(k_dither_unpermute<unsigned char>, tiles, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, a.R, (unsigned char *)d_out);
+        else if (elem_bytes == 4) hipLaunchKernelGGL(k_dither_unpermute<unsigned int>, tiles, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, a.R, (unsigned int *)d_out);
+        else hipLaunchKernelGGL(k_dither_unpermute<unsigned long long>, tiles, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, a.R, (unsigned long long *)d_out);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1585,18 +1677,26 @@ static void launch_dither_t(int mode, unsigned blocks, const double *d_img, size
 #undef PAMD_DITHER1
 }
 
-void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,
+static DitherConfig dither_settings() {
+    DitherConfig cfg = g_dither_cfg;
+    if (const char *e = getenv("PAMD_DITHER_SEGMENTS")) cfg.segments = atoi(e);
+    if (const char *e = getenv("PAMD_DITHER_WARM")) cfg.warm = atoi(e);
+    if (const char *e = getenv("PAMD_DITHER_LANES")) cfg.lanes = atoi(e);
+    return cfg;
+}
+// one lane per run where the pruned search applies and the image is worth it; one wavefront per run otherwise
+bool dither_lane_layout(size_t width, size_t height, int k) {
+    const DitherConfig cfg = dither_settings();
+    return k >= 8 && k <= 256 && width * height >= 65536 && cfg.segments != 1 && cfg.lanes != 0;
+}
+
+void launch_dither(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,
                    void *d_out, int elem_bytes, NNWork &w, hipStream_t s) {
     if (width * height >> 32) throw HipError("patolette_amd: the dither kernel numbers pixels with 32 bits");
     if (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8) throw HipError("patolette_amd: map element size must be 1, 4 or 8");
     {
-        DitherConfig cfg = g_dither_cfg;
-        if (const char *e = getenv("PAMD_DITHER_SEGMENTS")) cfg.segments = atoi(e);
-        if (const char *e = getenv("PAMD_DITHER_WARM")) cfg.warm = atoi(e);
-        if (const char *e = getenv("PAMD_DITHER_LANES")) cfg.lanes = atoi(e);
-        // one lane per run where the pruned search applies and the image is worth it; one wavefront per run (below) otherwise
-        const bool can = k >= 8 && k <= 256 && width * height >= 65536 && cfg.segments != 1;
-        if (can && cfg.lanes != 0) {
+        const DitherConfig cfg = dither_settings();
+        if (dither_lane_layout(width, height, k)) {
             DitherWeights wts;
             const double m = std::exp(std::log(16.0) / (16.0 - 1));
             double v = 1;
@@ -1608,9 +1708,10 @@ void launch_dither(const double *d_img, size_t plane_stride, size_t width, size_
                 HIP_CHECK(hipStreamSynchronize(s));
                 h_pal = hp.data();
             }
-            launch_dither_lanes(d_img, plane_stride, width, height, d_pal, h_pal, k, d_out, elem_bytes, w, cfg, wts, s);
+            launch_dither_lanes(d_img, plane_stride, which, width, height, d_pal, h_pal, k, d_out, elem_bytes, w, cfg, wts, s);
             return;
         }
+        if (which != PAMD_COPY) throw HipError("patolette_amd: the wavefront-per-run dither takes linear Rec2020 pixels");
     }
     size_t lds = ((size_t)6 * k + 3 * 128) * sizeof(double) + 128 * sizeof(unsigned int);      // palette (raw + weighted) + the ring of pending pixels
     double *gtab = nullptr;

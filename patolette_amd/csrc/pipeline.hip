@@ -1248,11 +1248,16 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
             palette_rows(pal, len, pf);
             E.map_palette = pal;
             if (d_map) {
-                E.aux.reserve(3 * N);
-                launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);          // plane stride of cvt is N for x,y,z
                 HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                launch_dither(E.aux.p, N, width, height, E.dpal.p, pal.data(), (int)len, d_map, map_elem, E.nn, s);
+                if (dither_lane_layout(width, height, (int)len)) {
+                    // the pixels go into curve order anyway: their conversion to linear Rec2020 rides on that pass
+                    launch_dither(E.cvt.p, N, pix, width, height, E.dpal.p, pal.data(), (int)len, d_map, map_elem, E.nn, s);
+                } else {
+                    E.aux.reserve(3 * N);
+                    launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);      // plane stride of cvt is N for x,y,z
+                    launch_dither(E.aux.p, N, PAMD_COPY, width, height, E.dpal.p, pal.data(), (int)len, d_map, map_elem, E.nn, s);
+                }
                 E.stats.dither_segments = E.nn.dither_segments; E.stats.dither_repairs = E.nn.dither_repairs; E.stats.dither_rounds = E.nn.dither_rounds;
             }
             palette_rows(pal, len, hm::color::rec2020_to_srgb);
@@ -2121,7 +2126,7 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
     E.src.reserve(3 * n); E.dpal.reserve(3 * k); E.dmap.reserve(n * 4);
     HIP_CHECK(hipMemcpy(E.src.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(E.dpal.p, palette, 3 * k * sizeof(double), hipMemcpyHostToDevice));
-    launch_dither(E.src.p, n, width, height, E.dpal.p, palette, (int)k, E.dmap.p, 4, E.nn, E.stream);
+    launch_dither(E.src.p, n, PAMD_COPY, width, height, E.dpal.p, palette, (int)k, E.dmap.p, 4, E.nn, E.stream);
     E.stats.dither_segments = E.nn.dither_segments; E.stats.dither_repairs = E.nn.dither_repairs; E.stats.dither_rounds = E.nn.dither_rounds;
     E.sync();
     if (std::max(width, height) > 1) {
