@@ -931,7 +931,8 @@ def main():
                                                         if args.kmeans_update else "reference (sequential f32 chains, bit-exact)"),
                    "width": width, "height": height, "palette_size": K, "images_per_step_per_gpu": S,
                    "input": "uniform random sRGB (splitmix64), planar f64, resident in HBM; index map left in HBM as u8",
-                   "cached_between_steps": "the KMeans subsample index list (faiss rand_perm(N, seed 1234): a pure function of N) stays on the device "
+                   "cached_between_steps": "the dither's curve order (rank along the Hilbert curve -> pixel number: a pure function of width and height) and "
+                                           "the KMeans subsample index list (faiss rand_perm(N, seed 1234): a pure function of N) stay on the device "
                                            "between calls; a first call makes it on a helper thread beside conversion and the quantisers -- "
                                            "`first_call` is the same step with the list made again in every call; a pool of <= 3 distinct images "
                                            "rotates through the steps",

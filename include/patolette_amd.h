@@ -197,7 +197,9 @@ int patolette_amd_set_kmeans_update(int mode);
 /* The KMeans subsample list (faiss rand_perm(N, seed 1234), Clustering.cpp:311-319: a pure function of the pixel count) is made
  * on a helper thread that starts at call entry and is joined when the KMeans stage begins.  1 (default): the list stays on the
  * device between calls on images of one size; 0: every call makes it again -- the cost of a FIRST call of a size, call after
- * call (bench.py reports both).  Process-wide.  Returns the previous setting. */
+ * call (bench.py reports both).  The same switch governs the other size-only table kept between calls: the Riemersma dither's
+ * curve order (rank along the Hilbert curve -> pixel number, 4 bytes per pixel, a function of width and height alone).
+ * Process-wide.  Returns the previous setting. */
 int patolette_amd_set_subsample_cache(int on);
 
 /* ---- single stages, host buffers in / out (for parity tests) ------------------------------ */

@@ -34,5 +34,7 @@ void launch_dither(const double *d_img, size_t plane_stride, int which, size_t w
 void dither_config(int segments, int warm);
 // which layout walks the runs: 1 = one lane per run where it applies (default), 0 = one wavefront per run, -1 = default
 void dither_layout(int lanes);
+// keep the curve order of an image size on the device between calls (default) or make it again in every call
+void dither_order_cache(bool on);
 
 }  // namespace pamd

@@ -1429,6 +1429,7 @@ struct DitherLanes {
     const unsigned char *lut;            // 16-byte records of the G^3 grid over the weighted palette (k_nn_lut_build)
     NNGrid g;
     double hi[3];                        // upper corner of the grid: queries outside [lo, hi] take the full scan
+    float amb;                           // f32 first pass: first and second must differ by more than this
 };
 
 __global__ __launch_bounds__(256) void k_dither_lane_check(DitherLanes a) {
@@ -1444,9 +1445,13 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const double *__restrict__ pal /* planar (k,3), linear Rec2020 */, int k, DitherWeights wts) {
     extern __shared__ double lds[];
     double *praw = lds, *pwt = lds + 3 * k;                        // [3][k] raw palette; [3][k] scaled by the (float)-cast weights (riemersma.c:419-425)
+    float4 *r32 = reinterpret_cast<float4 *>(lds + 6 * k);          // [k] {-2 (p - lo), |p - lo|^2} of the weighted palette in f32
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
-    for (int j = threadIdx.x; j < k; j += blockDim.x)
-        for (int c = 0; c < 3; c++) { const double v = pal[c * k + j]; praw[c * k + j] = v; pwt[c * k + j] = v * fw[c]; }
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        double sh[3];
+        for (int c = 0; c < 3; c++) { const double v = pal[c * k + j]; praw[c * k + j] = v; pwt[c * k + j] = v * fw[c]; sh[c] = v * fw[c] - a.g.lo[c]; }
+        r32[j] = make_float4((float)(-2.0 * sh[0]), (float)(-2.0 * sh[1]), (float)(-2.0 * sh[2]), (float)((sh[0] * sh[0] + sh[1] * sh[1]) + sh[2] * sh[2]));
+    }
     __syncthreads();
     const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
     bool active;
@@ -1482,13 +1487,12 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
     const int G = a.g.G;
     const double lo0 = a.g.lo[0], lo1 = a.g.lo[1], lo2 = a.g.lo[2], in0 = a.g.inv[0], in1 = a.g.inv[1], in2 = a.g.inv[2];
     const double hi0 = a.hi[0], hi1 = a.hi[1], hi2 = a.hi[2];
+    // Nearest colour.  First pass in f32 over the cell's candidates, as in k_nn_map_mid: t_j = |x - p_j|^2 - |x - lo|^2 from the
+    // shifted records {-2 (p - lo), |p - lo|^2} (three fma), smallest and second smallest tracked; the smallest names the winner of
+    // the f64 expression whenever the second lies more than a.amb above it (the bound of map.hip's table comment: the query is
+    // inside the grid here, the palette's |p - lo|^2 is bounded by the host).  Otherwise -- about one query in a thousand, and
+    // every query outside the grid or in a cell whose list runs past one record -- the exact f64 loop decides.
     auto nearest = [&](const double x, const double y, const double z, const bool on) -> int {
-        double bd = INFINITY; int best = 0;
-        auto test = [&](const int j) {
-            const double d0 = x - pwt[j], d1 = y - pwt[k + j], d2 = z - pwt[2 * k + j];
-            const double d = (d0 * d0 + d1 * d1) + d2 * d2;
-            if (d < bd) { bd = d; best = j; }                       // ascending j + strict '<' = lowest index on ties
-        };
         const bool inside = x >= lo0 && x <= hi0 && y >= lo1 && y <= hi1 && z >= lo2 && z <= hi2;   // (a NaN: not inside)
         int cnt = 0;
         unsigned long long w0 = 0, w1 = 0;
@@ -1498,14 +1502,37 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
             w0 = ((unsigned long long)rec.y << 32) | rec.x; w1 = ((unsigned long long)rec.w << 32) | rec.z;
             w0 = (w0 >> 8) | (w1 << 56); w1 >>= 8;
         }
-        const bool slow = on && (!inside || cnt > 15);              // outside the grid, or a cell whose list runs past one record
-        const int n = slow ? 0 : cnt;
-        for (int t = 0; __any(t < n); t++) {
-            const int j = (int)(w0 & 0xffULL);
-            w0 = (w0 >> 8) | (w1 << 56); w1 >>= 8;
-            if (t < n) test(j);
+        const bool listed = on && inside && cnt <= 15;              // else: outside the grid, or a cell whose list runs past one record
+        const int n = listed ? cnt : 0;
+        const float xf = (float)(x - lo0), yf = (float)(y - lo1), zf = (float)(z - lo2);
+        float m1 = INFINITY, m2 = INFINITY; int best = 0;
+        {
+            unsigned long long v0 = w0, v1 = w1;
+            for (int t = 0; __any(t < n); t++) {
+                const int j = (int)(v0 & 0xffULL);
+                v0 = (v0 >> 8) | (v1 << 56); v1 >>= 8;
+                const float4 r = r32[j];
+                float tj = __builtin_fmaf(xf, r.x, __builtin_fmaf(yf, r.y, __builtin_fmaf(zf, r.z, r.w)));
+                tj = t < n ? tj : INFINITY;
+                m2 = __builtin_fminf(m2, __builtin_fmaxf(m1, tj));
+                best = tj < m1 ? j : best;
+                m1 = __builtin_fminf(m1, tj);
+            }
         }
-        if (__any(slow)) { if (slow) for (int j = 0; j < k; j++) test(j); }
+        const bool exact = on && !(listed && (m2 - m1) > a.amb);    // (a NaN anywhere: exact)
+        if (__any(exact)) {
+            if (exact) {
+                double bd = INFINITY; best = 0;
+                auto test = [&](const int j) {
+                    const double d0 = x - pwt[j], d1 = y - pwt[k + j], d2 = z - pwt[2 * k + j];
+                    const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+                    if (d < bd) { bd = d; best = j; }               // ascending j + strict '<' = lowest index on ties
+                };
+                if (listed) {
+                    for (int t = 0; t < n; t++) { test((int)(w0 & 0xffULL)); w0 = (w0 >> 8) | (w1 << 56); w1 >>= 8; }
+                } else for (int j = 0; j < k; j++) test(j);
+            }
+        }
         return best;
     };
     const unsigned nsteps = wu + len;
@@ -1553,6 +1580,8 @@ void dither_config(int segments, int warm) { g_dither_cfg.segments = segments; g
 void dither_layout(int lanes) { g_dither_cfg.lanes = lanes; }
 
 static int current_device() { int d = -1; (void)hipGetDevice(&d); return d; }
+static bool g_dither_order_cache = true;
+void dither_order_cache(bool on) { g_dither_order_cache = on; }
 
 // One lane per run (k_dither_lanes): K in [8, 256], images of 2^16 pixels and more.  h_pal: the palette on the host, planar (k,3).
 static void launch_dither_lanes(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal,
@@ -1583,6 +1612,20 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         g.inv[c] = g.G / Rg;
         a.hi[c] = g.lo[c] + Rg;
     }
+    {
+        // margin of the f32 first pass (the table comment above k_nn_map_mid): 2.5 E, E = 2^-24 (9 max |p - lo|^2 + 5 |hi - lo|^2) (1 + 1e-3)
+        double wmax = 0.0, r2 = 0.0;
+        for (int j = 0; j < k; j++) {
+            double d = 0.0;
+            for (int c = 0; c < 3; c++) { const double t = wp[(size_t)c * k + j] - g.lo[c]; d += t * t; }
+            wmax = std::max(wmax, d);
+        }
+        for (int c = 0; c < 3; c++) { const double t = a.hi[c] - g.lo[c]; r2 += t * t; }
+        const double M = 2.5 * 1.001 * 0x1.0p-24 * (9.0 * wmax + 5.0 * r2);
+        a.amb = (float)M;
+        if ((double)a.amb < M) a.amb = std::nextafter(a.amb, INFINITY);
+        if (!(M < 3.0e38)) a.amb = INFINITY;
+    }
     const int ncell = g.G * g.G * g.G;
     w.dtab.reserve(3 * (size_t)k);
     w.lut.reserve((size_t)ncell * 32);
@@ -1603,7 +1646,7 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     }
     double *sx = w.dsort.p, *sy = sx + cells, *sz = sy + cells;
     const dim3 tiles((unsigned)ceil_div((size_t)a.R.Lmax, 64), (unsigned)nw), tiles16((unsigned)ceil_div((size_t)a.R.Lmax, 16), (unsigned)nw);
-    if (!(w.order_w == width && w.order_h == height && w.order_dev == current_device())) {
+    if (!(g_dither_order_cache && w.order_w == width && w.order_h == height && w.order_dev == current_device())) {
         // rank -> pixel number is a function of the image's dimensions alone: kept between calls on images of one size
         KTIME("k_dither_order", s, 4.0 * npix);
         const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(8192, npix / 16384));
@@ -1625,7 +1668,7 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((cells + 63) & ~(size_t)63));
     a.list = w.dside.p + 1;
     a.lut = l1; a.g = g;
-    const size_t lds = (size_t)6 * k * sizeof(double);
+    const size_t lds = (size_t)6 * k * sizeof(double) + (size_t)k * sizeof(float4);
     {
         KTIME("k_dither", s, 25.0 * npix);
         hipLaunchKernelGGL(k_dither_lanes<0>, (unsigned)ceil_div(S, 256), 256, lds, s, a, d_pal, k, wts);
@@ -1684,10 +1727,14 @@ static DitherConfig dither_settings() {
     if (const char *e = getenv("PAMD_DITHER_LANES")) cfg.lanes = atoi(e);
     return cfg;
 }
-// one lane per run where the pruned search applies and the image is worth it; one wavefront per run otherwise
+// One lane per run where the pruned search applies (8 <= K <= 256) and the image is large: the lane layout needs ~10^5 runs of a few
+// hundred pixels to fill the GPU and pays a gather, an un-permute and a repair round of fixed cost -- 2048^2: 2.3 ms against 1.6 ms
+// for one wavefront per run, 4096^2: 2.7 ms, 8192^2: 4.8 against 15.6 ms.  dither_layout(1) asks for it from 65 536 pixels on.
 bool dither_lane_layout(size_t width, size_t height, int k) {
     const DitherConfig cfg = dither_settings();
-    return k >= 8 && k <= 256 && width * height >= 65536 && cfg.segments != 1 && cfg.lanes != 0;
+    const size_t npix = width * height;
+    if (!(k >= 8 && k <= 256) || cfg.segments == 1 || cfg.lanes == 0) return false;
+    return cfg.lanes > 0 ? npix >= 65536 : npix >= ((size_t)1 << 23);
 }
 
 void launch_dither(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,

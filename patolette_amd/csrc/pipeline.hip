@@ -1747,6 +1747,7 @@ int patolette_amd_set_invariant_sums(int on) {
 }
 
 int patolette_amd_set_subsample_cache(int on) {
+    dither_order_cache(on != 0);             // the other size-only table kept between calls: the dither's curve order (map.hip)
     return g_perm_cache.exchange(on != 0 ? 1 : 0, std::memory_order_relaxed);
 }
 
