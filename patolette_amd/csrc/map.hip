@@ -1353,47 +1353,47 @@ __global__ __launch_bounds__(64) void k_dither_order(unsigned width, unsigned he
     }
 }
 
-// tile (pt, w): runs 64 w .. 64 w + 63, positions 16 pt .. 16 pt + 15, the three planes together.  Read side: a wavefront takes four
-// runs x sixteen consecutive ranks (pieces of the curve: a few cache lines each); write side: 64 consecutive runs = 512 bytes.
+// tile (pt, w): runs 8 w .. 8 w + 7, positions 256 pt .. 256 pt + 255, the three planes together.  Read side: 256 consecutive ranks of
+// a run are a 16 x 16 square of the image when the run starts on a multiple of 256 (power-of-two images: always) -- sixteen whole
+// 128-byte lines per plane; with tiles of 16 ranks per run every line was fetched twice over (FETCH_SIZE 8.6 GB for 3.5 GB of
+// pixels).  Write side: eight consecutive runs = 64 bytes.
 // WHICH: the conversion into linear Rec2020 the pixels still need (patolette.c:268-299; PAMD_COPY = none), done on the way -- the
 // same device routine k_convert applies, so the same bits, without a pass of its own over the image
 template <int WHICH>
 __global__ __launch_bounds__(256) void k_dither_streams(const double *__restrict__ img, size_t plane_stride, const unsigned *__restrict__ spos, DitherRuns R,
                                                        double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz) {
-    __shared__ unsigned long long t0[65];
-    __shared__ double tile[3][64][17];
-    const unsigned w = blockIdx.y, p0 = blockIdx.x * 16u, tid = threadIdx.x;
-    if (tid < 65) { const unsigned b = 64u * w + tid; t0[tid] = b <= R.S ? R.t(b) : R.N; }
+    __shared__ unsigned long long t0[9];
+    __shared__ double tile[3][8][257];
+    const unsigned w = blockIdx.y, p0 = blockIdx.x * 256u, tid = threadIdx.x;
+    if (tid < 9) { const unsigned b = 8u * w + tid; t0[tid] = b <= R.S ? R.t(b) : R.N; }
     if constexpr (WHICH != PAMD_COPY) pow_tables_to_lds();
     __syncthreads();
-    unsigned pix[4];
+    unsigned pix[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {                                    // consecutive threads: consecutive ranks of one run
-        const unsigned e = tid + 256u * i, l = e >> 4, p = p0 + (e & 15u);
-        const bool ok = 64u * w + l < R.S && t0[l] + p < t0[l + 1];
-        pix[i] = ok ? spos[t0[l] + p] : 0xFFFFFFFFu;
+    for (int i = 0; i < 8; i++) {                                    // run i of the tile: consecutive threads = consecutive ranks
+        const unsigned p = p0 + tid;
+        const bool ok = 8u * w + i < R.S && t0[i] + p < t0[i + 1];
+        pix[i] = ok ? spos[t0[i] + p] : 0xFFFFFFFFu;
     }
-    double v[4][3];
+    double v[8][3];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int c = 0; c < 3; c++) v[i][c] = pix[i] != 0xFFFFFFFFu ? img[(size_t)c * plane_stride + pix[i]] : 0.0;
     if constexpr (WHICH != PAMD_COPY) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (pix[i] != 0xFFFFFFFFu) dev_convert<WHICH>(v[i]);
+        for (int i = 0; i < 8; i++) if (pix[i] != 0xFFFFFFFFu) dev_convert<WHICH>(v[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const unsigned e = tid + 256u * i;
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) tile[c][e >> 4][e & 15u] = v[i][c];
-    }
+        for (int c = 0; c < 3; c++) tile[c][i][tid] = v[i][c];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; i++) {                                    // consecutive threads: consecutive runs = consecutive addresses
-        const unsigned e = tid + 256u * i, pp = e >> 6, l = e & 63u;
+    for (int i = 0; i < 8; i++) {                                    // consecutive threads: the eight runs of one position, then the next position
+        const unsigned e = tid + 256u * i, pp = e >> 3, l = e & 7u;
         if (p0 + pp < R.Lmax) {
-            const size_t at = R.idx(64u * w + l, p0 + pp);
+            const size_t at = R.idx(8u * w + l, p0 + pp);
             sx[at] = tile[0][l][pp]; sy[at] = tile[1][l][pp]; sz[at] = tile[2][l][pp];
         }
     }
@@ -1590,7 +1590,7 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     DitherLanes a{};
     // runs: eight wavefronts of 64 per CU (two per SIMD), none shorter than 256 pixels unless asked for
     size_t S = cfg.segments > 0 ? (size_t)cfg.segments : std::min<size_t>((size_t)num_cus() * 8 * 64, npix / 256);
-    S = std::max<size_t>(1, std::min(std::min(S, npix / 64), (size_t)64 * 65535));   // (a tile row per 64 runs: grid.y)
+    S = std::max<size_t>(1, std::min(std::min(S, npix / 64), (size_t)8 * 65535));    // (a tile row per 8 runs: grid.y)
     a.R.N = npix; a.R.S = (unsigned)S; a.R.Lmax = (unsigned)ceil_div(npix, S);
     a.warm = (unsigned)std::min<size_t>(cfg.warm >= 0 ? (size_t)cfg.warm : 512, npix / S);     // (the warm-up of a run is the end of its predecessor)
     const size_t nw = ceil_div(S, 64), cells = nw * a.R.Lmax * 64;
@@ -1645,7 +1645,7 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncell / 64, 64, 0, s, (const double *)w.dtab.p, k, g, l1, l2, (const unsigned char *)w.clist.p, (unsigned int *)nullptr);
     }
     double *sx = w.dsort.p, *sy = sx + cells, *sz = sy + cells;
-    const dim3 tiles((unsigned)ceil_div((size_t)a.R.Lmax, 64), (unsigned)nw), tiles16((unsigned)ceil_div((size_t)a.R.Lmax, 16), (unsigned)nw);
+    const dim3 tiles((unsigned)ceil_div((size_t)a.R.Lmax, 64), (unsigned)nw), tiles8((unsigned)ceil_div((size_t)a.R.Lmax, 256), (unsigned)ceil_div(S, 8));
     if (!(g_dither_order_cache && w.order_w == width && w.order_h == height && w.order_dev == current_device())) {
         // rank -> pixel number is a function of the image's dimensions alone: kept between calls on images of one size
         KTIME("k_dither_order", s, 4.0 * npix);
@@ -1657,10 +1657,10 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         KTIME("k_dither_gather", s, 52.0 * npix);
         const unsigned *sp = (const unsigned *)w.dpos.p;
         switch (which) {
-            case PAMD_COPY: hipLaunchKernelGGL(k_dither_streams<PAMD_COPY>, tiles16, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
-            case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_SRGB_TO_REC2020>, tiles16, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
-            case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_CIELUV_TO_REC2020>, tiles16, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
-            case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_ICTCP_TO_REC2020>, tiles16, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
+            case PAMD_COPY: hipLaunchKernelGGL(k_dither_streams<PAMD_COPY>, tiles8, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
+            case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_SRGB_TO_REC2020>, tiles8, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
+            case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_CIELUV_TO_REC2020>, tiles8, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
+            case PAMD_ICTCP_TO_REC2020: hipLaunchKernelGGL(k_dither_streams<PAMD_ICTCP_TO_REC2020>, tiles8, 256, 0, s, d_img, plane_stride, sp, a.R, sx, sy, sz); break;
             default: throw HipError("patolette_amd: the dither takes its pixels as linear Rec2020, sRGB, CIELuv or ICtCp");
         }
     }
