@@ -269,6 +269,7 @@ typedef struct patolette_amd__Stats {
     size_t dither_segments;   /* runs the Hilbert curve was cut into (walked side by side, one wavefront each) */
     size_t dither_repairs;    /* runs walked again because their speculative starting state was not the chain's */
     size_t dither_rounds;     /* boundary-verification passes (the last one found nothing to repair) */
+    size_t dither_through;    /* stalled verifications (a long flat stretch off the palette) resolved by walking one run through its successors */
 } patolette_amd__Stats;
 void patolette_amd_last_stats(patolette_amd__Stats *out);
 /* The palette exactly as the mapping stage of the last full-path call on this thread used it: linear Rec2020 when dithering

@@ -25,7 +25,7 @@ class Stats(C.Structure):
                                           "ms_kmeans", "ms_map", "ms_download", "ms_saliency")] + \
                [(n, C.c_size_t) for n in ("n_base_clusters", "n_clusters", "split_evals", "split_px",
                                           "lq_rounds", "kmeans_samples", "dither_segments", "dither_repairs",
-                                          "dither_rounds")]
+                                          "dither_rounds", "dither_through")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

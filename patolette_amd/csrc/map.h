@@ -20,6 +20,7 @@ struct NNWork {                        // scratch of the pruned NN map
     size_t order_w = 0, order_h = 0; int order_dev = -1;
     DevBuf<unsigned char> dsmap;       // ... the choices in curve order, and behind them the [S][16] boundary records
     size_t dither_segments = 0, dither_repairs = 0, dither_rounds = 0;   // of the last launch_dither
+    size_t dither_through = 0;         // ... times a stalled verification was resolved by walking one run through its successors
 };
 // lo/hi: exact per-plane min/max of the colours if known (else nullptr: computed with one more pass)
 void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k,

@@ -1016,7 +1016,9 @@ struct DitherSeg {
     unsigned S;                      // runs (1 = the whole image in one chain, no warm-up, no side records)
     unsigned warm;                   // in-image pixels of warm-up
     unsigned *side;                  // [S][16] choices the run's starting state was built from (0xFFFFFFFF = no record)
-    unsigned *repairs;               // bumped by every MODE-1 wavefront that had to walk its run again
+    unsigned *repairs;               // [0] bumped by every MODE-1 wavefront that had to walk its run again, [1] the lowest such run
+    unsigned b0;                     // MODE 1: block 0 takes run b0 (1 in a verification pass)
+    unsigned through;                // MODE 1: the walk does not end with the run but goes on until it meets the old chain (below)
 };
 
 // One wavefront walks one chain; every instruction of the chain is issued by that one wavefront (~2.5 ns each), so the count of
@@ -1142,14 +1144,14 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
     // ---- this wavefront's stretch of the curve: [d_begin, d_start) warm-up, [d_start, d_end) its own run ----
     const unsigned long long total = 1ULL << (2 * L);
     const unsigned long long npix = (unsigned long long)width * height;
-    const unsigned b = MODE == 0 ? blockIdx.x : blockIdx.x + 1u;
+    const unsigned b = MODE == 0 ? blockIdx.x : blockIdx.x + sg.b0;
     unsigned long long d_begin = 0, d_start = 0, d_end = total;
     unsigned head = 16, count = 16;                                  // ring positions (absolute); head is a multiple of 16
     unsigned *const side = sg.S > 1 ? sg.side + 16u * b : nullptr;
     if (sg.S > 1) {
         unsigned long long c_start = 0, c_begin = 0, cc;
         if (b > 0) dither_locate(L, width, height, npix * b / sg.S, d_start, c_start);
-        if (b + 1 < sg.S) dither_locate(L, width, height, npix * (b + 1) / sg.S, d_end, cc);
+        if (b + 1 < sg.S && !(MODE == 1 && sg.through)) dither_locate(L, width, height, npix * (b + 1) / sg.S, d_end, cc);
         d_begin = d_start;
         if (b > 0) {
             // MODE 0: the warm-up; MODE 1: just the sixteen pixels before the run (their positions end up in the ring)
@@ -1166,6 +1168,8 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
     }
 
     bool done = false;                                               // MODE 1: the old chain has been met
+    unsigned met = 0;                                                // ... for this many groups of sixteen in a row
+    const unsigned need = (MODE == 1 && sg.through) ? (unsigned)(npix / sg.S / 16) + 3u : 1u;
     // up to sixteen pending pixels, in order; `limit` < 16 only for the very last group
     auto group = [&](const int limit, const bool warmup) {
         double pcs[16];
@@ -1191,7 +1195,10 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
             else if (lane < limit) out[rpos[(head + (unsigned)lane) & (kRing - 1)]] = (OutT)res;
         } else {
             if (lane < limit) out[wpos] = (OutT)res;
-            if (limit == 16 && __all(lane >= 16 || was == (unsigned)res)) done = true;
+            // met: a whole group equals what is there.  A walk THROUGH the runs behind asks for more than a run's length of it: in a
+            // flat stretch the runs it crosses hold the same cycle at random phases, one in ten happens to be in step
+            if (limit == 16 && __all(lane >= 16 || was == (unsigned)res)) { if (++met >= need) done = true; }
+            else met = 0;
         }
         head += 16;
     };
@@ -1264,7 +1271,7 @@ __global__ __launch_bounds__(64) void k_dither(const double *__restrict__ img, s
         const bool same = __all(lane >= 16 || cur == side[lane & 15]);
         if (same) return;                                            // the run was started from the true state
         if (lane < 16) side[lane] = cur;
-        if (lane == 0) atomicAdd(sg.repairs, 1u);
+        if (lane == 0) { atomicAdd(sg.repairs, 1u); atomicMin(sg.repairs + 1, b); }
         // the queue as the chain holds it after those sixteen steps: their error vectors pushed in order into zero sums -- lane
         // (c, d) restarts at step d, so whatever it summed before never reaches a pixel
         const double ev = rpx[ch * kRing + slot] - prw[cur];
@@ -1584,7 +1591,9 @@ static bool g_dither_order_cache = true;
 void dither_order_cache(bool on) { g_dither_order_cache = on; }
 
 // One lane per run (k_dither_lanes): K in [8, 256], images of 2^16 pixels and more.  h_pal: the palette on the host, planar (k,3).
-static void launch_dither_lanes(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal,
+// Returns false when the verification stalls (a long flat stretch whose colour is not a palette entry: launch_dither_waves' comment):
+// the caller then takes the wavefront layout, which can walk one run through its successors.
+static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal,
                                 int k, void *d_out, int elem_bytes, NNWork &w, const DitherConfig &cfg, const DitherWeights &wts, hipStream_t s) {
     const size_t npix = width * height;
     DitherLanes a{};
@@ -1674,9 +1683,10 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         hipLaunchKernelGGL(k_dither_lanes<0>, (unsigned)ceil_div(S, 256), 256, lds, s, a, d_pal, k, wts);
     }
     HIP_CHECK(hipGetLastError());
-    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0;
+    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0; w.dither_through = 0;
+    unsigned prev_nf = 0xFFFFFFFFu;
+    int stalled = 0;
     for (size_t round = 0; S > 1; round++) {
-        if (round > S) throw HipError("patolette_amd: the dither's boundary repairs did not settle");
         HIP_CHECK(hipMemsetAsync(w.dside.p, 0, sizeof(unsigned), s));
         {
             KTIME("k_dither_fix", s, 0.0);
@@ -1687,6 +1697,9 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         const unsigned nf = *w.hrep.p;
         w.dither_rounds = round + 1;
         if (nf == 0) break;
+        stalled = (prev_nf != 0xFFFFFFFFu && nf + std::max(1u, prev_nf / 8) >= prev_nf) ? stalled + 1 : 0;
+        prev_nf = nf;
+        if (stalled >= 2) return false;
         w.dither_repairs += nf;
         KTIME("k_dither_fix", s, 0.0);
         hipLaunchKernelGGL(k_dither_lanes<1>, (unsigned)ceil_div((size_t)nf, 256), 256, lds, s, a, d_pal, k, wts);
@@ -1699,6 +1712,20 @@ static void launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         else hipLaunchKernelGGL(k_dither_unpermute<unsigned long long>, tiles, 256, 0, s, (const unsigned char *)a.smap, (const unsigned *)w.dpos.p, a.R, (unsigned long long *)d_out);
     }
     HIP_CHECK(hipGetLastError());
+    return true;
+}
+
+// the pixels into linear Rec2020 in image order (what the wavefront layout reads), for the fall-back out of the lane layout
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_dither_convert(const double *__restrict__ img, size_t plane_stride, size_t n, double *__restrict__ dst) {
+    pow_tables_to_lds();
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double c[3] = {img[i], img[plane_stride + i], img[2 * plane_stride + i]};
+        dev_convert<WHICH>(c);
+        dst[i] = c[0]; dst[n + i] = c[1]; dst[2 * n + i] = c[2];
+    }
 }
 
 template <typename OutT>
@@ -1737,6 +1764,9 @@ bool dither_lane_layout(size_t width, size_t height, int k) {
     return cfg.lanes > 0 ? npix >= 65536 : npix >= ((size_t)1 << 23);
 }
 
+static void launch_dither_waves(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
+                                void *d_out, int elem_bytes, NNWork &w, hipStream_t s);
+
 void launch_dither(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,
                    void *d_out, int elem_bytes, NNWork &w, hipStream_t s) {
     if (width * height >> 32) throw HipError("patolette_amd: the dither kernel numbers pixels with 32 bits");
@@ -1755,11 +1785,32 @@ void launch_dither(const double *d_img, size_t plane_stride, int which, size_t w
                 HIP_CHECK(hipStreamSynchronize(s));
                 h_pal = hp.data();
             }
-            launch_dither_lanes(d_img, plane_stride, which, width, height, d_pal, h_pal, k, d_out, elem_bytes, w, cfg, wts, s);
+            if (launch_dither_lanes(d_img, plane_stride, which, width, height, d_pal, h_pal, k, d_out, elem_bytes, w, cfg, wts, s)) return;
+            // stalled: the wavefront layout from scratch (it needs the pixels as linear Rec2020 in image order)
+            const size_t n = width * height;
+            if (which != PAMD_COPY) {
+                w.dsort.reserve(3 * n);
+                const int gb = stream_blocks(n, 16);
+                switch (which) {
+                    case PAMD_SRGB_TO_REC2020: hipLaunchKernelGGL(k_dither_convert<PAMD_SRGB_TO_REC2020>, gb, 256, 0, s, d_img, plane_stride, n, w.dsort.p); break;
+                    case PAMD_CIELUV_TO_REC2020: hipLaunchKernelGGL(k_dither_convert<PAMD_CIELUV_TO_REC2020>, gb, 256, 0, s, d_img, plane_stride, n, w.dsort.p); break;
+                    default: hipLaunchKernelGGL(k_dither_convert<PAMD_ICTCP_TO_REC2020>, gb, 256, 0, s, d_img, plane_stride, n, w.dsort.p); break;
+                }
+                HIP_CHECK(hipGetLastError());
+                d_img = w.dsort.p; plane_stride = n; which = PAMD_COPY;
+            }
+            const size_t lane_passes = w.dither_rounds;
+            launch_dither_waves(d_img, plane_stride, width, height, d_pal, k, d_out, elem_bytes, w, s);
+            w.dither_rounds += lane_passes;
             return;
         }
         if (which != PAMD_COPY) throw HipError("patolette_amd: the wavefront-per-run dither takes linear Rec2020 pixels");
     }
+    launch_dither_waves(d_img, plane_stride, width, height, d_pal, k, d_out, elem_bytes, w, s);
+}
+
+static void launch_dither_waves(const double *d_img, size_t plane_stride, size_t width, size_t height, const double *d_pal, int k,
+                                void *d_out, int elem_bytes, NNWork &w, hipStream_t s) {
     size_t lds = ((size_t)6 * k + 3 * 128) * sizeof(double) + 128 * sizeof(unsigned int);      // palette (raw + weighted) + the ring of pending pixels
     double *gtab = nullptr;
     if (lds > 150 * 1024) {                                      // K > 3200: the tables in global memory (workspace kept with the engine)
@@ -1787,14 +1838,20 @@ void launch_dither(const double *d_img, size_t plane_stride, int which, size_t w
     if (std::max(width, height) < 16) S = 1;
     if (S < 1) S = 1;
     sg.S = (unsigned)S;
-    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0;
+    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0; w.dither_through = 0;
     if (S > 1) {
         w.dside.reserve(16 * S + 16);
-        w.hrep.reserve(1);
+        w.hrep.reserve(2);
         sg.side = w.dside.p;
         sg.repairs = w.dside.p + 16 * S;
-        HIP_CHECK(hipMemsetAsync(sg.repairs, 0, sizeof(unsigned), s));
+        sg.b0 = 1; sg.through = 0;
     }
+    auto reset_counters = [&]() {                                // [0] = 0 repairs, [1] = no run yet (atomicMin)
+        w.hrep.p[0] = 0u; w.hrep.p[1] = 0xFFFFFFFFu;
+        HIP_CHECK(hipMemcpyAsync(sg.repairs, w.hrep.p, 2 * sizeof(unsigned), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));                      // (the pinned words are read back into below)
+    };
+    if (S > 1) reset_counters();
     auto launch = [&](int mode, unsigned blocks) {
         if (elem_bytes == 1) launch_dither_t<unsigned char>(mode, blocks, d_img, plane_stride, width, height, d_pal, k, (unsigned char *)d_out, wts, lds, gtab, sg, s);
         else if (elem_bytes == 4) launch_dither_t<unsigned int>(mode, blocks, d_img, plane_stride, width, height, d_pal, k, (unsigned int *)d_out, wts, lds, gtab, sg, s);
@@ -1807,19 +1864,40 @@ void launch_dither(const double *d_img, size_t plane_stride, int which, size_t w
     }
     if (S == 1 || std::max(width, height) <= 1) return;
     // verify every boundary, walk the runs whose starting state was not the true one again, until a pass finds nothing to do
+    // Where the image is FLAT over more than a warm-up and the flat colour is not a palette entry, the true chain is periodic (period
+    // 4 .. 14 measured) and a zero-queue chain settles into the same cycle at another phase: it never meets the true one, and a
+    // verification pass then fixes one run -- the lowest failing one, whose predecessor is final -- while its neighbours are rebuilt
+    // from tails that are about to change.  Two passes in a row that fix next to nothing are taken as that: the lowest failing run
+    // is walked THROUGH the runs behind it (one wavefront, the true chain) until it meets what is there -- the end of the flat
+    // stretch --, and the passes resume (runs it overwrote pass their next check in sixteen steps).
+    unsigned prev_r = 0xFFFFFFFFu;
+    int stalled = 0;
     for (size_t round = 0;; round++) {
-        if (round > S) throw HipError("patolette_amd: the dither's boundary repairs did not settle");
+        if (round > 2 * S + 8) throw HipError("patolette_amd: the dither's boundary repairs did not settle");
         {
             KTIME("k_dither_fix", s, 0.0);
             launch(1, (unsigned)S - 1);
         }
-        HIP_CHECK(hipMemcpyAsync(w.hrep.p, sg.repairs, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(w.hrep.p, sg.repairs, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-        const unsigned r = *w.hrep.p;
+        const unsigned r = w.hrep.p[0], lowest = w.hrep.p[1];
         w.dither_rounds = round + 1;
         if (r == 0) break;
         w.dither_repairs += r;
-        HIP_CHECK(hipMemsetAsync(sg.repairs, 0, sizeof(unsigned), s));
+        stalled = (prev_r != 0xFFFFFFFFu && r + std::max(1u, prev_r / 8) >= prev_r) ? stalled + 1 : 0;
+        prev_r = r;
+        reset_counters();
+        if (stalled >= 2 && (size_t)lowest + 1 < S) {
+            // the pass above has rebuilt run `lowest` from its final predecessor: it is final now, and the walk starts behind it
+            // (the record of that run is voided so that the kernel does not take its boundary for verified)
+            HIP_CHECK(hipMemsetAsync(sg.side + 16 * ((size_t)lowest + 1), 0xFF, 16 * sizeof(unsigned), s));
+            sg.b0 = lowest + 1; sg.through = 1;
+            { KTIME("k_dither_fix", s, 0.0); launch(1, 1u); }
+            sg.b0 = 1; sg.through = 0;
+            reset_counters();
+            w.dither_through++;
+            stalled = 0; prev_r = 0xFFFFFFFFu;
+        }
     }
 }
 

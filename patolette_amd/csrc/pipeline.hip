@@ -1258,7 +1258,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
                     launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);      // plane stride of cvt is N for x,y,z
                     launch_dither(E.aux.p, N, PAMD_COPY, width, height, E.dpal.p, pal.data(), (int)len, d_map, map_elem, E.nn, s);
                 }
-                E.stats.dither_segments = E.nn.dither_segments; E.stats.dither_repairs = E.nn.dither_repairs; E.stats.dither_rounds = E.nn.dither_rounds;
+                E.stats.dither_segments = E.nn.dither_segments; E.stats.dither_repairs = E.nn.dither_repairs; E.stats.dither_rounds = E.nn.dither_rounds; E.stats.dither_through = E.nn.dither_through;
             }
             palette_rows(pal, len, hm::color::rec2020_to_srgb);
         } else {                                                               // patolette.c:300-324
@@ -2128,7 +2128,7 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
     HIP_CHECK(hipMemcpy(E.src.p, colors, 3 * n * sizeof(double), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(E.dpal.p, palette, 3 * k * sizeof(double), hipMemcpyHostToDevice));
     launch_dither(E.src.p, n, PAMD_COPY, width, height, E.dpal.p, palette, (int)k, E.dmap.p, 4, E.nn, E.stream);
-    E.stats.dither_segments = E.nn.dither_segments; E.stats.dither_repairs = E.nn.dither_repairs; E.stats.dither_rounds = E.nn.dither_rounds;
+    E.stats.dither_segments = E.nn.dither_segments; E.stats.dither_repairs = E.nn.dither_repairs; E.stats.dither_rounds = E.nn.dither_rounds; E.stats.dither_through = E.nn.dither_through;
     E.sync();
     if (std::max(width, height) > 1) {
         std::vector<unsigned int> tmp(n);

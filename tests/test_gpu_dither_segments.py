@@ -151,3 +151,32 @@ def test_full_path_with_dither_on_through_the_c_abi(gpu, native, ob, cs, weighte
     assert np.max(np.abs(pal - pal_o)) <= 1e-9 * max(1.0, np.max(np.abs(pal_o)))
     assert np.array_equal(pmap, map_o), (int(np.sum(pmap != map_o)), st)
     assert st["dither_segments"] > 1
+
+
+@pytest.mark.parametrize("shape", ["flat", "half", "bands"])
+@pytest.mark.parametrize("k", [4, 16])
+def test_flat_stretches_off_the_palette(gpu, native, ob, cfg, shape, k):
+    """Where the image is flat over more than a warm-up and the flat colour is NOT a palette entry, the true chain is periodic
+    and a zero-queue chain settles into the same cycle at another phase: it never meets the true one (measured with the
+    oracle: period 4 .. 14, one start in ten in phase).  Verification passes then fix one run each; the product notices the
+    stall and walks the lowest unverified run through its successors (one wavefront, the true chain) until it meets what is
+    there.  Same map, and far fewer passes than runs."""
+    w, h = 512, 300
+    n = w * h
+    rng = np.random.default_rng(40 + k)
+    pal = rng.random((k if k >= 8 else 8, 3))                       # (8 rows at least: the lane layout's lower bound)
+    pal[k:] = 5.0 + rng.random((pal.shape[0] - k, 3))               # ... the extra ones far away: never chosen
+    img = np.tile(rng.random(3), (h, w, 1))
+    if shape == "half":
+        img[:, w // 2:] = rng.random((h, w - w // 2, 3))
+    elif shape == "bands":
+        for y0 in range(0, h, 60):
+            img[y0:y0 + 60] = rng.random(3)
+    flat = np.concatenate([img[:, :, c].reshape(-1) for c in range(3)])
+    want = ob.dither(flat, w, h, pal)
+    for seg in (0, 300):
+        cfg(seg)
+        got, st = _dither(gpu, native, flat, w, h, pal)
+        assert np.array_equal(got, want), "%s k=%d S=%d: %d mismatches, %s" % (shape, k, seg, int(np.sum(got != want)), st)
+        assert st["dither_rounds"] <= 40, st                        # (not one pass per run)
+        print("%s k=%d S=%d: %s" % (shape, k, seg, {q: st[q] for q in ("dither_segments", "dither_repairs", "dither_rounds", "dither_through")}))
