@@ -905,7 +905,7 @@ def main():
             parity = {"note": "the oracle derives its own saliency weights (unpinned restatement): no comparison in this run; see tests/test_gpu_saliency.py"}
         scale = "the full %dx%d workload" % (sw, sh) if sn == n else "%dx%d of the same workload (the %dx%d image would take %.0fx as long)" % (sw, sh, width, height, n / sn)
         if dither:
-            # the mapping stage side by side: the GPU's chain cut into runs walked by one wavefront each (speculative warm-up,
+            # the mapping stage side by side: the GPU's chain cut into runs walked side by side, one lane or one wavefront each (speculative warm-up,
             # verified boundaries, repairs: map.hip DitherSeg) against the oracle's one chain on one host core.  The oracle
             # searches the palette by brute force (exact, 256 f64 distances per pixel); the reference's FLANN kd-tree
             # (nearest.c:115-148) is not in this image and would be faster on the CPU side.

@@ -167,7 +167,7 @@ typedef struct patolette_amd__Comm {
 /* slice_data: planar f64 (x | y | z, plane stride slice_pixels) of pixels [slice_begin, slice_begin + slice_pixels) of an
  * image of total_pixels pixels, host memory; slice_weights: NULL or slice_pixels doubles (all ranks alike); palette:
  * palette_size x 3 column-major, the same on every rank; slice_map: slice_pixels entries (NULL with palette_only).
- * Not available per slice: dithering (one serial chain over the whole image: exit code -1) and derived saliency weights
+ * Not available per slice: dithering (one curve over the whole image: exit code -1) and derived saliency weights
  * (pass explicit weights).  Exit codes as patolette(); every slice must hold at least one pixel. */
 void patolette_amd_slice(size_t total_pixels, size_t slice_begin, size_t slice_pixels, const double *slice_data,
                          const double *slice_weights, size_t palette_size, const patolette__QuantizationOptions *options,
@@ -266,7 +266,7 @@ typedef struct patolette_amd__Stats {
     size_t split_px;          /* sum of their sizes: D_eff = split_px / (width*height) */
     size_t lq_rounds;         /* host<->device round trips of the split loop */
     size_t kmeans_samples;    /* samples clustered per KMeans iteration */
-    size_t dither_segments;   /* runs the Hilbert curve was cut into (walked side by side, one wavefront each) */
+    size_t dither_segments;   /* runs the Hilbert curve was cut into (walked side by side, one lane or one wavefront each) */
     size_t dither_repairs;    /* runs walked again because their speculative starting state was not the chain's */
     size_t dither_rounds;     /* boundary-verification passes (the last one found nothing to repair) */
     size_t dither_through;    /* stalled verifications (a long flat stretch off the palette) resolved by walking one run through its successors */

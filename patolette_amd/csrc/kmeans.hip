@@ -1087,6 +1087,117 @@ __global__ __launch_bounds__(256) void k_km_scatter(KmSamples s, const AT *__res
     }
 }
 
+// The same half of the sort through LDS (k <= 256, one-byte assignments, long chunks): k_km_scatter's stores leave a wavefront one
+// 16- or 32-byte piece per lane, every piece its own cache line and its own DRAM page (SQ: 56 % of the wavefront time waiting to
+// issue; 1.07 GB written at 1.1 TB/s).  Here a BLOCK takes one chunk, 4096 samples at a time (wavefront w the w-th 1024 of them):
+// ranks per wavefront as before (match masks, per-centroid counters in LDS), one prefix over (centroid, wavefront) for the batch,
+// the records placed in LDS in sorted order, and the stores made from there -- consecutive threads hold consecutive slots, so the
+// sixteen records a centroid gets from a batch on average leave as one 256-byte piece.  Same records in the same places: the sort
+// stays stable (wavefront, then trip, then lane = sample order).
+template <bool W>
+__global__ __launch_bounds__(256) void k_km_scatter_lds(KmSamples s, const unsigned char *__restrict__ assign, size_t nx, int k, int chunk_len,
+                                                       int nchunks, const unsigned int *__restrict__ table, const unsigned int *__restrict__ rowtot,
+                                                       float4 *sorted) {
+    extern __shared__ unsigned int lds_u[];
+    __shared__ unsigned int wsum[4];
+    constexpr int BW = 1024, U = BW / 64, B = 4 * BW;                                // samples per wavefront and per block in a batch
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned int *cur = lds_u;                                                       // [256] next place of every centroid in `sorted`
+    unsigned int *start = lds_u + 256;                                               // [256] first slot of every centroid in this batch
+    unsigned int *cntw = lds_u + 512;                                                // [4][256] members per wavefront in this batch -> its first slot
+    unsigned char *ca = reinterpret_cast<unsigned char *>(lds_u + 512 + 1024);       // [B] centroid of the record in a slot
+    float4 *rec = reinterpret_cast<float4 *>(lds_u + 512 + 1024 + B / 4);            // [B] the batch in sorted order
+    unsigned int *cnt = cntw + 256 * wid;
+    const int chunk = blockIdx.x;
+    {   // block-wide exclusive scan of rowtot[0..k), one centroid per thread, + what earlier chunks hold
+        const int j = threadIdx.x;
+        const unsigned a0 = j < k ? rowtot[j] : 0u;
+        const unsigned inc = wave_scan_incl_u32(a0);
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        unsigned pre = inc - a0;
+        for (int w2 = 0; w2 < wid; w2++) pre += wsum[w2];
+        cur[j] = j < k ? pre + table[(size_t)j * nchunks + chunk] : 0u;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++) cntw[256 * w2 + j] = 0u;
+    }
+    __syncthreads();
+    const size_t lo = (size_t)chunk * chunk_len;
+    const size_t hi = lo + chunk_len < nx ? lo + chunk_len : nx;
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    for (size_t b0 = lo; b0 < hi; b0 += B) {
+        const unsigned nb = (unsigned)(hi - b0 < (size_t)B ? hi - b0 : (size_t)B);
+        const unsigned w0 = (unsigned)wid * BW;                                       // this wavefront's first sample of the batch
+        unsigned ao[U]; float4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                                                // the whole batch is requested before any of it is used
+            const size_t i = b0 + w0 + (size_t)u * 64 + lane;
+            const size_t j = i < hi ? i : lo;
+            ao[u] = assign[j];
+            float w = 1.0f;
+            if constexpr (W) w = s.w[j];
+            r[u] = make_float4(s.x[j], s.y[j], s.z[j], w);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool v = w0 + (unsigned)u * 64u + (unsigned)lane < nb;
+            const unsigned long long valid = __ballot(v);
+            const int a = (int)ao[u];
+            const unsigned long long m = match_mask(v ? a : 0, 8, valid);
+            unsigned run = 0;
+            if (v) run = cnt[a];                                                     // read before the leader bumps it
+            const unsigned rk = (unsigned)__popcll(m & lt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (v && rk == 0) cnt[a] = run + (unsigned)__popcll(m);                  // leader
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            ao[u] = v ? ((unsigned)a | ((run + rk) << 8)) : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        {   // slots: centroid-major, then wavefront.  Thread j owns centroid j: its four wavefront counts become their first slots
+            const int j = threadIdx.x;
+            const unsigned c0 = cntw[j], c1 = cntw[256 + j], c2 = cntw[512 + j], c3 = cntw[768 + j];
+            const unsigned tot = c0 + c1 + c2 + c3;
+            const unsigned inc = wave_scan_incl_u32(tot);
+            if (lane == 63) wsum[wid] = inc;
+            __syncthreads();
+            unsigned pre = inc - tot;
+            for (int w2 = 0; w2 < wid; w2++) pre += wsum[w2];
+            start[j] = pre;
+            cntw[j] = pre; cntw[256 + j] = pre + c0; cntw[512 + j] = pre + c0 + c1; cntw[768 + j] = pre + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (ao[u] != 0xFFFFFFFFu) {
+                const unsigned a = ao[u] & 0xffu, slot = cnt[a] + (ao[u] >> 8);
+                rec[slot] = r[u];
+                ca[slot] = (unsigned char)a;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < B / 256; u++) {
+            const unsigned sidx = (unsigned)u * 256u + threadIdx.x;
+            if (sidx < nb) {
+                const unsigned c = ca[sidx];
+                sorted[(size_t)cur[c] + (sidx - start[c])] = rec[sidx];
+            }
+        }
+        __syncthreads();
+        {   // advance the places by what the batch held (the next centroid's first slot, or the batch's size, minus this one's)
+            const int j = threadIdx.x;
+            const unsigned nxt = j + 1 < 256 ? start[j + 1] : nb;
+            __syncthreads();
+            cur[j] += nxt - start[j];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) cntw[256 * w2 + j] = 0u;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- split_clusters (Clustering.cpp:216-263) on one lane, std::mt19937(1234) per call ----
 struct DevMT {
     unsigned mt[624]; int idx;
@@ -2299,7 +2410,17 @@ void kmeans_iterate(KMeansWork &w, size_t nx, int k, bool weighted, int niter, h
             KTIME("k_km_scatter", s, (weighted ? 36.0 : 32.0) * nx - (use_mid ? 3.0 : 0.0) * nx);
             const unsigned char *a8 = (const unsigned char *)w.assign.p;               // k_km_assign_mid leaves one byte per sample
             static const bool pair_on = !(getenv("PAMD_KM_PAIR") && atoi(getenv("PAMD_KM_PAIR")) == 0);
-            if (use_mid && pair_on && chunk_len >= 2 * k) {
+            static const bool lds_sort_on = !(getenv("PAMD_KM_LDS_SORT") && atoi(getenv("PAMD_KM_LDS_SORT")) == 0);
+            if (use_mid && lds_sort_on && chunk_len >= 4096 && k <= 256) {
+                constexpr size_t lds_ls = (size_t)(512 + 1024 + 4096 / 4 + 4 * 4096) * sizeof(unsigned int);
+                static PerDeviceOnce attr5;
+                if (attr5.first()) {
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ls));
+                    HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ls));
+                }
+                if (weighted) hipLaunchKernelGGL(k_km_scatter_lds<true>, nchunks, 256, lds_ls, s, ks, a8, nx, k, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+                else hipLaunchKernelGGL(k_km_scatter_lds<false>, nchunks, 256, lds_ls, s, ks, a8, nx, k, chunk_len, nchunks, w.table.p, w.rowtot.p, w.sorted.p);
+            } else if (use_mid && pair_on && chunk_len >= 2 * k) {
                 static PerDeviceOnce attr3;
                 if (attr3.first()) {
                     HIP_CHECK(hipFuncSetAttribute((const void *)k_km_scatter<true, unsigned char, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 256 * 4 + 4 * (256 + 64) * 16));

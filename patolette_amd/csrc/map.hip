@@ -12,8 +12,9 @@
 // 64-step batch the lanes decode 64 curve positions and prefetch their pixels in parallel, then
 // the steps run in order -- error sum in reference order, K/64 palette entries per lane, wave
 // arg-min with the lowest-index tie rule.  The chain's state is a function of its last sixteen
-// choices, so the curve is cut into ~2000 runs that are walked side by side from speculative
-// warm-ups, verified at every boundary and repaired where the speculation missed (DitherSeg).
+// choices, so the curve is cut into runs that are walked side by side from speculative warm-ups,
+// verified at every boundary and repaired where the speculation missed: ~2000 runs of one
+// wavefront each (DitherSeg), or ~130 000 runs of one LANE each on large images (DitherLanes).
 #include "map.h"
 
 #include <algorithm>

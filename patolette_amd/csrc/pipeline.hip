@@ -1202,7 +1202,7 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
     E.cvt.reserve((weighted ? 4 : 3) * N);
     E.cstats.reserve(1);
     if (E.shard && opt->dither && !opt->palette_only)
-        throw HipError("patolette_amd: dithering is one serial chain over the whole image; it is not available per slice");
+        throw HipError("patolette_amd: dithering walks the whole image along one curve; it is not available per slice");
     const ConvertPlan cp = convert_plan(E, opt, N);
     const int which = cp.which;
     const BinK sumk = cp.sumk, momk = cp.momk;

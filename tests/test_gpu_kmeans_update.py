@@ -150,3 +150,44 @@ def test_end_to_end_palette_within_tolerance_and_map_nearly_identical(gpu, ob, c
     assert differ <= n // 1000
     pal2, map2 = run()                                         # the default again: the option has not leaked
     assert np.array_equal(pal2, pal0, equal_nan=True) and np.array_equal(map2, map0)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_kmeans_over_every_pixel_of_a_16_mp_image(gpu, native, ob, weighted):
+    """KMeans over ALL 16.8 M pixels (kmeans_max_samples = N: 4096 chunks of 4096 samples), the size from which the second half of
+    the stable counting sort goes through LDS in 4096-sample batches (k_km_scatter_lds): the sorted copy must hold the same records
+    in the same places, or the sequential f32 centroid chains (Clustering.cpp:135-204) come out differently.  Against the oracle:
+    palette 1e-9, map bit for bit."""
+    import ctypes as C
+    import os
+    w = h = 4096
+    n, K = w * h, 256
+    L = gpu
+    img = L.patolette_amd_malloc(3 * n * 8)
+    wt = L.patolette_amd_malloc(n * 8) if weighted else None
+    dmap = L.patolette_amd_malloc(n)
+    try:
+        assert img and dmap and L.patolette_amd_fill_image(img, n, 5) == 0
+        if weighted:
+            assert wt and L.patolette_amd_fill_weights(wt, n, 5) == 0
+        opts = native.QuantizationOptions(False, False, 2, 2, n, False)
+        pal = np.zeros((K, 3), dtype=np.float64, order="F")
+        code = C.c_int(9)
+        L.patolette_amd_device(w, h, img, wt, K, C.byref(opts), pal.ctypes.data_as(C.POINTER(C.c_double)), dmap, 1, C.byref(code))
+        assert code.value == 0, native.last_error()
+        assert native.last_stats()["kmeans_samples"] == n
+        m8 = np.empty(n, dtype=np.uint8)
+        assert L.patolette_amd_memcpy_d2h(m8.ctypes.data_as(C.c_void_p), dmap, n) == 0
+    finally:
+        for q in (img, wt, dmap):
+            if q:
+                L.patolette_amd_free(q)
+    ob.set_threads(os.cpu_count() or 1)
+    try:
+        ec, pal_o, map_o = ob.patolette(w, h, ob.image(n, 5), ob.weights(n, 5) if weighted else None, K, dither=False, color_space=2,
+                                        kmeans_niter=2, kmeans_max_samples=n)
+    finally:
+        ob.set_threads(1)
+    assert ec == 0
+    assert np.max(np.abs(pal - pal_o)) <= 1e-9 * np.max(np.abs(pal_o))
+    assert int(np.count_nonzero(m8 != map_o.astype(np.uint8))) == 0
