@@ -486,6 +486,38 @@ def host_to_host_u8(L, native, cfg, reps=3):
     return out
 
 
+def default_call(L, native, reps=3):
+    """What a caller of the reference's Python binding gets with every default left alone (patolette.pyx:332-344: dither = True,
+    ICtCp, tile_size = 512 -> saliency weights, KMeans 32 iterations on 512^2 samples, 256 colours): an 8-bit host image in, a u8
+    index map out (`patolette_amd_u8`), PCIe included.  The reference runs this call single-threaded on the CPU; never `value`."""
+    import numpy as np
+    out = {"entry": "patolette_amd_u8(), pageable (H,W,3) u8 in, u8 map out; dither on, tile_size 512, KMeans 32 it, K = 256"}
+    for (w, h) in ((1920, 1080), (4096, 4096)):
+        n = w * h
+        img = np.random.default_rng(77).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        opts = native.QuantizationOptions(True, False, 2, 32, 512 ** 2, False)
+        pal = np.zeros((256, 3), dtype=np.float64, order="F")
+        pal8 = np.zeros((256, 3), dtype=np.uint8)
+        pmap = np.zeros(n, dtype=np.uint8)
+        code = C.c_int(0)
+        times = []
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            L.patolette_amd_u8(w, h, img.ctypes.data_as(C.c_void_p), 3, None, C.c_double(512.0), 256, C.byref(opts),
+                               pal.ctypes.data_as(native.dp), pal8.ctypes.data_as(C.c_void_p), pmap.ctypes.data_as(C.c_void_p), 1, None, C.byref(code))
+            dt = time.perf_counter() - t0
+            if code.value != 0:
+                return None
+            if i:
+                times.append(dt)
+        st = native.last_stats()
+        best = sorted(times)[len(times) // 2]
+        out["%dx%d" % (w, h)] = {"ms": round(1e3 * best, 3), "value": round(n / best / 1e6, 1), "unit": "Mpx/s",
+                                 "stages_ms": {k: round(v, 3) for k, v in st.items() if k.startswith("ms_") and v},
+                                 "dither_runs": st["dither_segments"], "dither_repairs": st["dither_repairs"]}
+    return out
+
+
 def parity_record(L, native, cfg, d_img, d_wt, pal_timed, res_all, res_one, ob):
     """The metric's second half ("palette dE vs ref"): rank 0's image 0 (seed 0) of the timed region against the CPU oracle's
     result for the SAME full-size image -- the one the cpu_baseline leg has just computed.  The palette compared is the one a
@@ -841,11 +873,12 @@ def main():
                     "time_share": round(kernels.get(dom, {"ms_per_step": 0.0})["ms_per_step"] / max(1e-9, sum(v["ms_per_step"] for v in kernels.values())), 3)}
 
     # ---- extras of the default run, all outside the timed region ----
-    ns_kernels = h2h = h2h_u8 = content = small = None
+    ns_kernels = h2h = h2h_u8 = content = small = dflt = None
     if not args.no_extras and world == 1 and args.config == "c3":
         small = small_image(L, _native)
         h2h = host_to_host(L, _native, cfg)
         h2h_u8 = host_to_host_u8(L, _native, cfg)
+        dflt = default_call(L, _native)
         ob_c = None
         if not args.no_cpu_baseline:                          # the oracle as the checker of the content workloads (never timed here)
             from oracle import binding as ob_c
@@ -944,7 +977,7 @@ def main():
                                     "TEST MODE --oversubscribe: %d ranks on %d device(s), gloo gather through host copies -- the N > 1 code path, not a scaling figure" % (world, L.patolette_amd_device_count())
                                     if args.oversubscribe else
                                     "RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region")},
-        "first_call": cold, "dither": dither_cmp, "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "small_image": small, "host_to_host": h2h, "host_to_host_u8": h2h_u8, "content": content, "throughput_concurrent": conc,
+        "first_call": cold, "dither": dither_cmp, "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "small_image": small, "host_to_host": h2h, "host_to_host_u8": h2h_u8, "default_call": dflt, "content": content, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
