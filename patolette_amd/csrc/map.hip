@@ -536,6 +536,7 @@ __device__ unsigned long long g_nn_trace[256][2];          // diagnostic build: 
 // ... and what its drains met: [0] drains, [1] pixels drained, [2] drains with a list of more than four, [3] of more than eight,
 // [4] pixels with more than eight, [5] pixels parked because the f32 pass could not tell first from second
 __device__ unsigned long long g_nn_stats[8];
+__device__ unsigned long long g_dl_stats[8];      // k_dither_lanes (PAMD_NN_STATS): lane-steps, outside the grid, long-list cells, ambiguous; wavefront-steps, with an exact pass, with a full scan, candidate-loop trips
 __device__ unsigned g_nn_flags;                             // timing experiments (wrong maps): 1 = drains evaluate nothing, 2 = nothing is parked
 #endif
 template <typename OutT, int P, int WAVES>
@@ -1434,7 +1435,7 @@ struct DitherLanes {
     unsigned short *side;                // [S][16] the choices a run's starting queue was built from (0xFFFF = none: the run is walked again)
     unsigned *list;                      // runs whose boundary check failed; list[-1] = how many
     unsigned warm;                       // <= the shortest run
-    const unsigned char *lut;            // 16-byte records of the G^3 grid over the weighted palette (k_nn_lut_build)
+    const unsigned char *lut, *lut2;     // 16-byte records of the G^3 grid over the weighted palette, and their continuations (k_nn_lut_build)
     NNGrid g;
     double hi[3];                        // upper corner of the grid: queries outside [lo, hi] take the full scan
     float amb;                           // f32 first pass: first and second must differ by more than this
@@ -1502,32 +1503,69 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
     // every query outside the grid or in a cell whose list runs past one record -- the exact f64 loop decides.
     auto nearest = [&](const double x, const double y, const double z, const bool on) -> int {
         const bool inside = x >= lo0 && x <= hi0 && y >= lo1 && y <= hi1 && z >= lo2 && z <= hi2;   // (a NaN: not inside)
-        int cnt = 0;
-        unsigned long long w0 = 0, w1 = 0;
+        int cnt = 255;
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;          // the cell's candidates, a byte each, the first in s0's low byte
         if (on && inside) {
-            const uint4 rec = *reinterpret_cast<const uint4 *>(a.lut + nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2) * 16);
+#ifdef PAMD_KM_TRACE
+            size_t cell = nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2);
+            if (g_nn_flags & 4u) cell = ((size_t)(threadIdx.x & 63) * 4099u) % ((size_t)G * G * G);   // timing experiment (wrong map): the record does not depend on the query
+#else
+            const size_t cell = nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2);
+#endif
+            const uint4 rec = *reinterpret_cast<const uint4 *>(a.lut + cell * 16);
             cnt = (int)(rec.x & 0xffu);
-            w0 = ((unsigned long long)rec.y << 32) | rec.x; w1 = ((unsigned long long)rec.w << 32) | rec.z;
-            w0 = (w0 >> 8) | (w1 << 56); w1 >>= 8;
+            const unsigned long long w0 = ((unsigned long long)rec.y << 32) | rec.x, w1 = ((unsigned long long)rec.w << 32) | rec.z;
+            s0 = (w0 >> 8) | (w1 << 56); s1 = w1 >> 8;              // fifteen entries; past a short list its last one repeats (k_nn_lut_build)
+            if (cnt > 15 && cnt != 255) {                           // a crowded cell: entries 15 .. 29 in the second record
+                const uint4 r2 = *reinterpret_cast<const uint4 *>(a.lut2 + cell * 16);
+                const unsigned long long x0 = ((unsigned long long)r2.y << 32) | r2.x, x1 = ((unsigned long long)r2.w << 32) | r2.z;
+                s1 |= x0 << 56; s2 = (x0 >> 8) | (x1 << 56); s3 = x1 >> 8;
+            }
         }
-        const bool listed = on && inside && cnt <= 15;              // else: outside the grid, or a cell whose list runs past one record
+        const bool listed = cnt != 255;                             // else: outside the grid, or a cell with more than thirty candidates: all k entries
         const int n = listed ? cnt : 0;
         const float xf = (float)(x - lo0), yf = (float)(y - lo1), zf = (float)(z - lo2);
         float m1 = INFINITY, m2 = INFINITY; int best = 0;
         {
-            unsigned long long v0 = w0, v1 = w1;
-            for (int t = 0; __any(t < n); t++) {
-                const int j = (int)(v0 & 0xffULL);
-                v0 = (v0 >> 8) | (v1 << 56); v1 >>= 8;
-                const float4 r = r32[j];
-                float tj = __builtin_fmaf(xf, r.x, __builtin_fmaf(yf, r.y, __builtin_fmaf(zf, r.z, r.w)));
-                tj = t < n ? tj : INFINITY;
-                m2 = __builtin_fminf(m2, __builtin_fmaxf(m1, tj));
-                best = tj < m1 ? j : best;
-                m1 = __builtin_fminf(m1, tj);
+            // four candidates a trip: their records are requested from LDS together, then evaluated in list order
+            unsigned long long v0 = s0, v1 = s1, v2 = s2, v3 = s3;
+            for (int t = 0; __any(t < n); t += 4) {
+                const unsigned four = (unsigned)v0;
+                v0 = (v0 >> 32) | (v1 << 32); v1 = (v1 >> 32) | (v2 << 32); v2 = (v2 >> 32) | (v3 << 32); v3 >>= 32;
+                int jj[4]; float4 r[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { jj[i] = t + i < n ? (int)((four >> (8 * i)) & 0xffu) : 0; r[i] = r32[jj[i]]; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float tj = __builtin_fmaf(xf, r[i].x, __builtin_fmaf(yf, r[i].y, __builtin_fmaf(zf, r[i].z, r[i].w)));
+                    tj = t + i < n ? tj : INFINITY;
+                    m2 = __builtin_fminf(m2, __builtin_fmaxf(m1, tj));
+                    best = tj < m1 ? jj[i] : best;
+                    m1 = __builtin_fminf(m1, tj);
+                }
             }
         }
+#ifdef PAMD_KM_TRACE
+        const bool exact = (g_nn_flags & 8u) ? false : (on && !(listed && (m2 - m1) > a.amb));    // (8: timing experiment, wrong map)
+#else
         const bool exact = on && !(listed && (m2 - m1) > a.amb);    // (a NaN anywhere: exact)
+#endif
+#ifdef PAMD_NN_STATS
+        {
+            const unsigned long long m_on = __ballot(on), m_out = __ballot(on && !inside), m_long = __ballot(on && inside && cnt > 15), m_amb = __ballot(on && listed && exact);
+            const unsigned long long m_ex = __ballot(exact), m_full = __ballot(exact && !listed);
+            int nmax = n;
+            for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+            if ((threadIdx.x & 63) == 0 && m_on) {
+                atomicAdd(&g_dl_stats[0], (unsigned long long)__popcll(m_on)); atomicAdd(&g_dl_stats[1], (unsigned long long)__popcll(m_out));
+                atomicAdd(&g_dl_stats[2], (unsigned long long)__popcll(m_long)); atomicAdd(&g_dl_stats[3], (unsigned long long)__popcll(m_amb));
+                atomicAdd(&g_dl_stats[4], 1ULL);
+                if (m_ex) atomicAdd(&g_dl_stats[5], 1ULL);
+                if (m_full) atomicAdd(&g_dl_stats[6], 1ULL);
+                atomicAdd(&g_dl_stats[7], (unsigned long long)nmax);
+            }
+        }
+#endif
         if (__any(exact)) {
             if (exact) {
                 double bd = INFINITY; best = 0;
@@ -1537,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
                     if (d < bd) { bd = d; best = j; }               // ascending j + strict '<' = lowest index on ties
                 };
                 if (listed) {
-                    for (int t = 0; t < n; t++) { test((int)(w0 & 0xffULL)); w0 = (w0 >> 8) | (w1 << 56); w1 >>= 8; }
+                    for (int t = 0; t < n; t++) { test((int)(s0 & 0xffULL)); s0 = (s0 >> 8) | (s1 << 56); s1 = (s1 >> 8) | (s2 << 56); s2 = (s2 >> 8) | (s3 << 56); s3 >>= 8; }
                 } else for (int j = 0; j < k; j++) test(j);
             }
         }
@@ -1610,6 +1648,9 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
     NNGrid g;
     g.G = npix >= ((size_t)1 << 20) ? 64 : 32;
+#ifdef PAMD_KM_TRACE
+    if (const char *e = getenv("PAMD_DITHER_GRID")) g.G = atoi(e) == 32 ? 32 : 64;      // diagnostic build: the records' grid
+#endif
     for (int c = 0; c < 3; c++) {
         double lo = INFINITY, hi = -INFINITY;
         for (int j = 0; j < k; j++) { const double v = h_pal[(size_t)c * k + j] * fw[c]; wp[(size_t)c * k + j] = v; lo = std::min(lo, v); hi = std::max(hi, v); }
@@ -1677,7 +1718,7 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     a.sx = sx; a.sy = sy; a.sz = sz;
     a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((cells + 63) & ~(size_t)63));
     a.list = w.dside.p + 1;
-    a.lut = l1; a.g = g;
+    a.lut = l1; a.lut2 = l2; a.g = g;
     const size_t lds = (size_t)6 * k * sizeof(double) + (size_t)k * sizeof(float4);
     {
         KTIME("k_dither", s, 25.0 * npix);
@@ -1918,6 +1959,11 @@ extern "C" int patolette_amd_debug_nn_trace(unsigned long long *out) {
 }
 extern "C" int patolette_amd_debug_nn_flags(unsigned flags) {
     return hipMemcpyToSymbol(HIP_SYMBOL(pamd::g_nn_flags), &flags, sizeof flags) == hipSuccess ? 0 : -1;
+}
+extern "C" int patolette_amd_debug_dither_lane_stats(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pamd::g_dl_stats), sizeof(pamd::g_dl_stats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pamd::g_dl_stats), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
 }
 extern "C" int patolette_amd_debug_nn_stats(unsigned long long *out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pamd::g_nn_stats), sizeof(pamd::g_nn_stats)) != hipSuccess) return -1;

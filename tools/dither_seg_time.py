@@ -1,5 +1,5 @@
 """Segment-parallel dither: time of the map stage of a dithered patolette_amd_device call for several cuts of the curve
-(runs x warm-up), device-resident image.  usage: dither_seg_time.py [side=8192] [K=256] ["S:W,S:W,..."]"""
+(runs x warm-up), device-resident image.  usage: [DST_CS=1] [DST_NITER=0] dither_seg_time.py [side=8192] [K=256] ["S:W,S:W,..."]"""
 import ctypes as C
 import sys
 
@@ -17,7 +17,9 @@ img = C.c_void_p(L.patolette_amd_malloc(3 * n * 8))
 wt = C.c_void_p(L.patolette_amd_malloc(n * 8))
 dmap = C.c_void_p(L.patolette_amd_malloc(n))
 assert L.patolette_amd_fill_image(img, n, 7) == 0 and L.patolette_amd_fill_weights(wt, n, 7) == 0
-opts = _native.QuantizationOptions(True, False, 1, 0, 512 ** 2, False)
+import os
+cs, niter = int(os.environ.get("DST_CS", "1")), int(os.environ.get("DST_NITER", "0"))      # colour space (1 CIELuv, 2 ICtCp, 0 sRGB), KMeans iterations
+opts = _native.QuantizationOptions(True, False, cs, niter, 512 ** 2, False)
 pal = np.zeros((K, 3), dtype=np.float64, order="F")
 code = C.c_int(0)
 ref = None
