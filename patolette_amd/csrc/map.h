@@ -21,6 +21,17 @@ struct NNWork {                        // scratch of the pruned NN map
     DevBuf<unsigned char> dsmap;       // ... the choices in curve order, and behind them the [S][16] boundary records
     size_t dither_segments = 0, dither_repairs = 0, dither_rounds = 0;   // of the last launch_dither
     size_t dither_through = 0;         // ... times a stalled verification was resolved by walking one run through its successors
+    hipStream_t side_stream = nullptr; // lane-per-run dither: the record grids are built here while the pixels are gathered
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int side_dev = -1;
+    NNWork() = default;
+    NNWork(const NNWork &) = delete;
+    NNWork &operator=(const NNWork &) = delete;
+    ~NNWork() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+    }
 };
 // lo/hi: exact per-plane min/max of the colours if known (else nullptr: computed with one more pass)
 void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const double *d_pal, int k,

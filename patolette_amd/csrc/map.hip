@@ -16,6 +16,7 @@
 // verified at every boundary and repaired where the speculation missed: ~2000 runs of one
 // wavefront each (DitherSeg), or ~130 000 runs of one LANE each on large images (DitherLanes).
 #include "map.h"
+#include "dither_slots.h"
 
 #include <algorithm>
 #include <cmath>
@@ -536,6 +537,7 @@ __device__ unsigned long long g_nn_trace[256][2];          // diagnostic build: 
 // ... and what its drains met: [0] drains, [1] pixels drained, [2] drains with a list of more than four, [3] of more than eight,
 // [4] pixels with more than eight, [5] pixels parked because the f32 pass could not tell first from second
 __device__ unsigned long long g_nn_stats[8];
+__device__ unsigned long long g_dl_wave[4096][4];  // ... and per wavefront of the speculative launch: clocks, steps with an exact pass, sum of the longest lists, steps with a crowded cell
 __device__ unsigned long long g_dl_stats[8];      // k_dither_lanes (PAMD_NN_STATS): lane-steps, outside the grid, long-list cells, ambiguous; wavefront-steps, with an exact pass, with a full scan, candidate-loop trips
 __device__ unsigned g_nn_flags;                             // timing experiments (wrong maps): 1 = drains evaluate nothing, 2 = nothing is parked
 #endif
@@ -1437,8 +1439,12 @@ struct DitherLanes {
     unsigned warm;                       // <= the shortest run
     const unsigned char *lut, *lut2;     // 16-byte records of the G^3 grid over the weighted palette, and their continuations (k_nn_lut_build)
     NNGrid g;
-    double hi[3];                        // upper corner of the grid: queries outside [lo, hi] take the full scan
+    double hi[3];                        // upper corner of the grid
+    const unsigned char *luto, *luto2;   // the same over the OUTER grid (32^3 cells, nine times the palette's extent): queries outside [lo, hi]
+    NNGrid go;
+    double hio[3];                       // its upper corner: queries outside that too take all k entries
     float amb;                           // f32 first pass: first and second must differ by more than this
+    float amb_p, amb_x;                  // ... for a query outside the grid: amb_p + amb_x |x - lo|^2
 };
 
 __global__ __launch_bounds__(256) void k_dither_lane_check(DitherLanes a) {
@@ -1448,6 +1454,58 @@ __global__ __launch_bounds__(256) void k_dither_lane_check(DitherLanes a) {
     bool same = true;
     for (unsigned i = 0; i < 16; i++) same = same && a.side[16ull * b + i] == (unsigned short)a.smap[a.R.idx(b - 1, lp - 16 + i)];
     if (!same) a.list[atomicAdd(a.list - 1, 1u)] = b;
+}
+
+// Every palette entry for the lanes that `want` it (a query outside both grids, a cell with more than thirty candidates), through
+// the f32 records of k_dither_lanes' LDS: the WAVEFRONT scans for each such lane in turn -- lane L takes entries L, L + 64,
+// L + 128, L + 192 against that lane's query, then the smallest and the second smallest of the 64 pairs (the smallest's owner
+// contributes its second) -- and the f64 loop over all k decides where the two lie within the margin.  Called by whole
+// wavefronts; not inlined on purpose.
+__device__ __attribute__((noinline)) int dither_nearest_all(const double x, const double y, const double z, const float xf, const float yf, const float zf,
+                                                             const bool want, const float amb, const int k) {
+    extern __shared__ double lds[];
+    const double *pwt = lds + 3 * k;
+    const float4 *r32 = reinterpret_cast<const float4 *>(lds + 6 * k);
+    const int ln = (int)(threadIdx.x & 63u);
+    float m1 = INFINITY, m2 = INFINITY; int best = 0;
+    unsigned long long todo = __ballot(want);
+    while (todo) {
+        const int l = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ULL;
+        const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xf), l));
+        const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yf), l));
+        const float qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zf), l));
+        float a1 = INFINITY, a2 = INFINITY; int ab = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = ln + 64 * q;
+            const float4 r = r32[j < k ? j : k - 1];
+            float tj = __builtin_fmaf(qx, r.x, __builtin_fmaf(qy, r.y, __builtin_fmaf(qz, r.z, r.w)));
+            tj = j < k ? tj : INFINITY;
+            a2 = __builtin_fminf(a2, __builtin_fmaxf(a1, tj));
+            ab = tj < a1 ? j : ab;
+            a1 = __builtin_fminf(a1, tj);
+        }
+        float g1 = a1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) g1 = __builtin_fminf(g1, __shfl_xor(g1, o, 64));
+        const unsigned long long wm = __ballot(a1 == g1);
+        const int who = wm ? (int)__builtin_ctzll(wm) : 0;           // (nobody: a NaN query -- the exact loop takes it)
+        float g2 = ln == who ? a2 : a1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) g2 = __builtin_fminf(g2, __shfl_xor(g2, o, 64));
+        const int gb = __builtin_amdgcn_readlane(ab, who);
+        if (ln == l) { m1 = wm ? g1 : NAN; m2 = g2; best = gb; }
+    }
+    if (want && !((m2 - m1) > amb)) {
+        double bd = INFINITY; best = 0;
+        for (int j = 0; j < k; j++) {
+            const double d0 = x - pwt[j], d1 = y - pwt[k + j], d2 = z - pwt[2 * k + j];
+            const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+            if (d < bd) { bd = d; best = j; }                       // ascending j + strict '<' = lowest index on ties
+        }
+    }
+    return best;
 }
 
 template <int MODE>
@@ -1478,53 +1536,86 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
             for (int i = 0; i < 16; i++) a.side[16ull * b + i] = 0xFFFFu;
         }
     }
-    double q0[16], q1[16], q2[16];                                  // the error queue: slot s = the error of the run's step s (mod 16)
-#pragma unroll
-    for (int s = 0; s < 16; s++) { q0[s] = 0.0; q1[s] = 0.0; q2[s] = 0.0; }
+#define PAMD_DL_EACH(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define PAMD_DL_DECL(S) double q0_##S = 0.0, q1_##S = 0.0, q2_##S = 0.0;
+    PAMD_DL_EACH(PAMD_DL_DECL)                                      // the error queue: slot s = the error of the run's step s (mod 16); named scalars: dither_slots.h
+#undef PAMD_DL_DECL
     if constexpr (MODE == 1) {
         if (active) {
             // the queue as the chain holds it after the last sixteen pixels of run b - 1: original pixel - chosen colour, oldest first
-#pragma unroll
-            for (int s = 0; s < 16; s++) {
-                const size_t rr = a.R.idx(b - 1, lp - 16 + s);
-                const unsigned c = a.smap[rr];
-                a.side[16ull * b + s] = (unsigned short)c;
-                q0[s] = a.sx[rr] - praw[c]; q1[s] = a.sy[rr] - praw[k + c]; q2[s] = a.sz[rr] - praw[2 * k + c];
+#define PAMD_DL_INIT(S)                                                                                                   \
+            {                                                                                                             \
+                const size_t rr = a.R.idx(b - 1, lp - 16 + S);                                                            \
+                const unsigned c = a.smap[rr];                                                                            \
+                a.side[16ull * b + S] = (unsigned short)c;                                                                \
+                q0_##S = a.sx[rr] - praw[c]; q1_##S = a.sy[rr] - praw[k + c]; q2_##S = a.sz[rr] - praw[2 * k + c];        \
             }
+            PAMD_DL_EACH(PAMD_DL_INIT)
+#undef PAMD_DL_INIT
         }
     }
     const int G = a.g.G;
     const double lo0 = a.g.lo[0], lo1 = a.g.lo[1], lo2 = a.g.lo[2], in0 = a.g.inv[0], in1 = a.g.inv[1], in2 = a.g.inv[2];
     const double hi0 = a.hi[0], hi1 = a.hi[1], hi2 = a.hi[2];
+    const double ol0 = a.go.lo[0], ol1 = a.go.lo[1], ol2 = a.go.lo[2], oh0 = a.hio[0], oh1 = a.hio[1], oh2 = a.hio[2];
     // Nearest colour.  First pass in f32 over the cell's candidates, as in k_nn_map_mid: t_j = |x - p_j|^2 - |x - lo|^2 from the
     // shifted records {-2 (p - lo), |p - lo|^2} (three fma), smallest and second smallest tracked; the smallest names the winner of
     // the f64 expression whenever the second lies more than a.amb above it (the bound of map.hip's table comment: the query is
     // inside the grid here, the palette's |p - lo|^2 is bounded by the host).  Otherwise -- about one query in a thousand, and
     // every query outside the grid or in a cell whose list runs past one record -- the exact f64 loop decides.
-    auto nearest = [&](const double x, const double y, const double z, const bool on) -> int {
-        const bool inside = x >= lo0 && x <= hi0 && y >= lo1 && y <= hi1 && z >= lo2 && z <= hi2;   // (a NaN: not inside)
+#ifdef PAMD_NN_STATS
+    unsigned ws_exact = 0, ws_full = 0, ws_trips = 0, ws_long = 0;  // (lane 0 of every wavefront counts its steps with an exact pass / a full scan)
+    const unsigned long long ws_t0 = wall_clock64();
+#endif
+    // the request: which grid, which cell, and the load of its record -- no branch, so that what follows it in the step is
+    // scheduled under the load (lanes that are off or outside both grids read the record of a clamped cell and ignore it)
+    struct NearestRec { uint4 rec; size_t cell; bool inside, outer; };
+    auto nearest_request = [&](const double x, const double y, const double z, const bool on) -> NearestRec {
+        NearestRec r;
+#ifdef PAMD_KM_TRACE
+        r.inside = (g_nn_flags & 16u) ? true : (x >= lo0 && x <= hi0 && y >= lo1 && y <= hi1 && z >= lo2 && z <= hi2);   // (16: timing experiment, wrong map: nobody is outside)
+#else
+        r.inside = x >= lo0 && x <= hi0 && y >= lo1 && y <= hi1 && z >= lo2 && z <= hi2;   // (a NaN: not inside)
+#endif
+        const double cx = on ? x : lo0, cy = on ? y : lo1, cz = on ? z : lo2;         // (a lane that is off may hold anything: cell 0)
+        r.cell = nn_cell(cx, cy, cz, G, lo0, lo1, lo2, in0, in1, in2);               // (clamped into the grid: a record, whatever the query)
+        r.outer = false;
+        const unsigned char *tab = a.lut;
+        // Error diffusion carries the queries far beyond the palette's hull wherever the image is (the queue's weights sum to 5.6:
+        // a colour the palette misses by d is asked for 5.6 d further out): those find their candidates in the outer grid.  A
+        // branch of the wavefront: on most content most steps have nobody outside.
+        if (__any(on && !r.inside)) {
+            r.outer = on && !r.inside && x >= ol0 && x <= oh0 && y >= ol1 && y <= oh1 && z >= ol2 && z <= oh2;
+            if (r.outer) { r.cell = nn_cell(x, y, z, a.go.G, ol0, ol1, ol2, a.go.inv[0], a.go.inv[1], a.go.inv[2]); tab = a.luto; }
+        }
+#ifdef PAMD_KM_TRACE
+        if (g_nn_flags & 4u) r.cell = ((size_t)(threadIdx.x & 63) * 4099u) % ((size_t)a.go.G * a.go.G * a.go.G);   // timing experiment (wrong map): the record does not depend on the query
+#endif
+        r.rec = *reinterpret_cast<const uint4 *>(tab + r.cell * 16);
+        return r;
+    };
+    auto nearest = [&](const double x, const double y, const double z, const bool on, const NearestRec nr) -> int {
+        const bool inside = nr.inside, outer = nr.outer;
         int cnt = 255;
         unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;          // the cell's candidates, a byte each, the first in s0's low byte
-        if (on && inside) {
-#ifdef PAMD_KM_TRACE
-            size_t cell = nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2);
-            if (g_nn_flags & 4u) cell = ((size_t)(threadIdx.x & 63) * 4099u) % ((size_t)G * G * G);   // timing experiment (wrong map): the record does not depend on the query
-#else
-            const size_t cell = nn_cell(x, y, z, G, lo0, lo1, lo2, in0, in1, in2);
-#endif
-            const uint4 rec = *reinterpret_cast<const uint4 *>(a.lut + cell * 16);
+        if (on && (inside || outer)) {
+            const uint4 rec = nr.rec;
+            const size_t cell = nr.cell;
+            const unsigned char *const t2 = inside ? a.lut2 : a.luto2;
             cnt = (int)(rec.x & 0xffu);
             const unsigned long long w0 = ((unsigned long long)rec.y << 32) | rec.x, w1 = ((unsigned long long)rec.w << 32) | rec.z;
             s0 = (w0 >> 8) | (w1 << 56); s1 = w1 >> 8;              // fifteen entries; past a short list its last one repeats (k_nn_lut_build)
             if (cnt > 15 && cnt != 255) {                           // a crowded cell: entries 15 .. 29 in the second record
-                const uint4 r2 = *reinterpret_cast<const uint4 *>(a.lut2 + cell * 16);
+                const uint4 r2 = *reinterpret_cast<const uint4 *>(t2 + cell * 16);
                 const unsigned long long x0 = ((unsigned long long)r2.y << 32) | r2.x, x1 = ((unsigned long long)r2.w << 32) | r2.z;
                 s1 |= x0 << 56; s2 = (x0 >> 8) | (x1 << 56); s3 = x1 >> 8;
             }
         }
-        const bool listed = cnt != 255;                             // else: outside the grid, or a cell with more than thirty candidates: all k entries
+        const bool listed = cnt != 255;                             // else: outside both grids, or a cell with more than thirty candidates: all k entries
         const int n = listed ? cnt : 0;
         const float xf = (float)(x - lo0), yf = (float)(y - lo1), zf = (float)(z - lo2);
+        // the margin of the first pass: the bound holds for any query with its own |x - lo|^2 in the place of |hi - lo|^2
+        const float amb = inside ? a.amb : __builtin_fmaf(a.amb_x, __builtin_fmaf(xf, xf, __builtin_fmaf(yf, yf, zf * zf)), a.amb_p);
         float m1 = INFINITY, m2 = INFINITY; int best = 0;
         {
             // four candidates a trip: their records are requested from LDS together, then evaluated in list order
@@ -1546,38 +1637,51 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
             }
         }
 #ifdef PAMD_KM_TRACE
-        const bool exact = (g_nn_flags & 8u) ? false : (on && !(listed && (m2 - m1) > a.amb));    // (8: timing experiment, wrong map)
+        const bool exact = (g_nn_flags & 8u) ? false : (on && listed && !((m2 - m1) > amb));    // (8: timing experiment, wrong map)
 #else
-        const bool exact = on && !(listed && (m2 - m1) > a.amb);    // (a NaN anywhere: exact)
+        const bool exact = on && listed && !((m2 - m1) > amb);      // (a NaN anywhere: exact)
 #endif
 #ifdef PAMD_NN_STATS
         {
-            const unsigned long long m_on = __ballot(on), m_out = __ballot(on && !inside), m_long = __ballot(on && inside && cnt > 15), m_amb = __ballot(on && listed && exact);
-            const unsigned long long m_ex = __ballot(exact), m_full = __ballot(exact && !listed);
+            const unsigned long long m_on = __ballot(on), m_out = __ballot(on && !listed), m_long = __ballot(on && (inside || outer) && cnt > 15), m_amb = __ballot(exact);
+            const unsigned long long m_ex = __ballot(exact), m_full = __ballot(on && !listed);
             int nmax = n;
             for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
             if ((threadIdx.x & 63) == 0 && m_on) {
                 atomicAdd(&g_dl_stats[0], (unsigned long long)__popcll(m_on)); atomicAdd(&g_dl_stats[1], (unsigned long long)__popcll(m_out));
                 atomicAdd(&g_dl_stats[2], (unsigned long long)__popcll(m_long)); atomicAdd(&g_dl_stats[3], (unsigned long long)__popcll(m_amb));
                 atomicAdd(&g_dl_stats[4], 1ULL);
-                if (m_ex) atomicAdd(&g_dl_stats[5], 1ULL);
-                if (m_full) atomicAdd(&g_dl_stats[6], 1ULL);
+                if (m_ex) { atomicAdd(&g_dl_stats[5], 1ULL); ws_exact++; }
+                if (m_full) { atomicAdd(&g_dl_stats[6], 1ULL); ws_full++; }
                 atomicAdd(&g_dl_stats[7], (unsigned long long)nmax);
+                ws_trips += (unsigned)nmax; if (m_out) ws_long++;
             }
         }
 #endif
         if (__any(exact)) {
+            // The f64 expression decides, among the CONTENDERS only: the true nearest entry (and every entry that ties with it) lies
+            // within 2 E of the f32 minimum, so the first pass is run over the list once more and only the entries within the margin of
+            // its minimum are measured in f64.  In list order with strict '<': the lowest index on ties.
             if (exact) {
                 double bd = INFINITY; best = 0;
-                auto test = [&](const int j) {
-                    const double d0 = x - pwt[j], d1 = y - pwt[k + j], d2 = z - pwt[2 * k + j];
-                    const double d = (d0 * d0 + d1 * d1) + d2 * d2;
-                    if (d < bd) { bd = d; best = j; }               // ascending j + strict '<' = lowest index on ties
-                };
-                if (listed) {
-                    for (int t = 0; t < n; t++) { test((int)(s0 & 0xffULL)); s0 = (s0 >> 8) | (s1 << 56); s1 = (s1 >> 8) | (s2 << 56); s2 = (s2 >> 8) | (s3 << 56); s3 >>= 8; }
-                } else for (int j = 0; j < k; j++) test(j);
+                const float lim = m1 + amb;
+                unsigned long long v0 = s0, v1 = s1, v2 = s2, v3 = s3;
+                for (int t = 0; t < n; t++) {
+                    const int j = (int)(v0 & 0xffULL);
+                    v0 = (v0 >> 8) | (v1 << 56); v1 = (v1 >> 8) | (v2 << 56); v2 = (v2 >> 8) | (v3 << 56); v3 >>= 8;
+                    const float4 r = r32[j];
+                    const float tj = __builtin_fmaf(xf, r.x, __builtin_fmaf(yf, r.y, __builtin_fmaf(zf, r.z, r.w)));
+                    if (tj <= lim) {
+                        const double d0 = x - pwt[j], d1 = y - pwt[k + j], d2 = z - pwt[2 * k + j];
+                        const double d = (d0 * d0 + d1 * d1) + d2 * d2;
+                        if (d < bd) { bd = d; best = j; }
+                    }
+                }
             }
+        }
+        if (__any(on && !listed)) {                                 // (a call: rare, and the step's code stays small)
+            const int ba = dither_nearest_all(x, y, z, xf, yf, zf, on && !listed, amb, k);
+            best = on && !listed ? ba : best;
         }
         return best;
     };
@@ -1588,36 +1692,187 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
     bool on = active && nsteps > 0;
     if (on) { c0 = a.sx[at]; c1 = a.sy[at]; c2 = a.sz[at]; if constexpr (MODE == 1) cm = (int)a.smap[at]; }
     int streak = 0;                                                 // MODE 1: consecutive choices equal to what smap holds
+    // Sixteen steps a trip: the queue's slots are registers, the step that starts at slot j reads them in the order j, j + 1, ...
+    // (dither_slots.h; with j a constant of the unrolled loop the macros' switches fold away).  One copy of the step selected by a
+    // scalar branch on the slot was measured 10 % slower (a lone wavefront pays for every taken branch with a refill of its
+    // instruction buffer), although it is a quarter of the code.
+    // The step is software-pipelined by hand: the first fifteen terms of the NEXT step's sums (they do not depend on this step's
+    // choice) are computed between the request for the cell's record and its first use.
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0;                            // riemersma.c:282-296: the sums of the step at hand, all but the last term
+    PAMD_DL_QUEUE_PARTIAL(0)
+    double l0 = q0_15, l1 = q1_15, l2 = q2_15;                      // the error of the step before (slot 15 of the starting queue)
     while (__any(on)) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const double p0 = c0, p1 = c1, p2 = c2;
-            const int was = cm;
-            const size_t cur = at;
-            const bool nxt = on && st + 1 < nsteps;
-            at = (st + 1 == wu) ? own : at + 64;                    // the run starts where the neighbour's column ends
-            if (nxt) { c0 = a.sx[at]; c1 = a.sy[at]; c2 = a.sz[at]; if constexpr (MODE == 1) cm = (int)a.smap[at]; }
-            double e0 = 0.0, e1 = 0.0, e2 = 0.0;                    // riemersma.c:282-296, in that order
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int s = (j + i) & 15;
-                e0 += q0[s] * wts.w[i]; e1 += q1[s] * wts.w[i]; e2 += q2[s] * wts.w[i];
+      for (int j = 0; j < 16; j++) {
+        const double p0 = c0, p1 = c1, p2 = c2;
+        const int was = cm;
+        const size_t cur = at;
+        const bool nxt = on && st + 1 < nsteps;
+        at = (st + 1 == wu) ? own : at + 64;                        // the run starts where the neighbour's column ends
+        if (nxt) { c0 = a.sx[at]; c1 = a.sy[at]; c2 = a.sz[at]; if constexpr (MODE == 1) cm = (int)a.smap[at]; }
+        e0 += l0 * wts.w[15]; e1 += l1 * wts.w[15]; e2 += l2 * wts.w[15];
+        const double x = kRw * (p0 + e0), y = kGw * (p1 + e1), z = kBw * (p2 + e2);
+        const NearestRec nr = nearest_request(x, y, z, on);
+        e0 = 0.0; e1 = 0.0; e2 = 0.0;
+        const int jn = (j + 1) & 15;
+        PAMD_DL_QUEUE_PARTIAL(jn)
+        const int bi = nearest(x, y, z, on, nr);
+        if (on) {
+            l0 = p0 - praw[bi]; l1 = p1 - praw[k + bi]; l2 = p2 - praw[2 * k + bi];       // riemersma.c:333-340
+            PAMD_DL_QUEUE_PUSH(j, l0, l1, l2)
+            if constexpr (MODE == 0) {
+                if (st >= wu) a.smap[cur] = (unsigned char)bi;
+                else if (st + 16 >= wu) a.side[16ull * b + (st + 16 - wu)] = (unsigned short)bi;
+            } else {
+                if (was == bi) streak++;
+                else { streak = 0; a.smap[cur] = (unsigned char)bi; }
             }
-            const int bi = nearest(kRw * (p0 + e0), kGw * (p1 + e1), kBw * (p2 + e2), on);
-            if (on) {
-                q0[j] = p0 - praw[bi]; q1[j] = p1 - praw[k + bi]; q2[j] = p2 - praw[2 * k + bi];       // riemersma.c:333-340
-                if constexpr (MODE == 0) {
-                    if (st >= wu) a.smap[cur] = (unsigned char)bi;
-                    else if (st + 16 >= wu) a.side[16ull * b + (st + 16 - wu)] = (unsigned short)bi;
-                } else {
-                    if (was == bi) streak++;
-                    else { streak = 0; a.smap[cur] = (unsigned char)bi; }
-                }
-            }
-            st++;
-            on = nxt && (MODE == 0 || streak < 16);
         }
+        st++;
+        on = nxt && (MODE == 0 || streak < 16);
+      }
     }
+#undef PAMD_DL_EACH
+#ifdef PAMD_NN_STATS
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&g_nn_stats[6], (unsigned long long)ws_exact); atomicMax(&g_nn_stats[7], (unsigned long long)ws_full);
+        const unsigned wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (MODE == 0 && wv < 4096u) { g_dl_wave[wv][0] = wall_clock64() - ws_t0; g_dl_wave[wv][1] = ws_exact; g_dl_wave[wv][2] = ws_trips; g_dl_wave[wv][3] = ws_long; }
+    }
+#endif
+}
+
+// A listed run again, by ONE WAVEFRONT (the repair passes of the lane layout).  A pass waits for its slowest run, a lane's step is
+// ~2 us of dependent loads and a pass listed a few hundred runs: 64 of them side by side in a wavefront gain nothing, each on a
+// wavefront of its own takes k_dither's step (the palette search across the 64 lanes, no table: ~0.45 us).  Pixels and choices
+// in the transposed layout (one cache line per lane and load: a few thousand runs, it does not matter here); the queue rebuilt
+// from the sixteen choices before the run as k_dither<.., 1> does; stops when a whole group of sixteen equals what is there.
+template <int PER>
+__global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const double *__restrict__ pal /* planar (k,3), linear Rec2020 */, int k, DitherWeights wts) {
+    extern __shared__ double lds[];
+    constexpr int kRing = 128;                                       // >= 64 + 15 pending pixels
+    double *praw = lds, *pwt = lds + 3 * k;                          // [3][k] raw palette; scaled by the (float)-cast weights (riemersma.c:419-425)
+    double *rpx = lds + 6 * k;                                       // [3][kRing] channels of the pending pixels
+    unsigned int *rpos = reinterpret_cast<unsigned int *>(rpx + 3 * kRing);   // [kRing] their places in the transposed layout
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= a.list[-1]) return;
+    const unsigned b = a.list[blockIdx.x];
+    const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
+    for (int j = lane; j < k; j += 64)
+        for (int c = 0; c < 3; c++) { const double v = pal[c * k + j]; praw[c * k + j] = v; pwt[c * k + j] = v * fw[c]; }
+    __syncthreads();
+    double ex[PER], ey[PER], ez[PER];                                // the lane's own entries [lane PER, (lane + 1) PER)
+#pragma unroll
+    for (int m = 0; m < PER; m++) {
+        const int j = lane * PER + m;
+        ex[m] = j < k ? pwt[j] : 1e300; ey[m] = j < k ? pwt[k + j] : 1e300; ez[m] = j < k ? pwt[2 * k + j] : 1e300;
+    }
+    const int ch = lane < 48 ? lane >> 4 : 2, dph = lane & 15;       // as k_dither: lane (c, d) sums channel c of the step d (mod 16)
+    const double Wc = ch == 0 ? kRw : (ch == 1 ? kGw : kBw);
+    double wl[16], keep[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        double v = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) v = (15 - ((dph - j - 1) & 15)) == i ? wts.w[i] : v;
+        wl[j] = v;
+        keep[j] = dph == j ? 0.0 : 1.0;
+    }
+    double acc = 0.0;
+    const double *prw = praw + ch * k;
+    auto nearest = [&](const double qx, const double qy, const double qz) -> int {     // k_dither's, PER > 0
+        double dd[PER];
+#pragma unroll
+        for (int m = 0; m < PER; m++) {
+            const double e0 = qx - ex[m], e1 = qy - ey[m], e2 = qz - ez[m];
+            dd[m] = (e0 * e0 + e1 * e1) + e2 * e2;
+        }
+        double bd = dd[0];
+#pragma unroll
+        for (int m = 1; m < PER; m++) bd = fmin(bd, dd[m]);
+        int bj;
+        if constexpr (PER == 4 || PER == 2) {
+            int e;
+            unsigned t;
+            if constexpr (PER == 4) t = dither_rows4(dd[0], dd[1], dd[2], dd[3], bd, e);
+            else t = dither_rows2(dd[0], bd, e);
+            bj = e | (lane * PER);
+            const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)t, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)t, 16),
+                           r2 = (unsigned)__builtin_amdgcn_readlane((int)t, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)t, 48);
+            unsigned m23, mh;
+            asm("s_min_u32 %0, %2, %3\n\ts_min_u32 %1, %4, %5\n\ts_min_u32 %0, %0, %1" : "=&s"(mh), "=&s"(m23) : "s"(r0), "s"(r1), "s"(r2), "s"(r3));
+            const unsigned hi = (unsigned)__double2hiint(bd), lo = (unsigned)__double2loint(bd);
+            unsigned long long c = __ballot(hi == mh);
+            if (__popcll(c) != 1) {
+                const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+                c = __ballot(hi == mh && lo == ml);
+            }
+            return __builtin_amdgcn_readlane(bj, (int)__builtin_ctzll(c));
+        } else {
+            bj = PER - 1;
+#pragma unroll
+            for (int m = PER - 2; m >= 0; m--) bj = dd[m] == bd ? m : bj;
+            bj += lane * PER;
+            return __builtin_amdgcn_readlane(bj, wave_argmin_nonneg_f64(bd));
+        }
+    };
+    const unsigned len = (unsigned)(a.R.t(b + 1) - a.R.t(b)), lp = (unsigned)(a.R.t(b) - a.R.t(b - 1));     // (b >= 1: run 0 is never listed)
+    unsigned head = 16, count = 16;
+    {
+        // the sixteen pixels before the run and the choices the map holds for them: the queue as the chain has it there
+        if (lane < 16) {
+            const size_t rr = a.R.idx(b - 1, lp - 16 + lane);
+            rpx[lane] = a.sx[rr]; rpx[kRing + lane] = a.sy[rr]; rpx[2 * kRing + lane] = a.sz[rr];
+            rpos[lane] = (unsigned)rr;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned cur = (unsigned)a.smap[rpos[dph]];
+        if (lane < 16) a.side[16ull * b + lane] = (unsigned short)cur;
+        const double ev = rpx[ch * kRing + dph] - prw[cur];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double e = __shfl(ev, (lane & 48) | j, 64);
+            acc = __builtin_fma(acc, keep[j], e * wl[j]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    bool done = false;
+    auto group = [&](const int limit) {
+        double pcs[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) pcs[j] = rpx[ch * kRing + ((head + (unsigned)j) & (kRing - 1))];
+        unsigned was = 0, wpos = 0;
+        if (lane < limit) { wpos = rpos[(head + (unsigned)lane) & (kRing - 1)]; was = (unsigned)a.smap[wpos]; }
+        int res = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j < limit) {                                         // wave-uniform
+                const double qv = Wc * (pcs[j] + acc);
+                const int bi = nearest(readlane_f64(qv, j), readlane_f64(qv, 16 + j), readlane_f64(qv, 32 + j));
+                res = lane == j ? bi : res;
+                const double err = pcs[j] - prw[bi];
+                acc = __builtin_fma(acc, keep[j], err * wl[j]);
+            }
+        }
+        if (lane < limit && was != (unsigned)res) a.smap[wpos] = (unsigned char)res;
+        if (limit == 16 && __all(lane >= 16 || was == (unsigned)res)) done = true;     // the old chain is met: the rest of the run stands
+        head += 16;
+    };
+    for (unsigned p0 = 0; p0 < len && !done; p0 += 64) {
+        const unsigned p = p0 + (unsigned)lane;
+        if (p < len) {
+            const size_t rr = a.R.idx(b, p);
+            const unsigned slot = (count + (unsigned)lane) & (kRing - 1);
+            rpx[slot] = a.sx[rr]; rpx[kRing + slot] = a.sy[rr]; rpx[2 * kRing + slot] = a.sz[rr];
+            rpos[slot] = (unsigned)rr;
+        }
+        count += len - p0 < 64u ? len - p0 : 64u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        while ((int)(count - head) >= 16 && !done) group(16);
+    }
+    if (count != head && !done) group((int)(count - head));
 }
 
 struct DitherConfig { int segments = 0, warm = -1, lanes = -1; };    // 0 / -1 = chosen by launch_dither
@@ -1646,7 +1901,9 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     // diffusion pushes queries beyond the palette's hull; what still falls outside takes the full scan
     std::vector<double> wp(3 * (size_t)k);
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
-    NNGrid g;
+    NNGrid g, go;
+    go.G = 32;
+    if (const char *e = getenv("PAMD_DITHER_OUTER_G")) go.G = atoi(e) == 16 ? 16 : 32;      // (measurement knob)
     g.G = npix >= ((size_t)1 << 20) ? 64 : 32;
 #ifdef PAMD_KM_TRACE
     if (const char *e = getenv("PAMD_DITHER_GRID")) g.G = atoi(e) == 32 ? 32 : 64;      // diagnostic build: the records' grid
@@ -1662,6 +1919,12 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         g.cw[c] = Rg / g.G;
         g.inv[c] = g.G / Rg;
         a.hi[c] = g.lo[c] + Rg;
+        // the outer grid: four extents wider on every side, 32 cells across
+        const double mo = 4.0 * r + 1e-2, Ro = r + 2 * mo;
+        go.lo[c] = lo - mo;
+        go.cw[c] = Ro / go.G;
+        go.inv[c] = go.G / Ro;
+        a.hio[c] = go.lo[c] + Ro;
     }
     {
         // margin of the f32 first pass (the table comment above k_nn_map_mid): 2.5 E, E = 2^-24 (9 max |p - lo|^2 + 5 |hi - lo|^2) (1 + 1e-3)
@@ -1676,11 +1939,15 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         a.amb = (float)M;
         if ((double)a.amb < M) a.amb = std::nextafter(a.amb, INFINITY);
         if (!(M < 3.0e38)) a.amb = INFINITY;
+        // outside the grid the query's own |x - lo|^2 stands where |hi - lo|^2 did (evaluated in f32: 1e-6 relative, inside the 1e-3)
+        const double Mp = 2.5 * 1.002 * 0x1.0p-24 * 9.0 * wmax, Mx = 2.5 * 1.002 * 0x1.0p-24 * 5.0;
+        a.amb_p = std::nextafter((float)Mp, INFINITY); a.amb_x = std::nextafter((float)Mx, INFINITY);
+        if (!(Mp < 3.0e38)) a.amb_p = INFINITY;
     }
-    const int ncell = g.G * g.G * g.G;
+    const int ncell = g.G * g.G * g.G, ncello = go.G * go.G * go.G;
     w.dtab.reserve(3 * (size_t)k);
-    w.lut.reserve((size_t)ncell * 32);
-    w.clist.reserve((size_t)(ncell / 64) * (1 + kCoarseMax) * 2);
+    w.lut.reserve(((size_t)ncell + ncello) * 32);
+    w.clist.reserve((size_t)((ncell + ncello) / 64) * (1 + kCoarseMax) * 2);
     w.dsort.reserve(3 * cells);
     if (w.dpos.cap < npix) { w.order_w = 0; w.order_h = 0; }
     w.dpos.reserve(npix);
@@ -1689,12 +1956,34 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     w.hrep.reserve(1);
     HIP_CHECK(hipMemcpyAsync(w.dtab.p, wp.data(), wp.size() * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));                               // (wp is a local: the copy must have left the host)
+    // the two record grids depend on the palette alone, the gather on the image alone: the grids are built on a side stream
+    // (forked off `s` here, joined before the first launch that reads them), a few hundred single-wavefront blocks under a
+    // bandwidth-bound kernel
+    if (w.side_stream == nullptr || w.side_dev != current_device()) {
+        if (w.ev_fork) { (void)hipEventDestroy(w.ev_fork); w.ev_fork = nullptr; }
+        if (w.ev_join) { (void)hipEventDestroy(w.ev_join); w.ev_join = nullptr; }
+        if (w.side_stream) { (void)hipStreamDestroy(w.side_stream); w.side_stream = nullptr; }
+        HIP_CHECK(hipStreamCreateWithFlags(&w.side_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+        w.side_dev = current_device();
+    }
+    hipStream_t sb = w.side_stream;
+    HIP_CHECK(hipEventRecord(w.ev_fork, s));
+    HIP_CHECK(hipStreamWaitEvent(sb, w.ev_fork, 0));
     unsigned char *l1 = w.lut.p, *l2 = w.lut.p + (size_t)ncell * 16;
     {
-        KTIME("k_nn_lut_build", s, 32.0 * ncell);
-        hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncell / 64, 64, 0, s, (const double *)w.dtab.p, k, g, w.clist.p, (float4 *)nullptr);
-        hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncell / 64, 64, 0, s, (const double *)w.dtab.p, k, g, l1, l2, (const unsigned char *)w.clist.p, (unsigned int *)nullptr);
+        KTIME("k_nn_lut_build", sb, 32.0 * ncell);
+        hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncell / 64, 64, 0, sb, (const double *)w.dtab.p, k, g, w.clist.p, (float4 *)nullptr);
+        hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncell / 64, 64, 0, sb, (const double *)w.dtab.p, k, g, l1, l2, (const unsigned char *)w.clist.p, (unsigned int *)nullptr);
     }
+    unsigned char *lo1 = w.lut.p + (size_t)ncell * 32, *lo2 = lo1 + (size_t)ncello * 16, *clo = (unsigned char *)w.clist.p + (size_t)(ncell / 64) * (1 + kCoarseMax);
+    {
+        KTIME("k_nn_lut_build", sb, 32.0 * ncello);
+        hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncello / 64, 64, 0, sb, (const double *)w.dtab.p, k, go, clo, (float4 *)nullptr);
+        hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncello / 64, 64, 0, sb, (const double *)w.dtab.p, k, go, lo1, lo2, (const unsigned char *)clo, (unsigned int *)nullptr);
+    }
+    HIP_CHECK(hipEventRecord(w.ev_join, sb));
     double *sx = w.dsort.p, *sy = sx + cells, *sz = sy + cells;
     const dim3 tiles((unsigned)ceil_div((size_t)a.R.Lmax, 64), (unsigned)nw), tiles8((unsigned)ceil_div((size_t)a.R.Lmax, 256), (unsigned)ceil_div(S, 8));
     if (!(g_dither_order_cache && w.order_w == width && w.order_h == height && w.order_dev == current_device())) {
@@ -1715,10 +2004,12 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
             default: throw HipError("patolette_amd: the dither takes its pixels as linear Rec2020, sRGB, CIELuv or ICtCp");
         }
     }
+    HIP_CHECK(hipStreamWaitEvent(s, w.ev_join, 0));
     a.sx = sx; a.sy = sy; a.sz = sz;
     a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((cells + 63) & ~(size_t)63));
     a.list = w.dside.p + 1;
     a.lut = l1; a.lut2 = l2; a.g = g;
+    a.luto = lo1; a.luto2 = lo2; a.go = go;
     const size_t lds = (size_t)6 * k * sizeof(double) + (size_t)k * sizeof(float4);
     {
         KTIME("k_dither", s, 25.0 * npix);
@@ -1744,7 +2035,13 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         if (stalled >= 2) return false;
         w.dither_repairs += nf;
         KTIME("k_dither_fix", s, 0.0);
-        hipLaunchKernelGGL(k_dither_lanes<1>, (unsigned)ceil_div((size_t)nf, 256), 256, lds, s, a, d_pal, k, wts);
+        // PAMD_DITHER_REPAIR=lanes: the listed runs 64 to a wavefront again (k_dither_lanes<1>), for comparison
+        static const bool repair_lanes = getenv("PAMD_DITHER_REPAIR") && !strcmp(getenv("PAMD_DITHER_REPAIR"), "lanes");
+        const size_t lds_r = (size_t)6 * k * sizeof(double) + 3 * 128 * sizeof(double) + 128 * sizeof(unsigned);
+        if (repair_lanes) hipLaunchKernelGGL(k_dither_lanes<1>, (unsigned)ceil_div((size_t)nf, 256), 256, lds, s, a, d_pal, k, wts);
+        else if (k <= 64) hipLaunchKernelGGL(k_dither_lane_repair<1>, nf, 64, lds_r, s, a, d_pal, k, wts);
+        else if (k <= 128) hipLaunchKernelGGL(k_dither_lane_repair<2>, nf, 64, lds_r, s, a, d_pal, k, wts);
+        else hipLaunchKernelGGL(k_dither_lane_repair<4>, nf, 64, lds_r, s, a, d_pal, k, wts);
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -1959,6 +2256,9 @@ extern "C" int patolette_amd_debug_nn_trace(unsigned long long *out) {
 }
 extern "C" int patolette_amd_debug_nn_flags(unsigned flags) {
     return hipMemcpyToSymbol(HIP_SYMBOL(pamd::g_nn_flags), &flags, sizeof flags) == hipSuccess ? 0 : -1;
+}
+extern "C" int patolette_amd_debug_dither_lane_waves(unsigned long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pamd::g_dl_wave), sizeof(unsigned long long) * 4 * (size_t)(n < 4096 ? n : 4096)) == hipSuccess ? 0 : -1;
 }
 extern "C" int patolette_amd_debug_dither_lane_stats(unsigned long long *out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pamd::g_dl_stats), sizeof(pamd::g_dl_stats)) != hipSuccess) return -1;
