@@ -19,6 +19,7 @@ struct NNWork {                        // scratch of the pruned NN map
     DevBuf<unsigned int> dpos;         // ... their linear pixel numbers (a function of width and height: kept between calls)
     size_t order_w = 0, order_h = 0; int order_dev = -1;
     DevBuf<unsigned char> dsmap;       // ... the choices in curve order, and behind them the [S][16] boundary records
+    DevBuf<unsigned char> dflag;       // ... [S + 1] which boundaries the last check listed
     size_t dither_segments = 0, dither_repairs = 0, dither_rounds = 0;   // of the last launch_dither
     size_t dither_through = 0;         // ... times a stalled verification was resolved by walking one run through its successors
     hipStream_t side_stream = nullptr; // lane-per-run dither: the record grids are built here while the pixels are gathered

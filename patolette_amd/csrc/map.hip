@@ -1436,13 +1436,14 @@ struct DitherLanes {
     unsigned char *smap;                 // choices, transposed layout
     unsigned short *side;                // [S][16] the choices a run's starting queue was built from (0xFFFF = none: the run is walked again)
     unsigned *list;                      // runs whose boundary check failed; list[-1] = how many
+    unsigned char *flag;                 // [S + 1] the same per run: 1 = listed by the last check
     unsigned warm;                       // <= the shortest run
     const unsigned char *lut, *lut2;     // 16-byte records of the G^3 grid over the weighted palette, and their continuations (k_nn_lut_build)
     NNGrid g;
     double hi[3];                        // upper corner of the grid
-    const unsigned char *luto, *luto2;   // the same over the OUTER grid (32^3 cells, nine times the palette's extent): queries outside [lo, hi]
-    NNGrid go;
-    double hio[3];                       // its upper corner: queries outside that too take all k entries
+    // the same over two wider grids for the queries outside [lo, hi]: the palette's box with 1.5 extents around it (as many cells as
+    // the first grid), then with 4 extents around it (32^3 cells); queries outside that too take all k entries
+    struct Wider { NNGrid g; double hi[3]; const unsigned char *lut, *lut2; } wide[2];
     float amb;                           // f32 first pass: first and second must differ by more than this
     float amb_p, amb_x;                  // ... for a query outside the grid: amb_p + amb_x |x - lo|^2
 };
@@ -1453,6 +1454,7 @@ __global__ __launch_bounds__(256) void k_dither_lane_check(DitherLanes a) {
     const unsigned lp = (unsigned)(a.R.t(b) - a.R.t(b - 1));        // length of run b - 1
     bool same = true;
     for (unsigned i = 0; i < 16; i++) same = same && a.side[16ull * b + i] == (unsigned short)a.smap[a.R.idx(b - 1, lp - 16 + i)];
+    a.flag[b] = same ? 0 : 1;                                       // (flag[0] and flag[S] stay 0)
     if (!same) a.list[atomicAdd(a.list - 1, 1u)] = b;
 }
 
@@ -1557,7 +1559,6 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
     const int G = a.g.G;
     const double lo0 = a.g.lo[0], lo1 = a.g.lo[1], lo2 = a.g.lo[2], in0 = a.g.inv[0], in1 = a.g.inv[1], in2 = a.g.inv[2];
     const double hi0 = a.hi[0], hi1 = a.hi[1], hi2 = a.hi[2];
-    const double ol0 = a.go.lo[0], ol1 = a.go.lo[1], ol2 = a.go.lo[2], oh0 = a.hio[0], oh1 = a.hio[1], oh2 = a.hio[2];
     // Nearest colour.  First pass in f32 over the cell's candidates, as in k_nn_map_mid: t_j = |x - p_j|^2 - |x - lo|^2 from the
     // shifted records {-2 (p - lo), |p - lo|^2} (three fma), smallest and second smallest tracked; the smallest names the winner of
     // the f64 expression whenever the second lies more than a.amb above it (the bound of map.hip's table comment: the query is
@@ -1569,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
 #endif
     // the request: which grid, which cell, and the load of its record -- no branch, so that what follows it in the step is
     // scheduled under the load (lanes that are off or outside both grids read the record of a clamped cell and ignore it)
-    struct NearestRec { uint4 rec; size_t cell; bool inside, outer; };
+    struct NearestRec { uint4 rec; size_t cell; const unsigned char *tab2; bool inside, outer; };
     auto nearest_request = [&](const double x, const double y, const double z, const bool on) -> NearestRec {
         NearestRec r;
 #ifdef PAMD_KM_TRACE
@@ -1580,16 +1581,24 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
         const double cx = on ? x : lo0, cy = on ? y : lo1, cz = on ? z : lo2;         // (a lane that is off may hold anything: cell 0)
         r.cell = nn_cell(cx, cy, cz, G, lo0, lo1, lo2, in0, in1, in2);               // (clamped into the grid: a record, whatever the query)
         r.outer = false;
+        r.tab2 = a.lut2;
         const unsigned char *tab = a.lut;
         // Error diffusion carries the queries far beyond the palette's hull wherever the image is (the queue's weights sum to 5.6:
         // a colour the palette misses by d is asked for 5.6 d further out): those find their candidates in the outer grid.  A
         // branch of the wavefront: on most content most steps have nobody outside.
         if (__any(on && !r.inside)) {
-            r.outer = on && !r.inside && x >= ol0 && x <= oh0 && y >= ol1 && y <= oh1 && z >= ol2 && z <= oh2;
-            if (r.outer) { r.cell = nn_cell(x, y, z, a.go.G, ol0, ol1, ol2, a.go.inv[0], a.go.inv[1], a.go.inv[2]); tab = a.luto; }
+#pragma unroll
+            for (int lv = 0; lv < 2; lv++) {
+                const DitherLanes::Wider &wd = a.wide[lv];
+                const bool here = on && !r.inside && !r.outer && x >= wd.g.lo[0] && x <= wd.hi[0] && y >= wd.g.lo[1] && y <= wd.hi[1] && z >= wd.g.lo[2] && z <= wd.hi[2];
+                if (here) {
+                    r.cell = nn_cell(x, y, z, wd.g.G, wd.g.lo[0], wd.g.lo[1], wd.g.lo[2], wd.g.inv[0], wd.g.inv[1], wd.g.inv[2]);
+                    tab = wd.lut; r.tab2 = wd.lut2; r.outer = true;
+                }
+            }
         }
 #ifdef PAMD_KM_TRACE
-        if (g_nn_flags & 4u) r.cell = ((size_t)(threadIdx.x & 63) * 4099u) % ((size_t)a.go.G * a.go.G * a.go.G);   // timing experiment (wrong map): the record does not depend on the query
+        if (g_nn_flags & 4u) r.cell = ((size_t)(threadIdx.x & 63) * 4099u) % (size_t)32768;   // timing experiment (wrong map): the record does not depend on the query
 #endif
         r.rec = *reinterpret_cast<const uint4 *>(tab + r.cell * 16);
         return r;
@@ -1601,7 +1610,7 @@ __global__ __launch_bounds__(256) void k_dither_lanes(DitherLanes a, const doubl
         if (on && (inside || outer)) {
             const uint4 rec = nr.rec;
             const size_t cell = nr.cell;
-            const unsigned char *const t2 = inside ? a.lut2 : a.luto2;
+            const unsigned char *const t2 = nr.tab2;
             cnt = (int)(rec.x & 0xffu);
             const unsigned long long w0 = ((unsigned long long)rec.y << 32) | rec.x, w1 = ((unsigned long long)rec.w << 32) | rec.z;
             s0 = (w0 >> 8) | (w1 << 56); s1 = w1 >> 8;              // fifteen entries; past a short list its last one repeats (k_nn_lut_build)
@@ -1816,27 +1825,11 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
             return __builtin_amdgcn_readlane(bj, wave_argmin_nonneg_f64(bd));
         }
     };
-    const unsigned len = (unsigned)(a.R.t(b + 1) - a.R.t(b)), lp = (unsigned)(a.R.t(b) - a.R.t(b - 1));     // (b >= 1: run 0 is never listed)
+    // A boundary that fails right behind another failing one is not this wavefront's: the first of such a row (its head) walks
+    // through all of them, one after the other -- each starts from what its predecessor ends with, nothing to gain side by side.
+    if (a.flag[b - 1]) return;                                      // (b >= 1: run 0 is never listed)
     unsigned head = 16, count = 16;
-    {
-        // the sixteen pixels before the run and the choices the map holds for them: the queue as the chain has it there
-        if (lane < 16) {
-            const size_t rr = a.R.idx(b - 1, lp - 16 + lane);
-            rpx[lane] = a.sx[rr]; rpx[kRing + lane] = a.sy[rr]; rpx[2 * kRing + lane] = a.sz[rr];
-            rpos[lane] = (unsigned)rr;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const unsigned cur = (unsigned)a.smap[rpos[dph]];
-        if (lane < 16) a.side[16ull * b + lane] = (unsigned short)cur;
-        const double ev = rpx[ch * kRing + dph] - prw[cur];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const double e = __shfl(ev, (lane & 48) | j, 64);
-            acc = __builtin_fma(acc, keep[j], e * wl[j]);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    unsigned tail = 0;                                              // lanes 0 .. 15: the last sixteen choices made, oldest first
     bool done = false;
     auto group = [&](const int limit) {
         double pcs[16];
@@ -1857,22 +1850,90 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
         }
         if (lane < limit && was != (unsigned)res) a.smap[wpos] = (unsigned char)res;
         if (limit == 16 && __all(lane >= 16 || was == (unsigned)res)) done = true;     // the old chain is met: the rest of the run stands
-        head += 16;
+        // the window of the last sixteen choices moves on by `limit`
+        const unsigned moved = (unsigned)__shfl((int)tail, (lane + limit) & 63, 64), fresh = (unsigned)__shfl(res, (lane - (16 - limit)) & 63, 64);
+        tail = lane < 16 - limit ? moved : fresh;
+        head += (unsigned)limit;
     };
-    for (unsigned p0 = 0; p0 < len && !done; p0 += 64) {
-        const unsigned p = p0 + (unsigned)lane;
-        if (p < len) {
-            const size_t rr = a.R.idx(b, p);
-            const unsigned slot = (count + (unsigned)lane) & (kRing - 1);
-            rpx[slot] = a.sx[rr]; rpx[kRing + slot] = a.sy[rr]; rpx[2 * kRing + slot] = a.sz[rr];
-            rpos[slot] = (unsigned)rr;
+    // the queue as the chain holds it after the sixteen pixels in ring slots head - 16 .. head - 1 with the choices `c16` (lane d
+    // of every quarter: the choice of pixel d): their error vectors pushed in order into zero sums -- lane (c, d) restarts at step
+    // d, so whatever it summed before never reaches a pixel.  Afterwards the ring is re-based: head = count = 16.
+    auto requeue = [&](const unsigned c16) {
+        const double ev = rpx[ch * kRing + ((head - 16u + (unsigned)dph) & (kRing - 1))] - prw[c16];
+        acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double e = __shfl(ev, (lane & 48) | j, 64);
+            acc = __builtin_fma(acc, keep[j], e * wl[j]);
         }
-        count += len - p0 < 64u ? len - p0 : 64u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        while ((int)(count - head) >= 16 && !done) group(16);
+    };
+    constexpr unsigned kMaxWalk = 64;                               // runs one wavefront walks through in a pass (the rest: next pass)
+    bool in_row = true;                                             // still among the failing boundaries this one heads
+    for (unsigned r = b, walked = 0;; ) {
+        const unsigned len = (unsigned)(a.R.t(r + 1) - a.R.t(r));
+        if (r == b) {
+            // the sixteen pixels before the run and the choices the map holds for them
+            const unsigned lp = (unsigned)(a.R.t(r) - a.R.t(r - 1));
+            if (lane < 16) {
+                const size_t rr = a.R.idx(r - 1, lp - 16 + lane);
+                rpx[lane] = a.sx[rr]; rpx[kRing + lane] = a.sy[rr]; rpx[2 * kRing + lane] = a.sz[rr];
+                rpos[lane] = (unsigned)rr;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            tail = (unsigned)a.smap[rpos[dph]];                      // (every lane: the choice of predecessor dph)
+        }
+        // what run r starts from: recorded, and the queue rebuilt from it (a partial group may have left the lanes' phases anywhere)
+        const unsigned c16 = (unsigned)__shfl((int)tail, dph, 64);
+        if (lane < 16) a.side[16ull * r + lane] = (unsigned short)tail;
+        requeue(c16);
+        {   // re-base the ring: the sixteen pixels just used move to slots 0 .. 15
+            double m0 = 0, m1 = 0, m2 = 0;
+            if (lane < 16) { const unsigned sl = (head - 16u + (unsigned)lane) & (kRing - 1); m0 = rpx[sl]; m1 = rpx[kRing + sl]; m2 = rpx[2 * kRing + sl]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) { rpx[lane] = m0; rpx[kRing + lane] = m1; rpx[2 * kRing + lane] = m2; }
+            head = count = 16;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        done = false;
+        for (unsigned p0 = 0; p0 < len && !done; p0 += 64) {
+            const unsigned p = p0 + (unsigned)lane;
+            if (p < len) {
+                const size_t rr = a.R.idx(r, p);
+                const unsigned slot = (count + (unsigned)lane) & (kRing - 1);
+                rpx[slot] = a.sx[rr]; rpx[kRing + slot] = a.sy[rr]; rpx[2 * kRing + slot] = a.sz[rr];
+                rpos[slot] = (unsigned)rr;
+            }
+            count += len - p0 < 64u ? len - p0 : 64u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            while ((int)(count - head) >= 16 && !done) group(16);
+        }
+        if (count != head && !done) group((int)(count - head));
+        // run r is final for this pass.  On into the next one?
+        const unsigned nr = r + 1;
+        if (nr >= a.R.S) break;
+        const bool listed = a.flag[nr] != 0;
+        if (done) {
+            // met what was there: the rest of run r stands.  If the next boundary stands too (or another row starts there), finished;
+            // inside this row the next run was started from something else: on, from the end of run r as the map has it
+            if (!(listed && in_row)) break;
+            const unsigned ln = len;
+            if (lane < 16) {
+                const size_t rr = a.R.idx(r, ln - 16 + lane);
+                const unsigned sl = (head - 16u + (unsigned)lane) & (kRing - 1);
+                rpx[sl] = a.sx[rr]; rpx[kRing + sl] = a.sy[rr]; rpx[2 * kRing + sl] = a.sz[rr];
+                rpos[sl] = (unsigned)rr;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            tail = (unsigned)a.smap[rpos[(head - 16u + (unsigned)dph) & (kRing - 1)]];
+        } else if (listed && !in_row) break;                        // the head of another row: its own wavefront's (checked again next pass)
+        if (!listed) in_row = false;
+        if (++walked >= kMaxWalk) break;
+        r = nr;
     }
-    if (count != head && !done) group((int)(count - head));
 }
 
 struct DitherConfig { int segments = 0, warm = -1, lanes = -1; };    // 0 / -1 = chosen by launch_dither
@@ -1901,9 +1962,7 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     // diffusion pushes queries beyond the palette's hull; what still falls outside takes the full scan
     std::vector<double> wp(3 * (size_t)k);
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
-    NNGrid g, go;
-    go.G = 32;
-    if (const char *e = getenv("PAMD_DITHER_OUTER_G")) go.G = atoi(e) == 16 ? 16 : 32;      // (measurement knob)
+    NNGrid g, gw[2];
     g.G = npix >= ((size_t)1 << 20) ? 64 : 32;
 #ifdef PAMD_KM_TRACE
     if (const char *e = getenv("PAMD_DITHER_GRID")) g.G = atoi(e) == 32 ? 32 : 64;      // diagnostic build: the records' grid
@@ -1919,12 +1978,15 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         g.cw[c] = Rg / g.G;
         g.inv[c] = g.G / Rg;
         a.hi[c] = g.lo[c] + Rg;
-        // the outer grid: four extents wider on every side, 32 cells across
-        const double mo = 4.0 * r + 1e-2, Ro = r + 2 * mo;
-        go.lo[c] = lo - mo;
-        go.cw[c] = Ro / go.G;
-        go.inv[c] = go.G / Ro;
-        a.hio[c] = go.lo[c] + Ro;
+        // the wider grids: 1.5 extents around the palette's box with the first grid's number of cells, 4 extents with 32 across
+        for (int lv = 0; lv < 2; lv++) {
+            gw[lv].G = lv == 0 ? g.G : 32;
+            const double mo = (lv == 0 ? 1.5 : 4.0) * r + (lv == 0 ? 5e-3 : 1e-2), Ro = r + 2 * mo;
+            gw[lv].lo[c] = lo - mo;
+            gw[lv].cw[c] = Ro / gw[lv].G;
+            gw[lv].inv[c] = gw[lv].G / Ro;
+            a.wide[lv].hi[c] = gw[lv].lo[c] + Ro;
+        }
     }
     {
         // margin of the f32 first pass (the table comment above k_nn_map_mid): 2.5 E, E = 2^-24 (9 max |p - lo|^2 + 5 |hi - lo|^2) (1 + 1e-3)
@@ -1944,15 +2006,17 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         a.amb_p = std::nextafter((float)Mp, INFINITY); a.amb_x = std::nextafter((float)Mx, INFINITY);
         if (!(Mp < 3.0e38)) a.amb_p = INFINITY;
     }
-    const int ncell = g.G * g.G * g.G, ncello = go.G * go.G * go.G;
+    const int ncell = g.G * g.G * g.G, ncellw[2] = {gw[0].G * gw[0].G * gw[0].G, gw[1].G * gw[1].G * gw[1].G};
     w.dtab.reserve(3 * (size_t)k);
-    w.lut.reserve(((size_t)ncell + ncello) * 32);
-    w.clist.reserve((size_t)((ncell + ncello) / 64) * (1 + kCoarseMax) * 2);
+    w.lut.reserve(((size_t)ncell + ncellw[0] + ncellw[1]) * 32);
+    w.clist.reserve((size_t)((ncell + ncellw[0] + ncellw[1]) / 64) * (1 + kCoarseMax) * 2);
     w.dsort.reserve(3 * cells);
     if (w.dpos.cap < npix) { w.order_w = 0; w.order_h = 0; }
     w.dpos.reserve(npix);
     w.dsmap.reserve(cells + 32 * S + 128);
     w.dside.reserve(S + 16);
+    w.dflag.reserve(S + 64);
+    HIP_CHECK(hipMemsetAsync(w.dflag.p, 0, S + 64, s));                 // (the check writes entries 1 .. S - 1; 0 and S stay 0)
     w.hrep.reserve(1);
     HIP_CHECK(hipMemcpyAsync(w.dtab.p, wp.data(), wp.size() * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));                               // (wp is a local: the copy must have left the host)
@@ -1977,11 +2041,17 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncell / 64, 64, 0, sb, (const double *)w.dtab.p, k, g, w.clist.p, (float4 *)nullptr);
         hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncell / 64, 64, 0, sb, (const double *)w.dtab.p, k, g, l1, l2, (const unsigned char *)w.clist.p, (unsigned int *)nullptr);
     }
-    unsigned char *lo1 = w.lut.p + (size_t)ncell * 32, *lo2 = lo1 + (size_t)ncello * 16, *clo = (unsigned char *)w.clist.p + (size_t)(ncell / 64) * (1 + kCoarseMax);
     {
-        KTIME("k_nn_lut_build", sb, 32.0 * ncello);
-        hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncello / 64, 64, 0, sb, (const double *)w.dtab.p, k, go, clo, (float4 *)nullptr);
-        hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncello / 64, 64, 0, sb, (const double *)w.dtab.p, k, go, lo1, lo2, (const unsigned char *)clo, (unsigned int *)nullptr);
+        unsigned char *tp = w.lut.p + (size_t)ncell * 32, *cp = (unsigned char *)w.clist.p + (size_t)(ncell / 64) * (1 + kCoarseMax);
+        for (int lv = 0; lv < 2; lv++) {
+            unsigned char *t1 = tp, *t2 = tp + (size_t)ncellw[lv] * 16;
+            KTIME("k_nn_lut_build", sb, 32.0 * ncellw[lv]);
+            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncellw[lv] / 64, 64, 0, sb, (const double *)w.dtab.p, k, gw[lv], cp, (float4 *)nullptr);
+            hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncellw[lv] / 64, 64, 0, sb, (const double *)w.dtab.p, k, gw[lv], t1, t2, (const unsigned char *)cp, (unsigned int *)nullptr);
+            a.wide[lv].g = gw[lv]; a.wide[lv].lut = t1; a.wide[lv].lut2 = t2;
+            tp += (size_t)ncellw[lv] * 32;
+            cp += (size_t)(ncellw[lv] / 64) * (1 + kCoarseMax);
+        }
     }
     HIP_CHECK(hipEventRecord(w.ev_join, sb));
     double *sx = w.dsort.p, *sy = sx + cells, *sz = sy + cells;
@@ -2008,8 +2078,8 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     a.sx = sx; a.sy = sy; a.sz = sz;
     a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((cells + 63) & ~(size_t)63));
     a.list = w.dside.p + 1;
+    a.flag = w.dflag.p;
     a.lut = l1; a.lut2 = l2; a.g = g;
-    a.luto = lo1; a.luto2 = lo2; a.go = go;
     const size_t lds = (size_t)6 * k * sizeof(double) + (size_t)k * sizeof(float4);
     {
         KTIME("k_dither", s, 25.0 * npix);
@@ -2029,6 +2099,8 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         HIP_CHECK(hipStreamSynchronize(s));
         const unsigned nf = *w.hrep.p;
         w.dither_rounds = round + 1;
+        static const bool trace = getenv("PAMD_DITHER_TRACE") != nullptr;      // one line per verification pass on stderr
+        if (trace) fprintf(stderr, "patolette_amd: dither, lane layout: pass %zu, %u of %zu boundaries fail\n", round + 1, nf, S - 1);
         if (nf == 0) break;
         stalled = (prev_nf != 0xFFFFFFFFu && nf + std::max(1u, prev_nf / 8) >= prev_nf) ? stalled + 1 : 0;
         prev_nf = nf;
