@@ -518,6 +518,57 @@ def default_call(L, native, reps=3):
     return out
 
 
+def dither_content(L, native, side=4096, reps=3):
+    """The dither on image CONTENT other than noise (noise is the best case: the speculative runs meet the true chain soonest and the
+    queries stay inside the record grid): map-stage time of a device-resident call with dither on (ICtCp, K = 256, KMeans off) on
+    the tests' scene enlarged 2 x (smooth like a large photograph), analytic gradients with 2 % noise, without noise, and
+    posterised to 8 levels per channel (large flat areas).  Untimed extra; bit-exactness of these content classes against the
+    oracle is held by tests/test_gpu_dither_segments.py and tools/fuzz_dither_large.py at sizes the oracle does in seconds."""
+    import numpy as np
+    from tests.util import scene
+    n = side * side
+    img = L.patolette_amd_malloc(3 * n * 8)
+    dmap = L.patolette_amd_malloc(n)
+    if not img or not dmap:
+        return None
+    out = {"config": "%dx%d, K = 256, ICtCp, dither on, KMeans off; ms_map = conversions to Rec2020 + dither, device-resident" % (side, side)}
+    try:
+        opts = native.QuantizationOptions(True, False, 2, 0, 512 ** 2, False)
+        pal = np.zeros((256, 3), dtype=np.float64, order="F")
+        code = C.c_int(0)
+        y, x = np.mgrid[0:side, 0:side].astype(np.float32)
+        sm = np.stack([0.5 + 0.5 * np.sin(x / 337.0) * np.cos(y / 253.0), (x + y) / (2.0 * side), 0.5 + 0.5 * np.cos((x - y) / 571.0)]).astype(np.float64)
+        del x, y
+
+        def cases():
+            yield "noise", None
+            yield "scene_x2", np.ascontiguousarray(np.moveaxis(np.kron(scene(side // 2, side // 2, 4), np.ones((2, 2, 1))), 2, 0))
+            yield "gradients_2pct_noise", np.clip(sm + 0.02 * np.random.default_rng(3).standard_normal(sm.shape), 0, 1)
+            yield "gradients", sm
+            yield "posterised_8_levels", np.round(sm * 7) / 7
+        for name, planes in cases():
+            if planes is None:
+                assert L.patolette_amd_fill_image(img, n, 7) == 0
+            else:
+                flat = np.ascontiguousarray(planes.reshape(-1))
+                assert L.patolette_amd_memcpy_h2d(img, flat.ctypes.data_as(C.c_void_p), flat.nbytes) == 0
+                del flat
+            ms = []
+            for i in range(reps + 1):
+                L.patolette_amd_device(side, side, img, None, 256, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+                if code.value != 0:
+                    return None
+                st = native.last_stats()
+                if i:
+                    ms.append(st["ms_map"])
+            out[name] = {"ms_map": round(sorted(ms)[len(ms) // 2], 3), "ns_per_px": round(1e6 * sorted(ms)[len(ms) // 2] / n, 4), "runs": st["dither_segments"],
+                         "repairs": st["dither_repairs"], "passes": st["dither_rounds"], "through_walks": st["dither_through"]}
+    finally:
+        L.patolette_amd_free(img)
+        L.patolette_amd_free(dmap)
+    return out
+
+
 def parity_record(L, native, cfg, d_img, d_wt, pal_timed, res_all, res_one, ob):
     """The metric's second half ("palette dE vs ref"): rank 0's image 0 (seed 0) of the timed region against the CPU oracle's
     result for the SAME full-size image -- the one the cpu_baseline leg has just computed.  The palette compared is the one a
@@ -873,9 +924,10 @@ def main():
                     "time_share": round(kernels.get(dom, {"ms_per_step": 0.0})["ms_per_step"] / max(1e-9, sum(v["ms_per_step"] for v in kernels.values())), 3)}
 
     # ---- extras of the default run, all outside the timed region ----
-    ns_kernels = h2h = h2h_u8 = content = small = dflt = None
+    ns_kernels = h2h = h2h_u8 = content = small = dflt = dcontent = None
     if not args.no_extras and world == 1 and args.config == "c3":
         small = small_image(L, _native)
+        dcontent = dither_content(L, _native)
         h2h = host_to_host(L, _native, cfg)
         h2h_u8 = host_to_host_u8(L, _native, cfg)
         dflt = default_call(L, _native)
@@ -977,7 +1029,7 @@ def main():
                                     "TEST MODE --oversubscribe: %d ranks on %d device(s), gloo gather through host copies -- the N > 1 code path, not a scaling figure" % (world, L.patolette_amd_device_count())
                                     if args.oversubscribe else
                                     "RCCL gather of u8 maps (per step, asynchronous, overlapping the next step) + f64 palettes to rank 0, inside the timed region")},
-        "first_call": cold, "dither": dither_cmp, "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "small_image": small, "host_to_host": h2h, "host_to_host_u8": h2h_u8, "default_call": dflt, "content": content, "throughput_concurrent": conc,
+        "first_call": cold, "dither": dither_cmp, "parity": parity, "gather_check": gather_check, "roofline": roofline, "cpu_baseline": cpu, "north_star_kernels": ns_kernels, "small_image": small, "host_to_host": h2h, "host_to_host_u8": h2h_u8, "default_call": dflt, "dither_content": dcontent, "content": content, "throughput_concurrent": conc,
         "stages_ms_last_step": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
         "run": {k: v for k, v in stats.items() if not k.startswith("ms_")},
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
