@@ -22,8 +22,8 @@ struct NNWork {                        // scratch of the pruned NN map
     DevBuf<unsigned char> dflag;       // ... [S + 1] which boundaries the last check listed
     size_t dither_segments = 0, dither_repairs = 0, dither_rounds = 0;   // of the last launch_dither
     size_t dither_through = 0;         // ... times a stalled verification was resolved by walking one run through its successors
-    hipStream_t side_stream = nullptr; // lane-per-run dither: the record grids are built here while the pixels are gathered
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side_stream = nullptr, side_stream2 = nullptr;   // lane-per-run dither: the record grids are built here while the pixels are gathered
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     int side_dev = -1;
     NNWork() = default;
     NNWork(const NNWork &) = delete;
@@ -31,7 +31,9 @@ struct NNWork {                        // scratch of the pruned NN map
     ~NNWork() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_join2) (void)hipEventDestroy(ev_join2);
         if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (side_stream2) (void)hipStreamDestroy(side_stream2);
     }
 };
 // lo/hi: exact per-plane min/max of the colours if known (else nullptr: computed with one more pass)

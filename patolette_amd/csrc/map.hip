@@ -1956,7 +1956,10 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     size_t S = cfg.segments > 0 ? (size_t)cfg.segments : std::min<size_t>((size_t)num_cus() * 8 * 64, npix / 256);
     S = std::max<size_t>(1, std::min(std::min(S, npix / 64), (size_t)8 * 65535));    // (a tile row per 8 runs: grid.y)
     a.R.N = npix; a.R.S = (unsigned)S; a.R.Lmax = (unsigned)ceil_div(npix, S);
-    a.warm = (unsigned)std::min<size_t>(cfg.warm >= 0 ? (size_t)cfg.warm : 512, npix / S);     // (the warm-up of a run is the end of its predecessor)
+    // warm-up: 256 pixels.  With a repair pass that costs a tenth of a millisecond (one wavefront per listed run) the 2-6 % of the
+    // boundaries that 256 steps do not settle are cheaper than 256 more steps for every run (8192^2: noise 3.65 -> 3.28 ms,
+    // scene 6.0 -> 5.4, gradients + 2 % noise 5.36 -> 5.27; 384 lies between)
+    a.warm = (unsigned)std::min<size_t>(cfg.warm >= 0 ? (size_t)cfg.warm : 256, npix / S);     // (the warm-up of a run is the end of its predecessor)
     const size_t nw = ceil_div(S, 64), cells = nw * a.R.Lmax * 64;
     // the grid of the exact-pruning records: the weighted palette's bounding box, half its extent wider on every side -- error
     // diffusion pushes queries beyond the palette's hull; what still falls outside takes the full scan
@@ -2026,15 +2029,20 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     if (w.side_stream == nullptr || w.side_dev != current_device()) {
         if (w.ev_fork) { (void)hipEventDestroy(w.ev_fork); w.ev_fork = nullptr; }
         if (w.ev_join) { (void)hipEventDestroy(w.ev_join); w.ev_join = nullptr; }
+        if (w.ev_join2) { (void)hipEventDestroy(w.ev_join2); w.ev_join2 = nullptr; }
         if (w.side_stream) { (void)hipStreamDestroy(w.side_stream); w.side_stream = nullptr; }
+        if (w.side_stream2) { (void)hipStreamDestroy(w.side_stream2); w.side_stream2 = nullptr; }
         HIP_CHECK(hipStreamCreateWithFlags(&w.side_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&w.side_stream2, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&w.ev_join2, hipEventDisableTiming));
         w.side_dev = current_device();
     }
-    hipStream_t sb = w.side_stream;
+    hipStream_t sb = w.side_stream, sc = w.side_stream2;            // the first grid on one, the two wider ones on the other
     HIP_CHECK(hipEventRecord(w.ev_fork, s));
     HIP_CHECK(hipStreamWaitEvent(sb, w.ev_fork, 0));
+    HIP_CHECK(hipStreamWaitEvent(sc, w.ev_fork, 0));
     unsigned char *l1 = w.lut.p, *l2 = w.lut.p + (size_t)ncell * 16;
     {
         KTIME("k_nn_lut_build", sb, 32.0 * ncell);
@@ -2045,15 +2053,16 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         unsigned char *tp = w.lut.p + (size_t)ncell * 32, *cp = (unsigned char *)w.clist.p + (size_t)(ncell / 64) * (1 + kCoarseMax);
         for (int lv = 0; lv < 2; lv++) {
             unsigned char *t1 = tp, *t2 = tp + (size_t)ncellw[lv] * 16;
-            KTIME("k_nn_lut_build", sb, 32.0 * ncellw[lv]);
-            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncellw[lv] / 64, 64, 0, sb, (const double *)w.dtab.p, k, gw[lv], cp, (float4 *)nullptr);
-            hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncellw[lv] / 64, 64, 0, sb, (const double *)w.dtab.p, k, gw[lv], t1, t2, (const unsigned char *)cp, (unsigned int *)nullptr);
+            KTIME("k_nn_lut_build", sc, 32.0 * ncellw[lv]);
+            hipLaunchKernelGGL(k_nn_lut_coarse<unsigned char>, ncellw[lv] / 64, 64, 0, sc, (const double *)w.dtab.p, k, gw[lv], cp, (float4 *)nullptr);
+            hipLaunchKernelGGL(k_nn_lut_build<unsigned char>, ncellw[lv] / 64, 64, 0, sc, (const double *)w.dtab.p, k, gw[lv], t1, t2, (const unsigned char *)cp, (unsigned int *)nullptr);
             a.wide[lv].g = gw[lv]; a.wide[lv].lut = t1; a.wide[lv].lut2 = t2;
             tp += (size_t)ncellw[lv] * 32;
             cp += (size_t)(ncellw[lv] / 64) * (1 + kCoarseMax);
         }
     }
     HIP_CHECK(hipEventRecord(w.ev_join, sb));
+    HIP_CHECK(hipEventRecord(w.ev_join2, sc));
     double *sx = w.dsort.p, *sy = sx + cells, *sz = sy + cells;
     const dim3 tiles((unsigned)ceil_div((size_t)a.R.Lmax, 64), (unsigned)nw), tiles8((unsigned)ceil_div((size_t)a.R.Lmax, 256), (unsigned)ceil_div(S, 8));
     if (!(g_dither_order_cache && w.order_w == width && w.order_h == height && w.order_dev == current_device())) {
@@ -2075,6 +2084,7 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         }
     }
     HIP_CHECK(hipStreamWaitEvent(s, w.ev_join, 0));
+    HIP_CHECK(hipStreamWaitEvent(s, w.ev_join2, 0));
     a.sx = sx; a.sy = sy; a.sz = sz;
     a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((cells + 63) & ~(size_t)63));
     a.list = w.dside.p + 1;
