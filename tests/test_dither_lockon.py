@@ -125,3 +125,22 @@ def test_run_boundaries_of_the_segment_parallel_dither(ob, native, w, h):
         assert c.value == np.searchsorted(pos, d.value)
     lib.patolette_amd_debug_dither_locate(w, h, w * h, C.byref(d), C.byref(c))
     assert d.value == 1 << (2 * L) and c.value == w * h
+
+
+def test_the_queue_rotations_header_is_what_its_generator_writes():
+    """patolette_amd/csrc/dither_slots.h (the sixteen rotations of the lane kernel's error queue) is generated: the committed file
+    must be the generator's output, and every rotation must read the slots in the order j, j + 1, ... with the weights 0 .. 14."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_dither_slots.py")], capture_output=True, text=True, check=True).stdout
+    have = open(os.path.join(root, "patolette_amd", "csrc", "dither_slots.h")).read()
+    body = have[have.index("// ---- GENERATED"):]
+    want = gen.replace("    // ---- GENERATED", "// ---- GENERATED").replace("    // ---- end", "// ---- end")
+    assert body == want
+    for J in range(16):
+        m = re.search(r"case %d: (e0 \+= .*?) \\\n" % J, body)
+        terms = re.findall(r"e0 \+= q0_(\d+) \* wts\.w\[(\d+)\];", m.group(1))
+        assert [(int(a), int(b)) for a, b in terms] == [((J + i) & 15, i) for i in range(15)]
