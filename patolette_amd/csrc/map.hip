@@ -1828,6 +1828,11 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
     // A boundary that fails right behind another failing one is not this wavefront's: the first of such a row (its head) walks
     // through all of them, one after the other -- each starts from what its predecessor ends with, nothing to gain side by side.
     if (a.flag[b - 1]) return;                                      // (b >= 1: run 0 is never listed)
+    constexpr unsigned kHist = 2048;                                // choices remembered (a power of two)
+    unsigned char *hist = reinterpret_cast<unsigned char *>(rpos + kRing);   // [kHist] the choices of steps T - kHist .. T - 1, step s at s mod kHist
+    unsigned T = 0;                                                 // steps walked since the history was started
+    unsigned flat_from = 0;                                         // steps flat_from .. T - 1 were made on pixels of ONE colour (cflat: this lane's channel of it)
+    double cflat = 0.0;
     unsigned head = 16, count = 16;
     unsigned tail = 0;                                              // lanes 0 .. 15: the last sixteen choices made, oldest first
     bool done = false;
@@ -1853,11 +1858,22 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
         // the window of the last sixteen choices moves on by `limit`
         const unsigned moved = (unsigned)__shfl((int)tail, (lane + limit) & 63, 64), fresh = (unsigned)__shfl(res, (lane - (16 - limit)) & 63, 64);
         tail = lane < 16 - limit ? moved : fresh;
+        // the history, and how long the pixels have been of one colour
+        if (lane < limit) hist[(T + (unsigned)lane) & (kHist - 1)] = (unsigned char)res;
+        const double mine = rpx[ch * kRing + ((head + (unsigned)dph) & (kRing - 1))];
+        const bool same = T > flat_from && __all(lane >= 48 || dph >= limit || mine == cflat);
+        if (!same) {                                                 // the stretch starts again at this group's last pixel
+            cflat = rpx[ch * kRing + ((head + (unsigned)limit - 1u) & (kRing - 1))];
+            flat_from = T + (unsigned)limit - 1u;
+        }
+        T += (unsigned)limit;
         head += (unsigned)limit;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
     // the queue as the chain holds it after the sixteen pixels in ring slots head - 16 .. head - 1 with the choices `c16` (lane d
     // of every quarter: the choice of pixel d): their error vectors pushed in order into zero sums -- lane (c, d) restarts at step
-    // d, so whatever it summed before never reaches a pixel.  Afterwards the ring is re-based: head = count = 16.
+    // d, so whatever it summed before never reaches a pixel.
     auto requeue = [&](const unsigned c16) {
         const double ev = rpx[ch * kRing + ((head - 16u + (unsigned)dph) & (kRing - 1))] - prw[c16];
         acc = 0.0;
@@ -1867,10 +1883,85 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
             acc = __builtin_fma(acc, keep[j], e * wl[j]);
         }
     };
-    constexpr unsigned kMaxWalk = 64;                               // runs one wavefront walks through in a pass (the rest: next pass)
+    constexpr unsigned kMaxWalk = 64;                               // runs one wavefront WALKS through in a pass (the rest: next pass)
     bool in_row = true;                                             // still among the failing boundaries this one heads
-    for (unsigned r = b, walked = 0;; ) {
-        const unsigned len = (unsigned)(a.R.t(r + 1) - a.R.t(r));
+    bool halt = false;                                              // a jump ended at a boundary this wavefront must not cross
+    unsigned r = b, walked = 0;
+    unsigned len = 0, base = 0;                                     // run r's length; the run's position that ring slot 16 stands for
+
+    // A FLAT stretch (pixels of one colour that is not a palette entry) makes the chain periodic, out of step with whatever was
+    // speculated there: nothing is ever met, and a walk is a pixel per 0.45 us.  But once the last sixteen choices equal the
+    // sixteen P steps earlier -- all of it on pixels of the one colour -- the chain's state equals its state P steps earlier, and
+    // for as long as the colour lasts choice[s] = choice[s - P].  The walk then WRITES the pattern to the end of the stretch,
+    // across run boundaries (side records, row rules as below), and takes its queue up from there.
+    auto choice_at = [&](const unsigned step, const unsigned P) -> unsigned {     // (step >= T - kHist)
+        return (unsigned)hist[(step < T ? step : T - P + (step - T) % P) & (kHist - 1)];
+    };
+    auto find_period = [&]() -> unsigned {
+        const unsigned span = T - flat_from;                        // >= 48
+        const unsigned pmax = span - 16u < kHist - 32u ? span - 16u : kHist - 32u;
+        unsigned w4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) w4 |= (unsigned)hist[(T - 16u + (unsigned)i) & (kHist - 1)] << (8 * i);
+        for (unsigned P0 = 1; P0 <= pmax; P0 += 64) {
+            const unsigned P = P0 + (unsigned)lane;
+            bool ok = P <= pmax;
+            unsigned v4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) v4 |= (unsigned)hist[(T - 16u - P + (unsigned)i) & (kHist - 1)] << (8 * i);
+            ok = ok && v4 == w4;
+            if (__any(ok)) {
+                if (ok) for (unsigned i = 4; i < 16; i++) ok = ok && hist[(T - 16u - P + i) & (kHist - 1)] == hist[(T - 16u + i) & (kHist - 1)];
+                const unsigned long long m = __ballot(ok);
+                if (m) return P0 + (unsigned)__builtin_ctzll(m);
+            }
+        }
+        return 0u;
+    };
+    auto jump = [&](const unsigned P) {
+        unsigned step = T, p = base + head - 16u;                   // the next step's number; the run's next position
+        const unsigned s1 = (head - 1u) & (kRing - 1);
+        const double cx = rpx[s1], cy = rpx[kRing + s1], cz = rpx[2 * kRing + s1];
+        for (;;) {
+            unsigned J = len - p;                                   // positions ahead in run r of the same colour
+            bool ended = false;
+            for (unsigned q0 = p; q0 < len && !ended; q0 += 64) {
+                const unsigned q = q0 + (unsigned)lane;
+                bool ne = false;
+                if (q < len) { const size_t rr = a.R.idx(r, q); ne = !(a.sx[rr] == cx && a.sy[rr] == cy && a.sz[rr] == cz); }
+                const unsigned long long m = __ballot(ne);
+                if (m) { J = q0 - p + (unsigned)__builtin_ctzll(m); ended = true; }
+            }
+            for (unsigned m0 = 0; m0 < J; m0 += 64) {
+                const unsigned m = m0 + (unsigned)lane;
+                if (m < J) a.smap[a.R.idx(r, p + m)] = (unsigned char)choice_at(step + m, P);
+            }
+            step += J; p += J;
+            if (ended) break;                                       // the colour changes inside run r
+            // the end of run r: the rules of the walk below
+            const unsigned nr = r + 1;
+            if (nr >= a.R.S) { halt = true; break; }
+            const bool listed = a.flag[nr] != 0;
+            if (listed && !in_row) { halt = true; break; }
+            if (!listed) in_row = false;
+            if (lane < 16) a.side[16ull * nr + lane] = (unsigned short)choice_at(step - 16u + (unsigned)lane, P);
+            r = nr; p = 0;
+            len = (unsigned)(a.R.t(r + 1) - a.R.t(r));
+        }
+        // the last sixteen choices and pixels (all of the one colour: the stretch was 48 steps and more before the jump)
+        tail = choice_at(step - 16u + (unsigned)(lane & 15), P);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) { rpx[lane] = cx; rpx[kRing + lane] = cy; rpx[2 * kRing + lane] = cz; }
+        head = count = 16;
+        base = p;
+        T = 0; flat_from = 0;                                       // (the history starts again)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        requeue((unsigned)__shfl((int)tail, dph, 64));
+    };
+
+    for (;;) {
+        len = (unsigned)(a.R.t(r + 1) - a.R.t(r));
         if (r == b) {
             // the sixteen pixels before the run and the choices the map holds for them
             const unsigned lp = (unsigned)(a.R.t(r) - a.R.t(r - 1));
@@ -1893,24 +1984,43 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
             __builtin_amdgcn_wave_barrier();
             if (lane < 16) { rpx[lane] = m0; rpx[kRing + lane] = m1; rpx[2 * kRing + lane] = m2; }
             head = count = 16;
+            base = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
         done = false;
-        for (unsigned p0 = 0; p0 < len && !done; p0 += 64) {
-            const unsigned p = p0 + (unsigned)lane;
-            if (p < len) {
-                const size_t rr = a.R.idx(r, p);
-                const unsigned slot = (count + (unsigned)lane) & (kRing - 1);
-                rpx[slot] = a.sx[rr]; rpx[kRing + slot] = a.sy[rr]; rpx[2 * kRing + slot] = a.sz[rr];
-                rpos[slot] = (unsigned)rr;
+        for (;;) {
+            unsigned pl = base + (count - 16u);                     // the run's next position to fetch
+            if (pl < len) {
+                const unsigned nld = len - pl < 64u ? len - pl : 64u;
+                if ((unsigned)lane < nld) {
+                    const size_t rr = a.R.idx(r, pl + (unsigned)lane);
+                    const unsigned slot = (count + (unsigned)lane) & (kRing - 1);
+                    rpx[slot] = a.sx[rr]; rpx[kRing + slot] = a.sy[rr]; rpx[2 * kRing + slot] = a.sz[rr];
+                    rpos[slot] = (unsigned)rr;
+                }
+                count += nld;
+                pl += nld;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            count += len - p0 < 64u ? len - p0 : 64u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            while ((int)(count - head) >= 16 && !done) group(16);
+            bool jumped = false;
+            while ((int)(count - head) >= 16 && !done && !jumped) {
+                group(16);
+                // every 64 steps of a stretch: has the chain come round?
+                if (!done && T - flat_from >= 48u && ((T - flat_from) & 63u) < 16u) {
+                    const unsigned P = find_period();
+                    if (P) { jump(P); jumped = true; }
+                }
+            }
+            if (done || halt) break;
+            if (jumped) continue;                                   // (r, len, base are the jump's)
+            if (pl >= len) {
+                if (count != head) group((int)(count - head));
+                break;
+            }
         }
-        if (count != head && !done) group((int)(count - head));
+        if (halt) break;
         // run r is final for this pass.  On into the next one?
         const unsigned nr = r + 1;
         if (nr >= a.R.S) break;
@@ -1919,9 +2029,8 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
             // met what was there: the rest of run r stands.  If the next boundary stands too (or another row starts there), finished;
             // inside this row the next run was started from something else: on, from the end of run r as the map has it
             if (!(listed && in_row)) break;
-            const unsigned ln = len;
             if (lane < 16) {
-                const size_t rr = a.R.idx(r, ln - 16 + lane);
+                const size_t rr = a.R.idx(r, len - 16 + lane);
                 const unsigned sl = (head - 16u + (unsigned)lane) & (kRing - 1);
                 rpx[sl] = a.sx[rr]; rpx[kRing + sl] = a.sy[rr]; rpx[2 * kRing + sl] = a.sz[rr];
                 rpos[sl] = (unsigned)rr;
@@ -1929,6 +2038,7 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             tail = (unsigned)a.smap[rpos[(head - 16u + (unsigned)dph) & (kRing - 1)]];
+            T = 0; flat_from = 0;                                   // (steps were skipped: the history starts again)
         } else if (listed && !in_row) break;                        // the head of another row: its own wavefront's (checked again next pass)
         if (!listed) in_row = false;
         if (++walked >= kMaxWalk) break;
@@ -2119,7 +2229,7 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         KTIME("k_dither_fix", s, 0.0);
         // PAMD_DITHER_REPAIR=lanes: the listed runs 64 to a wavefront again (k_dither_lanes<1>), for comparison
         static const bool repair_lanes = getenv("PAMD_DITHER_REPAIR") && !strcmp(getenv("PAMD_DITHER_REPAIR"), "lanes");
-        const size_t lds_r = (size_t)6 * k * sizeof(double) + 3 * 128 * sizeof(double) + 128 * sizeof(unsigned);
+        const size_t lds_r = (size_t)6 * k * sizeof(double) + 3 * 128 * sizeof(double) + 128 * sizeof(unsigned) + 2048;   // + the history of choices
         if (repair_lanes) hipLaunchKernelGGL(k_dither_lanes<1>, (unsigned)ceil_div((size_t)nf, 256), 256, lds, s, a, d_pal, k, wts);
         else if (k <= 64) hipLaunchKernelGGL(k_dither_lane_repair<1>, nf, 64, lds_r, s, a, d_pal, k, wts);
         else if (k <= 128) hipLaunchKernelGGL(k_dither_lane_repair<2>, nf, 64, lds_r, s, a, d_pal, k, wts);
