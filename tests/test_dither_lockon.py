@@ -144,3 +144,32 @@ def test_the_queue_rotations_header_is_what_its_generator_writes():
         m = re.search(r"case %d: (e0 \+= .*?) \\\n" % J, body)
         terms = re.findall(r"e0 \+= q0_(\d+) \* wts\.w\[(\d+)\];", m.group(1))
         assert [(int(a), int(b)) for a, b in terms] == [((J + i) & 15, i) for i in range(15)]
+
+
+@pytest.mark.parametrize("k", [4, 16, 64, 256])
+def test_on_one_colour_a_recurrence_of_sixteen_choices_gives_the_rest_of_the_chain(ob, k):
+    """What the lane dither's walk through FLAT stretches rests on (map.hip, k_dither_lane_repair `jump`): on pixels of one colour the
+    chain's state is its last sixteen choices, so once choices[T-16:T] == choices[T-16-P:T-P] the chain repeats with period P for
+    as long as the colour lasts.  With the oracle's chain over a flat image: the first such (T, P) predicts every later choice."""
+    rng = np.random.default_rng(100 + k)
+    w = h = 128
+    n = w * h
+    order = np.asarray(ob.hilbert_order(w, h))
+    for trial in range(3):
+        pal = rng.random((k, 3))
+        c = rng.random(3)
+        flat = np.concatenate([np.full(n, c[j]) for j in range(3)])
+        seq = np.asarray(ob.dither(flat, w, h, pal))[order]
+        found = None
+        for T in range(48, 4096, 16):
+            win = seq[T - 16:T]
+            for P in range(1, T - 16 + 1):
+                if np.array_equal(seq[T - 16 - P:T - P], win):
+                    found = (T, P)
+                    break
+            if found:
+                break
+        assert found, "no recurrence within 4096 steps (k = %d)" % k
+        T, P = found
+        pred = seq[T - P + (np.arange(T, n) - T) % P]
+        assert np.array_equal(pred, seq[T:]), (k, T, P)
