@@ -1437,6 +1437,7 @@ struct DitherLanes {
     unsigned short *side;                // [S][16] the choices a run's starting queue was built from (0xFFFF = none: the run is walked again)
     unsigned *list;                      // runs whose boundary check failed; list[-1] = how many
     unsigned char *flag;                 // [S + 1] the same per run: 1 = listed by the last check
+    int solo;                            // k_dither_lane_repair: one wavefront alone, from the lowest listed boundary through everything in its way
     unsigned warm;                       // <= the shortest run
     const unsigned char *lut, *lut2;     // 16-byte records of the G^3 grid over the weighted palette, and their continuations (k_nn_lut_build)
     NNGrid g;
@@ -1765,7 +1766,17 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
     unsigned int *rpos = reinterpret_cast<unsigned int *>(rpx + 3 * kRing);   // [kRing] their places in the transposed layout
     const int lane = threadIdx.x;
     if (blockIdx.x >= a.list[-1]) return;
-    const unsigned b = a.list[blockIdx.x];
+    const bool solo = a.solo != 0;                                   // (launched as ONE block then)
+    unsigned b = a.list[blockIdx.x];
+    if (solo) {                                                      // the lowest listed boundary (the list is in no order)
+        b = 0;
+        for (unsigned q0 = 1; q0 < a.R.S && !b; q0 += 64) {
+            const unsigned q = q0 + (unsigned)threadIdx.x;
+            const unsigned long long m = __ballot(q < a.R.S && a.flag[q] != 0);
+            if (m) b = q0 + (unsigned)__builtin_ctzll(m);
+        }
+        if (!b) return;
+    }
     const double fw[3] = {(double)(float)kRw, (double)(float)kGw, (double)(float)kBw};
     for (int j = lane; j < k; j += 64)
         for (int c = 0; c < 3; c++) { const double v = pal[c * k + j]; praw[c * k + j] = v; pwt[c * k + j] = v * fw[c]; }
@@ -1825,9 +1836,13 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
             return __builtin_amdgcn_readlane(bj, wave_argmin_nonneg_f64(bd));
         }
     };
+    // solo (the passes have stalled: bands of one colour with many failing boundaries each -- every row's wavefront stops at the next
+    // row's head, which started from a tail that has just been rewritten: one row per band and pass): this wavefront alone, from the
+    // lowest failing boundary through everything in its way, rows and heads alike, until it meets what is there behind a boundary
+    // that holds.  Nobody else writes, so the rules that keep two wavefronts off one run do not apply.
     // A boundary that fails right behind another failing one is not this wavefront's: the first of such a row (its head) walks
     // through all of them, one after the other -- each starts from what its predecessor ends with, nothing to gain side by side.
-    if (a.flag[b - 1]) return;                                      // (b >= 1: run 0 is never listed)
+    if (!solo && a.flag[b - 1]) return;                             // (b >= 1: run 0 is never listed)
     constexpr unsigned kHist = 2048;                                // choices remembered (a power of two)
     unsigned char *hist = reinterpret_cast<unsigned char *>(rpos + kRing);   // [kHist] the choices of steps T - kHist .. T - 1, step s at s mod kHist
     unsigned T = 0;                                                 // steps walked since the history was started
@@ -1942,7 +1957,7 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
             const unsigned nr = r + 1;
             if (nr >= a.R.S) { halt = true; break; }
             const bool listed = a.flag[nr] != 0;
-            if (listed && !in_row) { halt = true; break; }
+            if (listed && !in_row && !solo) { halt = true; break; }
             if (!listed) in_row = false;
             if (lane < 16) a.side[16ull * nr + lane] = (unsigned short)choice_at(step - 16u + (unsigned)lane, P);
             r = nr; p = 0;
@@ -2028,7 +2043,7 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
         if (done) {
             // met what was there: the rest of run r stands.  If the next boundary stands too (or another row starts there), finished;
             // inside this row the next run was started from something else: on, from the end of run r as the map has it
-            if (!(listed && in_row)) break;
+            if (!(listed && (in_row || solo))) break;
             if (lane < 16) {
                 const size_t rr = a.R.idx(r, len - 16 + lane);
                 const unsigned sl = (head - 16u + (unsigned)lane) & (kRing - 1);
@@ -2039,9 +2054,9 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
             __builtin_amdgcn_wave_barrier();
             tail = (unsigned)a.smap[rpos[(head - 16u + (unsigned)dph) & (kRing - 1)]];
             T = 0; flat_from = 0;                                   // (steps were skipped: the history starts again)
-        } else if (listed && !in_row) break;                        // the head of another row: its own wavefront's (checked again next pass)
+        } else if (listed && !in_row && !solo) break;               // the head of another row: its own wavefront's (checked again next pass)
         if (!listed) in_row = false;
-        if (++walked >= kMaxWalk) break;
+        if (++walked >= (solo ? 65536u : kMaxWalk)) break;
         r = nr;
     }
 }
@@ -2224,16 +2239,22 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         if (nf == 0) break;
         stalled = (prev_nf != 0xFFFFFFFFu && nf + std::max(1u, prev_nf / 8) >= prev_nf) ? stalled + 1 : 0;
         prev_nf = nf;
-        if (stalled >= 2) return false;
-        w.dither_repairs += nf;
+        const bool solo = stalled >= 2;                              // no progress twice in a row: one wavefront alone, then the passes resume
+        if (solo) {
+            if (++w.dither_through > 4096) return false;            // (never seen; the wavefront layout takes the image then)
+            stalled = 0; prev_nf = 0xFFFFFFFFu;
+        }
+        a.solo = solo ? 1 : 0;
+        w.dither_repairs += solo ? 1 : nf;
         KTIME("k_dither_fix", s, 0.0);
         // PAMD_DITHER_REPAIR=lanes: the listed runs 64 to a wavefront again (k_dither_lanes<1>), for comparison
         static const bool repair_lanes = getenv("PAMD_DITHER_REPAIR") && !strcmp(getenv("PAMD_DITHER_REPAIR"), "lanes");
         const size_t lds_r = (size_t)6 * k * sizeof(double) + 3 * 128 * sizeof(double) + 128 * sizeof(unsigned) + 2048;   // + the history of choices
-        if (repair_lanes) hipLaunchKernelGGL(k_dither_lanes<1>, (unsigned)ceil_div((size_t)nf, 256), 256, lds, s, a, d_pal, k, wts);
-        else if (k <= 64) hipLaunchKernelGGL(k_dither_lane_repair<1>, nf, 64, lds_r, s, a, d_pal, k, wts);
-        else if (k <= 128) hipLaunchKernelGGL(k_dither_lane_repair<2>, nf, 64, lds_r, s, a, d_pal, k, wts);
-        else hipLaunchKernelGGL(k_dither_lane_repair<4>, nf, 64, lds_r, s, a, d_pal, k, wts);
+        const unsigned nblk = solo ? 1u : nf;
+        if (repair_lanes && !solo) hipLaunchKernelGGL(k_dither_lanes<1>, (unsigned)ceil_div((size_t)nf, 256), 256, lds, s, a, d_pal, k, wts);
+        else if (k <= 64) hipLaunchKernelGGL(k_dither_lane_repair<1>, nblk, 64, lds_r, s, a, d_pal, k, wts);
+        else if (k <= 128) hipLaunchKernelGGL(k_dither_lane_repair<2>, nblk, 64, lds_r, s, a, d_pal, k, wts);
+        else hipLaunchKernelGGL(k_dither_lane_repair<4>, nblk, 64, lds_r, s, a, d_pal, k, wts);
         HIP_CHECK(hipGetLastError());
     }
     {
