@@ -278,6 +278,42 @@ void patolette_amd_last_stats(patolette_amd__Stats *out);
  * the oracle's dither / NN map the very inputs the device stage saw. */
 size_t patolette_amd_last_map_palette(double *out, size_t capacity_rows);
 
+/* ---- what the quantisers of the last call on this thread decided (full path or patolette_amd_quantize_clusters) -----------
+ * The global quantiser's axis, covariance and cuts (quantize/global.c:388-443) and, per committed split of the greedy loop
+ * (quantize/local.c:347-390) in commit order: which row of `result` was split (`best`, :348-352), where (the bucket of
+ * get_optimal_bucket_index, :102-177), along which axis (cluster.c:191-217, with the very matrix the eigen-solver was handed),
+ * into how many members, and the distortions behind the benefit (:256-275).  On content whose decisions are ties in exact
+ * arithmetic (perfect gradients, a handful of colours) the reference's own choice hinges on the rounding of its sequential
+ * sums; tests/tie_prover.py takes this trace and the pixels and checks, in exact integer arithmetic, that every decision
+ * recorded here lies within that rounding envelope of the exact optimum.  The CPU oracle exports the same records. */
+typedef struct patolette_amd__SplitRecord {
+    int32_t row, new_row;     /* row split; row that received the LEFT child (= clusters before the commit, local.c:375-376) */
+    int32_t split;            /* bucket index of the cut */
+    int32_t degenerate;       /* the projection took sort.c:61-79's round-robin rule */
+    uint64_t n, n_left, n_right;
+    double sw;                /* sum of the cluster's weights */
+    double axis[3];
+    double cov6[6];           /* xx, yx, zx, yy, zy, zz as handed to the eigen-solver (pca.c:62-101) */
+    double dist, dist_left, dist_right, benefit;
+} patolette_amd__SplitRecord;
+typedef struct patolette_amd__SplitTrace {
+    int32_t n_base, n_clusters, n_records, stopped_early;   /* stopped_early: best benefit < 1e-16 (local.c:365-370) */
+    double gq_axis[3];
+    uint64_t gq_cuts[14];     /* n_base + 1 entries (global.c:290) */
+    double gq_cov6[6];        /* the unweighted covariance of all pixels as handed to the eigen-solver (global.c:407) */
+} patolette_amd__SplitTrace;
+/* returns the number of records; copies min(capacity, that) of them */
+size_t patolette_amd_last_split_trace(patolette_amd__SplitTrace *hdr, patolette_amd__SplitRecord *recs, size_t capacity);
+/* PALETTE_create's rows of the last call (palette/create.c:11-33: the clusters' weighted centres in the quantisation space,
+ * before any KMeans), column-major with `capacity_rows` rows when they suffice; returns the number of rows */
+size_t patolette_amd_last_cluster_centers(double *out, size_t capacity_rows);
+
+/* TESTS ONLY: make the quantisers take a deliberately WRONG decision, to show that tests/tie_prover.py tells a tie from a bug.
+ * 0 = none (default); 1 = the cut one occupied bucket past the arg-max of local.c:171; 2 = the greedy step takes the second
+ * best cluster (local.c:277-307); 3 = the cut at the LAST maximum of the objective instead of the first (a member of the tie
+ * set: differs from the reference only where the objective is exactly tied).  Process-wide; returns the previous setting. */
+int patolette_amd_debug_fault(int which);
+
 /* ---- per-kernel timing with HIP events on the launch stream ------------------------------ */
 void patolette_amd_profile_enable(int on);   /* also resets the accumulated numbers */
 /* restrict the timing to the kernel of this name (NULL or "" = every kernel): two event records per launch

@@ -29,6 +29,28 @@ class Options(C.Structure):
                 ("kmeans_niter", C.c_int), ("kmeans_max_samples", C.c_size_t), ("verbose", C.c_bool)]
 
 
+class SplitRecord(C.Structure):
+    # orc_SplitRecord (patolette_oracle.h) == patolette_amd__SplitRecord (include/patolette_amd.h)
+    _fields_ = [("row", C.c_int32), ("new_row", C.c_int32), ("split", C.c_int32), ("degenerate", C.c_int32),
+                ("n", C.c_uint64), ("n_left", C.c_uint64), ("n_right", C.c_uint64), ("sw", C.c_double),
+                ("axis", C.c_double * 3), ("cov6", C.c_double * 6), ("dist", C.c_double), ("dist_left", C.c_double),
+                ("dist_right", C.c_double), ("benefit", C.c_double)]
+
+
+class SplitTraceHeader(C.Structure):
+    _fields_ = [("n_base", C.c_int32), ("n_clusters", C.c_int32), ("n_records", C.c_int32), ("stopped_early", C.c_int32),
+                ("gq_axis", C.c_double * 3), ("gq_cuts", C.c_uint64 * 14), ("gq_cov6", C.c_double * 6)]
+
+
+def trace_to_dict(hdr, recs):
+    """ctypes header + records -> plain Python (the form tests/tie_prover.py works on)."""
+    return dict(n_base=hdr.n_base, n_clusters=hdr.n_clusters, stopped_early=bool(hdr.stopped_early),
+                gq_axis=[float(v) for v in hdr.gq_axis], gq_cov6=[float(v) for v in hdr.gq_cov6], gq_cuts=[int(v) for v in hdr.gq_cuts][:hdr.n_base + 1],
+                splits=[dict(row=r.row, new_row=r.new_row, split=r.split, degenerate=r.degenerate, n=r.n, n_left=r.n_left,
+                             n_right=r.n_right, sw=r.sw, axis=[float(v) for v in r.axis], cov6=[float(v) for v in r.cov6],
+                             dist=r.dist, dist_left=r.dist_left, dist_right=r.dist_right, benefit=r.benefit) for r in recs])
+
+
 _lib = None
 dp = C.POINTER(C.c_double)
 fp = C.POINTER(C.c_float)
@@ -81,8 +103,16 @@ def lib():
         L.orc_patolette.argtypes = [C.c_size_t, C.c_size_t, dp, dp, C.c_size_t, C.POINTER(Options),
                                     dp, zp, C.POINTER(C.c_int)]
         L.orc_patolette.restype = None
+        L.orc_patolette_from_centers.argtypes = [C.c_size_t, C.c_size_t, dp, dp, C.c_size_t, C.POINTER(Options), dp, C.c_size_t, dp, zp]
+        L.orc_patolette_from_centers.restype = None
         L.orc_exit_message.argtypes = [C.c_int]
         L.orc_exit_message.restype = C.c_char_p
+        L.orc_last_split_trace.argtypes = [C.POINTER(SplitTraceHeader), C.POINTER(SplitRecord), C.c_size_t]
+        L.orc_last_split_trace.restype = C.c_size_t
+        L.orc_set_sum_reversed.argtypes = [C.c_int]
+        L.orc_set_sum_reversed.restype = None
+        L.orc_set_fault.argtypes = [C.c_int]
+        L.orc_set_fault.restype = None
         L.orc_last_timings.argtypes = [dp]
         L.orc_last_timings.restype = None
         L.orc_set_threads.argtypes = [C.c_int]
@@ -147,6 +177,25 @@ def quantize_clusters(flat, w, n, K, want_membership=True):
                 n_base=nbase.value, split_evals=sev.value, split_px=spx.value)
 
 
+def last_split_trace():
+    """Split trace of the last quantize_clusters / patolette call (orc_last_split_trace) as a dict."""
+    hdr = SplitTraceHeader()
+    n = lib().orc_last_split_trace(C.byref(hdr), None, 0)
+    recs = (SplitRecord * max(1, n))()
+    lib().orc_last_split_trace(C.byref(hdr), recs, n)
+    return trace_to_dict(hdr, recs[:n])
+
+
+def set_sum_reversed(on):
+    """Test knob: the reference's sequential sums taken back to front (another member of its rounding-noise set)."""
+    lib().orc_set_sum_reversed(int(bool(on)))
+
+
+def set_fault(which):
+    """Test knob: 0 none; 1 wrong cut; 2 wrong greedy step; 3 last arg-max (a tie-set member)."""
+    lib().orc_set_fault(int(which))
+
+
 def kmeans_refine(flat, w, n, centers, niter, max_samples):
     """centers: (k,3). Returns refined (k,3)."""
     k = centers.shape[0]
@@ -206,6 +255,20 @@ def patolette(width, height, flat, w, K, dither=True, palette_only=False, color_
                         pal.ctypes.data_as(dp) if K > 0 else None,
                         pmap.ctypes.data_as(zp) if pmap is not None and n > 0 else None, C.byref(code))
     return code.value, pal, pmap
+
+
+def patolette_from_centers(width, height, flat, w, K, centers, dither=True, palette_only=False, color_space=2,
+                           kmeans_niter=32, kmeans_max_samples=512 ** 2):
+    """The reference's path behind the local quantiser (patolette.c:246-336) from given cluster centres ((len,3), quantisation
+    space): returns (palette (K,3) F-order, palette_map or None)."""
+    opt = Options(dither, palette_only, color_space, kmeans_niter, kmeans_max_samples, False)
+    pal = np.zeros((K, 3), dtype=np.float64, order="F")
+    n = width * height
+    pmap = None if palette_only else np.zeros(n, dtype=np.uintp)
+    cen = planar(centers)
+    lib().orc_patolette_from_centers(width, height, _d(flat), _d(w), K, C.byref(opt), _d(cen), len(centers),
+                                     pal.ctypes.data_as(dp), pmap.ctypes.data_as(zp) if pmap is not None else None)
+    return pal, pmap
 
 
 def set_threads(n):

@@ -35,6 +35,38 @@ static double now_s(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+/* ---- test knobs (tests/tie_prover.py, tests/test_tie_prover.py) -----------------------------
+ * g_sum_reversed: the reference's sequential f64 sums (matrix2D.c:200-233, pca.c:84-97, cluster.c:111-152,
+ * local.c:118-134, cells.c:82-112) taken back to front instead of front to back -- another member of the set of
+ * results that differ from the reference's only by the rounding of its sums (what an OpenBLAS dgemv kernel chosen
+ * for another CPU, or the HIP path's order-free sums, produce).  g_fault: a deliberately WRONG decision rule, to
+ * show that the prover tells a tie from a bug: 1 = the cut one bucket past the arg-max (local.c:171),
+ * 2 = the greedy step takes the SECOND best cluster (local.c:277-307), 3 = the cut at the LAST maximum of the
+ * objective instead of the first (a tie-set member: must NOT turn the prover red on its own). */
+static int g_sum_reversed = 0, g_fault = 0;
+void orc_set_sum_reversed(int on) { g_sum_reversed = on != 0; }
+void orc_set_fault(int which) { g_fault = which; }
+#define AT(ii, n) (g_sum_reversed ? (n) - 1 - (ii) : (ii))
+
+static orc_SplitTraceHeader g_trace_hdr;
+static orc_SplitRecord *g_trace = NULL;
+static size_t g_trace_len = 0, g_trace_cap = 0;
+static void trace_reset(void) { g_trace_len = 0; memset(&g_trace_hdr, 0, sizeof g_trace_hdr); }
+static orc_SplitRecord *trace_push(void) {
+    if (g_trace_len == g_trace_cap) {
+        g_trace_cap = g_trace_cap ? 2 * g_trace_cap : 256;
+        g_trace = (orc_SplitRecord *)realloc(g_trace, g_trace_cap * sizeof *g_trace);
+    }
+    orc_SplitRecord *r = &g_trace[g_trace_len++];
+    memset(r, 0, sizeof *r);
+    return r;
+}
+size_t orc_last_split_trace(orc_SplitTraceHeader *hdr, orc_SplitRecord *recs, size_t capacity) {
+    if (hdr) *hdr = g_trace_hdr;
+    if (recs) memcpy(recs, g_trace, sizeof *recs * (g_trace_len < capacity ? g_trace_len : capacity));
+    return g_trace_len;
+}
+
 /* ======================================================================================
  * Synthetic inputs
  * ==================================================================================== */
@@ -549,7 +581,8 @@ static void vector_mean(const double *c, const double *w, size_t n, double mean[
     for (int j = 0; j < 3; j++) {
         const double *col = c + (size_t)j * n;
         double acc = 0;
-        for (size_t i = 0; i < n; i++) {
+        for (size_t ii = 0; ii < n; ii++) {
+            size_t i = AT(ii, n);
             double wi = w == NULL ? 1 : w[i];
             double v = col[i] * wi;
             acc += v;
@@ -558,7 +591,7 @@ static void vector_mean(const double *c, const double *w, size_t n, double mean[
     }
     double s;
     if (w == NULL) s = 1 / (double)n;
-    else { double ws = 0; for (size_t i = 0; i < n; i++) ws += w[i]; s = 1 / ws; }
+    else { double ws = 0; for (size_t ii = 0; ii < n; ii++) ws += w[AT(ii, n)]; s = 1 / ws; }
     for (int j = 0; j < 3; j++) mean[j] *= s;
 }
 
@@ -571,13 +604,14 @@ int orc_pca_axis(const double *c, const double *w, size_t n, double axis[3], dou
         for (size_t i = 0; i < n; i++) cen[(size_t)j * n + i] = c[(size_t)j * n + i] - mean[j];
     double w_sum;
     if (w == NULL) w_sum = (double)n;
-    else { w_sum = 0; for (size_t i = 0; i < n; i++) w_sum += w[i]; }
+    else { w_sum = 0; for (size_t ii = 0; ii < n; ii++) w_sum += w[AT(ii, n)]; }
     double vcov[9];
     for (int j = 0; j < 3; j++) {
         for (int k = 0; k < 3; k++) {
             double value = 0;
             const double *cj = cen + (size_t)j * n, *ck = cen + (size_t)k * n;
-            for (size_t i = 0; i < n; i++) {
+            for (size_t ii = 0; ii < n; ii++) {
+                size_t i = AT(ii, n);
                 double wi = w == NULL ? 1 : w[i];
                 value += wi * cj[i] * ck[i];
             }
@@ -595,7 +629,9 @@ int orc_pca_axis(const double *c, const double *w, size_t n, double axis[3], dou
 /* ======================================================================================
  * Bucket sort along an axis -- quantize/sort.c:12-91
  * ==================================================================================== */
+static int g_sort_degenerate;                                /* the last orc_axis_sort took sort.c:61-79's round-robin rule */
 void orc_axis_sort(const double *c, size_t n, const double axis[3], size_t bucket_count, size_t *map) {
+    g_sort_degenerate = 0;
     const double *p0 = c, *p1 = c + n, *p2 = c + 2 * n;
     double *dots = (double *)malloc(sizeof(double) * (n ? n : 1));
     dots[0] = 0.0;                                           /* n == 0: nothing to sort, keep the reads below defined */
@@ -606,6 +642,7 @@ void orc_axis_sort(const double *c, size_t n, const double axis[3], size_t bucke
     for (size_t i = 0; i < n; i++) { if (dots[i] < min_dot) min_dot = dots[i]; }
     for (size_t i = 0; i < n; i++) { if (dots[i] > max_dot) max_dot = dots[i]; }
     if (max_dot - min_dot < ORC_DELTA) {                     /* sort.c:61-79 */
+        g_sort_degenerate = 1;
         size_t j = 0;
         for (size_t i = 0; i < n; i++) {
             map[i] = j;
@@ -636,14 +673,16 @@ typedef struct {
 static void cells_preprocess(const double *c, size_t n, const size_t *bucket_map, Cells *k) { /* cells.c:53-139 */
     memset(k, 0, sizeof *k);
     const double *p[3] = {c, c + n, c + 2 * n};
-    for (size_t i = 0; i < n; i++) {
+    for (size_t ii = 0; ii < n; ii++) {
+        size_t i = AT(ii, n);
         size_t j = bucket_map[i] + 1;
         double cx = p[0][i], cy = p[1][i], cz = p[2][i];
         k->w0[j] += 1;
         k->w1[0][j] += cx; k->w1[1][j] += cy; k->w1[2][j] += cz;
         k->w2[j] += (SQ(cx) + SQ(cy) + SQ(cz));
     }
-    for (size_t i = 0; i < n; i++) {
+    for (size_t ii = 0; ii < n; ii++) {
+        size_t i = AT(ii, n);
         size_t j = bucket_map[i] + 1;
         for (int s = 0; s < 3; s++)
             for (int r = 0; r <= s; r++) k->wrs[r][s][j] += p[r][i] * p[s][i];
@@ -771,6 +810,7 @@ typedef struct Cluster {
     int has_center; double center[3];
     double distortion; /* -1 = not computed */
     int has_axis; double axis[3];
+    double vcov[9];    /* the matrix handed to the eigen-solver (pca.c:62-101), for the split trace */
 } Cluster;
 
 static Cluster *cluster_init(const double *dataset, const double *dw, size_t N, size_t *idx, size_t n) {
@@ -810,7 +850,8 @@ static double cluster_distortion(Cluster *c) {                /* cluster.c:111-1
     const double *col = cluster_colors(c), *w = cluster_weights(c), *ctr = cluster_center(c);
     double x = ctr[0], y = ctr[1], z = ctr[2], d = 0;
     size_t n = c->n;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t ii = 0; ii < n; ii++) {
+        size_t i = AT(ii, n);
         double weight = w == NULL ? 1 : w[i];
         double cx = col[i], cy = col[n + i], cz = col[2 * n + i];
         double distance = (SQ(cx - x) + SQ(cy - y) + SQ(cz - z)) * weight;
@@ -821,7 +862,7 @@ static double cluster_distortion(Cluster *c) {                /* cluster.c:111-1
 }
 static const double *cluster_axis(Cluster *c) {               /* cluster.c:191-217 */
     if (c->has_axis) return c->axis;
-    if (orc_pca_axis(cluster_colors(c), cluster_weights(c), c->n, c->axis, NULL) != 0) return NULL;
+    if (orc_pca_axis(cluster_colors(c), cluster_weights(c), c->n, c->axis, c->vcov) != 0) return NULL;
     c->has_axis = 1;
     return c->axis;
 }
@@ -850,14 +891,19 @@ static Cluster **gq_color_clusters(const double *colors, const double *w, size_t
 
 /* global.c:388-443 */
 static Cluster **gq_quantize(const double *colors, const double *w, size_t N, size_t K, size_t *count_out) {
-    double axis[3];
-    if (orc_pca_axis(colors, NULL, N, axis, NULL) != 0) return NULL;      /* UNWEIGHTED, global.c:407 */
+    double axis[3], gq_vcov[9];
+    if (orc_pca_axis(colors, NULL, N, axis, gq_vcov) != 0) return NULL;   /* UNWEIGHTED, global.c:407 */
     size_t *bucket_map = (size_t *)malloc(sizeof(size_t) * N);
     orc_axis_sort(colors, N, axis, BUCKETS, bucket_map);
     Cells *cache = (Cells *)malloc(sizeof(Cells));
     cells_preprocess(colors, N, bucket_map, cache);
     size_t qlen = 0;
     size_t *q = gq_principal_quantizer(K, cache, &qlen);
+    trace_reset();
+    for (int j = 0; j < 3; j++) g_trace_hdr.gq_axis[j] = axis[j];
+    g_trace_hdr.gq_cov6[0] = gq_vcov[0]; g_trace_hdr.gq_cov6[1] = gq_vcov[1]; g_trace_hdr.gq_cov6[2] = gq_vcov[2];
+    g_trace_hdr.gq_cov6[3] = gq_vcov[4]; g_trace_hdr.gq_cov6[4] = gq_vcov[5]; g_trace_hdr.gq_cov6[5] = gq_vcov[8];
+    if (q) { g_trace_hdr.n_base = (int32_t)(qlen - 1); for (size_t j = 0; j < qlen && j < 14; j++) g_trace_hdr.gq_cuts[j] = q[j]; }
     Cluster **res = NULL;
     if (q) res = gq_color_clusters(colors, w, N, q, qlen, bucket_map, count_out);
     free(bucket_map); free(cache); free(q);
@@ -867,7 +913,7 @@ static Cluster **gq_quantize(const double *colors, const double *w, size_t N, si
 /* ======================================================================================
  * Local quantiser -- quantize/local.c
  * ==================================================================================== */
-typedef struct { Cluster *left, *right; } Pair;
+typedef struct { Cluster *left, *right; size_t split; int degenerate; } Pair;
 static size_t g_split_evals, g_split_px;
 
 static size_t lq_optimal_bucket(Cluster *c, const size_t *bucket_map) {     /* local.c:102-177 */
@@ -876,7 +922,8 @@ static size_t lq_optimal_bucket(Cluster *c, const size_t *bucket_map) {     /* l
     static size_t sizes[BUCKETS];
     static double sums[3][BUCKETS];
     memset(sizes, 0, sizeof sizes); memset(sums, 0, sizeof sums);
-    for (size_t i = 0; i < n; i++) {
+    for (size_t ii = 0; ii < n; ii++) {
+        size_t i = AT(ii, n);
         size_t b = bucket_map[i];
         double cx = col[i], cy = col[n + i], cz = col[2 * n + i];
         double weight = w == NULL ? 1 : w[i];
@@ -898,7 +945,12 @@ static size_t lq_optimal_bucket(Cluster *c, const size_t *bucket_map) {     /* l
             obj += v;
         }
         if (i == 0) { best = obj; loc = 0; }                 /* vector.c:26-46: first max wins */
-        else if (obj > best) { best = obj; loc = i; }
+        else if (obj > best || (g_fault == 3 && obj == best)) { best = obj; loc = i; }
+    }
+    if (g_fault == 1) {                                      /* test knob: a WRONG cut -- one more occupied bucket goes left */
+        size_t b = loc + 1;
+        while (b < BUCKETS - 1 && sizes[b] == sizes[loc]) b++;
+        if (b < BUCKETS - 1 && sizes[b] < sizes[BUCKETS - 1]) loc = b;
     }
     return loc;
 }
@@ -912,6 +964,7 @@ static Pair *lq_split_cluster(Cluster *c) {                   /* local.c:179-254
     g_split_evals++; g_split_px += n;
     size_t *bucket_map = (size_t *)malloc(sizeof(size_t) * n);
     orc_axis_sort(col, n, axis, BUCKETS, bucket_map);
+    const int degenerate = g_sort_degenerate;
     size_t split = lq_optimal_bucket(c, bucket_map);
     size_t ls = 0, rs = 0;
     for (size_t i = 0; i < n; i++) { if (bucket_map[i] <= split) ls++; else rs++; }
@@ -925,6 +978,7 @@ static Pair *lq_split_cluster(Cluster *c) {                   /* local.c:179-254
     Pair *p = (Pair *)malloc(sizeof *p);
     p->left = cluster_init(c->dataset, c->dataset_w, c->N, li, ls);
     p->right = cluster_init(c->dataset, c->dataset_w, c->N, ri, rs);
+    p->split = split; p->degenerate = degenerate;
     return p;
 }
 static double lq_split_benefit(Cluster *c, Pair *ch) {        /* local.c:256-275 */
@@ -935,7 +989,7 @@ static double lq_split_benefit(Cluster *c, Pair *ch) {        /* local.c:256-275
 
 /* local.c:318-404.  clusters[0..count) are consumed; returns array of *out_len clusters. */
 static Cluster **lq_quantize(Cluster **clusters, size_t count, size_t K, size_t *out_len) {
-    if (count >= K) { *out_len = count; return clusters; }
+    if (count >= K) { *out_len = count; g_trace_hdr.n_clusters = (int32_t)count; return clusters; }
     Cluster **result = (Cluster **)calloc(K, sizeof(Cluster *));
     memcpy(result, clusters, sizeof(Cluster *) * count);
     Pair **children = (Pair **)calloc(K, sizeof(Pair *));
@@ -947,10 +1001,30 @@ static Cluster **lq_quantize(Cluster **clusters, size_t count, size_t K, size_t 
         for (size_t j = 0; j < i; j++) benefits[j] = children[j] ? lq_split_benefit(result[j], children[j]) : 0;
         double bv = benefits[0];
         for (size_t j = 0; j < i; j++) if (benefits[j] > bv) { bv = benefits[j]; best = j; }
+        if (g_fault == 2) {                                   /* test knob: a WRONG greedy step (the second best, if it splits at all) */
+            size_t second = best; double sv = -1;
+            for (size_t j = 0; j < i; j++) if (j != best && benefits[j] > sv) { sv = benefits[j]; second = j; }
+            if (sv >= ORC_DELTA && sv < bv) best = second;
+        }
         double benefit = lq_split_benefit(result[best], children[best]);
-        if (benefit < ORC_DELTA) { len = i; break; }
+        if (benefit < ORC_DELTA) { len = i; g_trace_hdr.stopped_early = 1; break; }
         Cluster *left = children[best]->left, *right = children[best]->right;
         Cluster *old = result[best];
+        {
+            orc_SplitRecord *r = trace_push();
+            r->row = (int32_t)best; r->new_row = (int32_t)i; r->split = (int32_t)children[best]->split;
+            r->degenerate = children[best]->degenerate;
+            r->n = old->n; r->n_left = left->n; r->n_right = right->n;
+            const double *ow = cluster_weights(old);
+            double sw = 0;
+            if (ow) for (size_t t = 0; t < old->n; t++) sw += ow[t]; else sw = (double)old->n;
+            r->sw = sw;
+            for (int j = 0; j < 3; j++) r->axis[j] = old->axis[j];
+            r->cov6[0] = old->vcov[0]; r->cov6[1] = old->vcov[1]; r->cov6[2] = old->vcov[2];
+            r->cov6[3] = old->vcov[4]; r->cov6[4] = old->vcov[5]; r->cov6[5] = old->vcov[8];
+            r->dist = cluster_distortion(old); r->dist_left = cluster_distortion(left); r->dist_right = cluster_distortion(right);
+            r->benefit = benefit;
+        }
         free(children[best]); children[best] = NULL;
         result[i] = left;
         result[best] = right;
@@ -965,6 +1039,7 @@ static Cluster **lq_quantize(Cluster **clusters, size_t count, size_t K, size_t 
     free(children);
     free(clusters);
     *out_len = len;
+    g_trace_hdr.n_clusters = (int32_t)len; g_trace_hdr.n_records = (int32_t)g_trace_len;
     return result;
 }
 
@@ -1361,6 +1436,41 @@ const char *orc_exit_message(int exit_code) { return orc_messages[-1 * exit_code
 static double g_timings[6];
 void orc_last_timings(double out[6]) { memcpy(out, g_timings, sizeof g_timings); }
 
+/* patolette.c:246-336: everything behind the local quantiser -- optional KMeans, mapping or dithering with the colour-space
+ * routing, palette write-out.  colors: the image in the quantisation space (converted in place further, as the reference
+ * does); pal: planar (len,3) cluster centres, consumed. */
+static void patolette_tail(size_t width, size_t height, double *colors, const double *weights, size_t K, const orc_Options *opt,
+                           double *pal, size_t len, double *palette, size_t *palette_map) {
+    const size_t N = width * height;
+    double t = now_s();
+    if (opt->kmeans_niter > 0) orc_kmeans_refine(colors, weights, N, pal, len, opt->kmeans_niter, opt->kmeans_max_samples);
+    g_timings[3] = now_s() - t;
+
+    t = now_s();
+    if (!opt->palette_only) {
+        if (opt->dither) {
+            if (opt->color_space == ORC_CIELuv) { orc_cieluv_to_rec2020(colors, N); orc_cieluv_to_rec2020(pal, len); }
+            else if (opt->color_space == ORC_ICtCp) { orc_ictcp_to_rec2020(colors, N); orc_ictcp_to_rec2020(pal, len); }
+            else { orc_srgb_to_rec2020(colors, N); orc_srgb_to_rec2020(pal, len); }
+            orc_dither_riemersma(colors, width, height, pal, len, palette_map);
+            /* the reference also converts `colors` back to sRGB here (patolette.c:297): dead work, skipped */
+            orc_rec2020_to_srgb(pal, len);
+        } else {
+            if (opt->color_space == ORC_CIELuv) {
+                orc_cieluv_to_rec2020(colors, N); orc_cieluv_to_rec2020(pal, len);
+                orc_rec2020_to_srgb(colors, N); orc_rec2020_to_srgb(pal, len);
+                orc_srgb_to_ictcp(colors, N); orc_srgb_to_ictcp(pal, len);
+            }
+            orc_nn_map(colors, N, pal, len, palette_map);
+            orc_ictcp_to_rec2020(pal, len);
+            orc_rec2020_to_srgb(pal, len);
+        }
+    }
+    g_timings[4] = now_s() - t;
+    for (size_t j = 0; j < K * 3; j++) palette[j] = -1.0;    /* patolette.c:327-336 */
+    for (int j = 0; j < 3; j++) for (size_t i = 0; i < len; i++) palette[K * (size_t)j + i] = pal[(size_t)j * len + i];
+}
+
 void orc_patolette(size_t width, size_t height, const double *data, const double *weight_data,
                    size_t K, const orc_Options *opt, double *palette, size_t *palette_map, int *exit_code) {
     *exit_code = 0;                                           /* patolette.c:61-95 */
@@ -1392,37 +1502,27 @@ void orc_patolette(size_t width, size_t height, const double *data, const double
 
     double *pal = (double *)calloc(3 * (len ? len : 1), sizeof(double));   /* planar (len,3) */
     for (size_t i = 0; i < len; i++) { const double *c = cluster_center(cl[i]); for (int j = 0; j < 3; j++) pal[(size_t)j * len + i] = c[j]; }
-    t = now_s();
-    if (opt->kmeans_niter > 0) orc_kmeans_refine(colors, weights, N, pal, len, opt->kmeans_niter, opt->kmeans_max_samples);
-    g_timings[3] = now_s() - t;
-
-    t = now_s();
-    if (!opt->palette_only) {
-        if (opt->dither) {
-            if (opt->color_space == ORC_CIELuv) { orc_cieluv_to_rec2020(colors, N); orc_cieluv_to_rec2020(pal, len); }
-            else if (opt->color_space == ORC_ICtCp) { orc_ictcp_to_rec2020(colors, N); orc_ictcp_to_rec2020(pal, len); }
-            else { orc_srgb_to_rec2020(colors, N); orc_srgb_to_rec2020(pal, len); }
-            orc_dither_riemersma(colors, width, height, pal, len, palette_map);
-            /* the reference also converts `colors` back to sRGB here (patolette.c:297): dead work, skipped */
-            orc_rec2020_to_srgb(pal, len);
-        } else {
-            if (opt->color_space == ORC_CIELuv) {
-                orc_cieluv_to_rec2020(colors, N); orc_cieluv_to_rec2020(pal, len);
-                orc_rec2020_to_srgb(colors, N); orc_rec2020_to_srgb(pal, len);
-                orc_srgb_to_ictcp(colors, N); orc_srgb_to_ictcp(pal, len);
-            }
-            orc_nn_map(colors, N, pal, len, palette_map);
-            orc_ictcp_to_rec2020(pal, len);
-            orc_rec2020_to_srgb(pal, len);
-        }
-    }
-    g_timings[4] = now_s() - t;
-    for (size_t j = 0; j < K * 3; j++) palette[j] = -1.0;    /* patolette.c:327-336 */
-    for (int j = 0; j < 3; j++) for (size_t i = 0; i < len; i++) palette[K * (size_t)j + i] = pal[(size_t)j * len + i];
+    patolette_tail(width, height, colors, weights, K, opt, pal, len, palette, palette_map);
     for (size_t i = 0; i < len; i++) cluster_destroy(cl[i]);
     free(cl); free(pal); free(colors); free(weights);
     g_timings[5] = now_s() - t0;
     *exit_code = 0;
+}
+
+/* The reference's path from given cluster centres on (tests/tie_prover.py): `data` sRGB as for orc_patolette, `centers` planar
+ * (len,3) in the quantisation space -- what PALETTE_create (create.c:11-33) would hand to patolette.c:246.  Lets a test replay
+ * KMeans + mapping / dithering + write-out behind a clustering that differs from the oracle's only by proven ties. */
+void orc_patolette_from_centers(size_t width, size_t height, const double *data, const double *weight_data, size_t K,
+                                const orc_Options *opt, const double *centers, size_t len, double *palette, size_t *palette_map) {
+    const size_t N = width * height;
+    double *colors = (double *)malloc(sizeof(double) * 3 * N);
+    memcpy(colors, data, sizeof(double) * 3 * N);
+    if (opt->color_space == ORC_CIELuv) orc_srgb_to_cieluv(colors, N);
+    else if (opt->color_space == ORC_ICtCp) orc_srgb_to_ictcp(colors, N);
+    double *pal = (double *)malloc(sizeof(double) * 3 * (len ? len : 1));
+    memcpy(pal, centers, sizeof(double) * 3 * len);
+    patolette_tail(width, height, colors, weight_data, K, opt, pal, len, palette, palette_map);
+    free(pal); free(colors);
 }
 
 /* ======================================================================================

@@ -67,6 +67,31 @@ int orc_quantize_clusters(const double *colors, const double *weights, size_t n,
                           double *centers, size_t *n_clusters, uint32_t *cluster_of,
                           size_t *n_base, size_t *split_evals, size_t *split_px);
 
+/* ---- split trace of the last orc_quantize_clusters / orc_patolette call (tests/tie_prover.py): what the global
+ * quantiser decided and, per committed split of the greedy loop (local.c:347-390, in commit order), which cluster was
+ * split where.  The HIP path exports the same records (include/patolette_amd.h: patolette_amd_last_split_trace). */
+typedef struct {
+    int32_t row;          /* index in `result` of the cluster that was split (`best`, local.c:348-352) */
+    int32_t new_row;      /* index that received the LEFT child (= clusters before the commit, local.c:375) */
+    int32_t split;        /* bucket index of the cut (local.c:205-208) */
+    int32_t degenerate;   /* the projection took sort.c:61-79's round-robin rule */
+    uint64_t n, n_left, n_right;
+    double sw;            /* sum of the cluster's weights */
+    double axis[3];       /* principal axis incl. sign (cluster.c:191-217) */
+    double cov6[6];       /* the matrix handed to dsyev: xx, yx, zx, yy, zy, zz (pca.c:62-101) */
+    double dist, dist_left, dist_right, benefit;   /* cluster.c:111-152, local.c:256-275 */
+} orc_SplitRecord;
+typedef struct {
+    int32_t n_base, n_clusters, n_records, stopped_early;   /* stopped_early: benefit < 1e-16 (local.c:365-370) */
+    double gq_axis[3];
+    uint64_t gq_cuts[14];                                    /* n_base + 1 entries (global.c:290) */
+    double gq_cov6[6];                                       /* xx, yx, zx, yy, zy, zz handed to dsyev (global.c:407) */
+} orc_SplitTraceHeader;
+size_t orc_last_split_trace(orc_SplitTraceHeader *hdr, orc_SplitRecord *recs, size_t capacity);
+/* test knobs: see patolette_oracle.c */
+void orc_set_sum_reversed(int on);
+void orc_set_fault(int which);
+
 /* ---- KMeans refinement restating the patched faiss 1.10 path, AVX2 flavour
  * (palette/refine.c:56-221 -> faiss/Clustering.cpp:70-120,135-263,267-554,587-603,
  *  utils/distances_fused/simdlib_based.cpp:27-277, utils/random.cpp:35-51,184-194).
@@ -103,6 +128,9 @@ void orc_patolette(size_t width, size_t height, const double *data, const double
                    size_t palette_size, const orc_Options *options, double *palette,
                    size_t *palette_map, int *exit_code);
 const char *orc_exit_message(int exit_code);
+/* patolette.c:246-336 alone: KMeans, mapping / dithering, write-out behind GIVEN cluster centres (planar (len,3), quantisation space) */
+void orc_patolette_from_centers(size_t width, size_t height, const double *data, const double *weights, size_t palette_size,
+                                const orc_Options *options, const double *centers, size_t len, double *palette, size_t *palette_map);
 
 /* per-stage wall seconds of the last orc_patolette call: convert, gq, lq, kmeans, map/dither, total */
 void orc_last_timings(double out[6]);

@@ -31,6 +31,20 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class SplitRecord(C.Structure):
+    """patolette_amd__SplitRecord (include/patolette_amd.h): one committed split of the greedy loop, local.c:347-390."""
+    _fields_ = [("row", C.c_int32), ("new_row", C.c_int32), ("split", C.c_int32), ("degenerate", C.c_int32),
+                ("n", C.c_uint64), ("n_left", C.c_uint64), ("n_right", C.c_uint64), ("sw", C.c_double),
+                ("axis", C.c_double * 3), ("cov6", C.c_double * 6), ("dist", C.c_double), ("dist_left", C.c_double),
+                ("dist_right", C.c_double), ("benefit", C.c_double)]
+
+
+class SplitTrace(C.Structure):
+    """patolette_amd__SplitTrace: what the global quantiser decided (global.c:388-443) + counts."""
+    _fields_ = [("n_base", C.c_int32), ("n_clusters", C.c_int32), ("n_records", C.c_int32), ("stopped_early", C.c_int32),
+                ("gq_axis", C.c_double * 3), ("gq_cuts", C.c_uint64 * 14), ("gq_cov6", C.c_double * 6)]
+
+
 ALLREDUCE_SUM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
 
@@ -105,6 +119,9 @@ SYMBOLS = {
                                                  C.POINTER(C.c_ulonglong)]),
     "patolette_amd_last_stats": (None, [C.POINTER(Stats)]),
     "patolette_amd_last_map_palette": (C.c_size_t, [dp, C.c_size_t]),
+    "patolette_amd_last_split_trace": (C.c_size_t, [C.POINTER(SplitTrace), C.POINTER(SplitRecord), C.c_size_t]),
+    "patolette_amd_last_cluster_centers": (C.c_size_t, [dp, C.c_size_t]),
+    "patolette_amd_debug_fault": (C.c_int, [C.c_int]),
     "patolette_amd_profile_enable": (None, [C.c_int]),
     "patolette_amd_profile_only": (None, [C.c_char_p]),
     "patolette_amd_profile_sample": (None, [C.c_int]),
@@ -140,6 +157,30 @@ def last_stats():
     s = Stats()
     lib().patolette_amd_last_stats(C.byref(s))
     return s.as_dict()
+
+
+def last_split_trace():
+    """The quantisers' decisions of the last call on this thread (patolette_amd_last_split_trace) as a plain dict:
+    n_base, n_clusters, stopped_early, gq_axis, gq_cov6, gq_cuts, splits[...]."""
+    hdr = SplitTrace()
+    n = lib().patolette_amd_last_split_trace(C.byref(hdr), None, 0)
+    recs = (SplitRecord * max(1, n))()
+    lib().patolette_amd_last_split_trace(C.byref(hdr), recs, n)
+    return dict(n_base=hdr.n_base, n_clusters=hdr.n_clusters, stopped_early=bool(hdr.stopped_early),
+                gq_axis=[float(v) for v in hdr.gq_axis], gq_cov6=[float(v) for v in hdr.gq_cov6],
+                gq_cuts=[int(v) for v in hdr.gq_cuts][:hdr.n_base + 1],
+                splits=[dict(row=r.row, new_row=r.new_row, split=r.split, degenerate=r.degenerate, n=r.n, n_left=r.n_left,
+                             n_right=r.n_right, sw=r.sw, axis=[float(v) for v in r.axis], cov6=[float(v) for v in r.cov6],
+                             dist=r.dist, dist_left=r.dist_left, dist_right=r.dist_right, benefit=r.benefit) for r in recs[:n]])
+
+
+def last_cluster_centers():
+    """PALETTE_create's rows of the last call, (len, 3), in the quantisation space (before any KMeans)."""
+    import numpy as np
+    n = lib().patolette_amd_last_cluster_centers(None, 0)
+    out = np.zeros((max(1, n), 3), order="F")
+    lib().patolette_amd_last_cluster_centers(out.ctypes.data_as(dp), max(1, n))
+    return np.ascontiguousarray(out[:n])
 
 
 def profile(enable=True, only=None, sample=1):

@@ -105,14 +105,14 @@ __global__ void k_put_nodes(NodeDev *table, const NodeIn *stage, const int *ids,
     for (int j = 0; j < 3; j++) { d.axis[j] = in.axis[j]; d.mean[j] = in.mean[j]; }
     d.sw = in.sw; d.klin = in.klin; d.kquad = in.kquad;
     node_reset_outputs(d);
-    d.split = in.split;
+    d.split = in.split; d.psplit = -1;
 }
 __global__ void k_get_nodes(const NodeDev *table, NodeOut *stage, const int *ids, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const NodeDev &d = table[ids[i]];
     NodeOut o;
-    o.begin = d.begin; o.n = d.n; o.gn = d.gn; o.buf = d.buf; o.degenerate = d.degenerate; o.split = d.split; o.pad = 0;
+    o.begin = d.begin; o.n = d.n; o.gn = d.gn; o.buf = d.buf; o.degenerate = d.degenerate; o.split = d.split; o.psplit = d.psplit;
     o.sw = d.sw;
     for (int j = 0; j < 3; j++) o.mean[j] = d.mean[j];
     for (int q = 0; q < 7; q++) {                          // slot sums are exact (binned parts), any order
@@ -295,6 +295,10 @@ struct Engine {
     double ms_saliency = 0.0;
     std::string last_error;
     std::vector<double> map_palette;             // the palette as the mapping stage used it (planar (len,3)): Rec2020 / ICtCp / sRGB
+    // what the quantisers of the last call decided (patolette_amd_last_split_trace): a few hundred small records, always kept
+    patolette_amd__SplitTrace trace_hdr{};
+    std::vector<patolette_amd__SplitRecord> trace;
+    std::vector<double> cluster_centers;         // PALETTE_create's rows, planar (len,3), before any KMeans
 
     void init() {
         if (stream) return;
@@ -440,6 +444,7 @@ struct HNode {
     int buf = 0;
     double sw = 0, mean[3] = {0, 0, 0}, cov6[6] = {0, 0, 0, 0, 0, 0}, dist = 0;
     int left = -1, right = -1;
+    int psplit = -1;                         // the parent's cut as the device took it (bucket | degenerate << 16): split trace
     bool split_done = false, nosplit = false;
     // filled when the moments arrive (leaf_bound): the principal axis (dsyev semantics) and an upper bound of the benefit
     // of ANY split of the node
@@ -680,6 +685,10 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     }
     double axis[3];
     if (!node_axis(hn[0], axis)) return -1;
+    E.trace.clear();
+    E.trace_hdr = patolette_amd__SplitTrace{};
+    for (int j = 0; j < 3; j++) E.trace_hdr.gq_axis[j] = axis[j];
+    for (int q = 0; q < 6; q++) E.trace_hdr.gq_cov6[q] = hn[0].cov6[q] / hn[0].sw;
 
     // projection, 512 buckets, cell moments (sort.c, cells.c:53-139)
     {
@@ -723,6 +732,8 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     std::vector<size_t> cuts = hm::gq_principal_quantizer(K, *cm, E.h_gq.p->cut);
     if (cuts.size() < 2) return -1;
     const int kbase = (int)cuts.size() - 1;
+    E.trace_hdr.n_base = kbase;
+    for (int j = 0; j <= kbase && j < 14; j++) E.trace_hdr.gq_cuts[j] = cuts[j];
 
     // base clusters: bucket b belongs to the first cell j with b+1 <= q[j+1] (global.c:328-335)
     std::vector<unsigned char> lut(kBuckets);
@@ -824,9 +835,24 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             // first maximum among ALL entries = first maximum among the known ones iff every unknown
             // benefit (<= that node's distortion) is strictly below it
             if (max_unknown < 0 || (best >= 0 && bv > max_unknown)) {
-                if (!(bv >= kDelta)) break;                     // benefit < DELTA: stop, keep `count` clusters
+                if (g_debug_fault.load(std::memory_order_relaxed) == 2) {   // tests only: a WRONG greedy step (the second best known one)
+                    int second = -1; double sv = -1;
+                    for (size_t j = 0; j < count; j++) if ((int)j != best && fkn[j] && fval[j] > sv) { sv = fval[j]; second = (int)j; }
+                    if (second >= 0 && sv >= kDelta && sv < bv) { best = second; bv = sv; }
+                }
+                if (!(bv >= kDelta)) { E.trace_hdr.stopped_early = 1; break; }   // benefit < DELTA: stop, keep `count` clusters
                 const HNode &h = hn[result[best]];
                 const int l = h.left, r = h.right;
+                {
+                    patolette_amd__SplitRecord tr{};
+                    tr.row = best; tr.new_row = (int32_t)count;
+                    tr.split = hn[l].psplit < 0 ? -1 : (hn[l].psplit & 0xffff); tr.degenerate = hn[l].psplit < 0 ? 0 : (hn[l].psplit >> 16) & 1;
+                    tr.n = h.gn; tr.n_left = hn[l].gn; tr.n_right = hn[r].gn; tr.sw = h.sw;
+                    for (int j = 0; j < 3; j++) tr.axis[j] = h.axis[j];
+                    for (int q = 0; q < 6; q++) tr.cov6[q] = h.cov6[q] / h.sw;
+                    tr.dist = h.dist; tr.dist_left = hn[l].dist; tr.dist_right = hn[r].dist; tr.benefit = bv;
+                    E.trace.push_back(tr);
+                }
                 result[count] = l;                              // local.c:375-376: palette ORDER
                 result[best] = r;
                 refresh(count); refresh((size_t)best);
@@ -834,7 +860,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
                 if (verbose) { printf("patolette ======== Processed colors: %zu\r", count); fflush(stdout); }   // local.c:386-389
                 continue;
             }
-            if (std::max(best >= 0 ? bv : 0.0, max_unknown) < kDelta) break;   // nothing can reach DELTA
+            if (std::max(best >= 0 ? bv : 0.0, max_unknown) < kDelta) { E.trace_hdr.stopped_early = 1; break; }   // nothing can reach DELTA
             // blocked: evaluate, in ONE round, the split of every leaf of the candidate tree that could still
             // matter -- undecided frontier nodes and, speculatively, the children of decided ones (a node's
             // split depends only on its members, never on the greedy order).  Leaves whose distortion (an
@@ -953,7 +979,7 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
             for (size_t i = 0; i < cids.size(); i++) {
                 HNode &c = hn[cids[i]];
                 const NodeOut &d = got[i];
-                c.begin = d.begin; c.n = d.n; c.gn = d.gn; c.buf = d.buf; c.sw = d.sw;
+                c.begin = d.begin; c.n = d.n; c.gn = d.gn; c.buf = d.buf; c.sw = d.sw; c.psplit = d.psplit;
                 for (int j = 0; j < 3; j++) c.mean[j] = d.mean[j];
                 absorb_moments(c, d);
                 leaf_bound(c);
@@ -973,6 +999,8 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     for (size_t i = 0; i < len; i++) for (int j = 0; j < 3; j++) centers[(size_t)j * len + i] = hn[result[i]].mean[j];   // create.c:11-33
     if (max_members) { *max_members = 0; for (size_t i = 0; i < len; i++) *max_members = std::max(*max_members, hn[result[i]].gn); }
     E.stats.n_clusters = len;
+    E.trace_hdr.n_clusters = (int32_t)len; E.trace_hdr.n_records = (int32_t)E.trace.size();
+    E.cluster_centers = centers;
     E.stats.ms_lq = now_ms() - t0;
     return 0;
 }
@@ -2139,9 +2167,23 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
     PAMD_GUARD_END(-1)
 }
 
+int patolette_amd_debug_fault(int which) { return g_debug_fault.exchange(which); }
 void patolette_amd_dither_config(int segments, int warm) { dither_config(segments, warm); }
 void patolette_amd_dither_layout(int lanes) { dither_layout(lanes); }
 void patolette_amd_last_stats(patolette_amd__Stats *out) { *out = engine().stats; }
+size_t patolette_amd_last_split_trace(patolette_amd__SplitTrace *hdr, patolette_amd__SplitRecord *recs, size_t capacity) {
+    Engine &E = engine();
+    if (hdr) *hdr = E.trace_hdr;
+    if (recs) std::memcpy(recs, E.trace.data(), sizeof *recs * std::min(capacity, E.trace.size()));
+    return E.trace.size();
+}
+size_t patolette_amd_last_cluster_centers(double *out, size_t capacity_rows) {
+    Engine &E = engine();
+    const size_t len = E.cluster_centers.size() / 3;
+    if (out && len <= capacity_rows)
+        for (int j = 0; j < 3; j++) for (size_t i = 0; i < len; i++) out[(size_t)j * capacity_rows + i] = E.cluster_centers[(size_t)j * len + i];
+    return len;
+}
 size_t patolette_amd_last_map_palette(double *out, size_t capacity_rows) {
     const std::vector<double> &mp = engine().map_palette;
     const size_t len = mp.size() / 3;

@@ -1,6 +1,8 @@
 // quant.h -- device records and launchers of the cluster-split kernels (quant.hip).
 #pragma once
 
+#include <atomic>
+
 #include "common.h"
 #include "devutil.h"
 
@@ -30,7 +32,7 @@ struct NodeIn {
 // device -> host (k_get_nodes)
 struct NodeOut {
     unsigned long long begin, n, gn;
-    int buf, degenerate, split, pad;
+    int buf, degenerate, split, psplit;
     double sw, mean[3];
     double acc[7][2];                  // slot sums: 6 covariance sums (xx,yx,zx,yy,zy,zz) + distortion, 2 binned parts each
 };
@@ -53,6 +55,7 @@ struct NodeDev {
     unsigned long long minkey[kSlots], maxkey[kSlots];   // ordered keys of the projection extrema
     int degenerate;                    // max - min < 1e-16 -> round-robin buckets (sort.c:61-79)
     int split;                         // optimal bucket index (local.c:171)
+    int psplit, pad_;                  // the PARENT's cut as k_cut took it: bucket | degenerate << 16 (for the split trace; -1: a base cluster)
     unsigned long long cbegin[kMaxChildren + 1];   // children segments in the other buffer
     // ---- moments about `mean` (k_cov / k_scatter): 6 covariance sums + distortion, 2 parts each
     double acc[kSlots][7][2];
@@ -121,6 +124,7 @@ void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles
 void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
                       NodeDev *d_nodes, hipStream_t s, bool from_end = false);
 
+extern std::atomic<int> g_debug_fault;   // patolette_amd_debug_fault (tests only): 0 none, 1 wrong cut, 2 wrong greedy step, 3 last arg-max
 size_t hist_slot_doubles();            // doubles per histogram slot
 
 }  // namespace pamd

@@ -16,6 +16,8 @@
 // and the results are bit-reproducible for any launch geometry.
 #include "quant.h"
 
+#include <atomic>
+
 #include <type_traits>
 
 namespace pamd {
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(512) void k_hist_fix(QuantBuffers qb, const Tile *_
 template <bool W>
 __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restrict__ round_nodes, const double *__restrict__ hist,
                                              const unsigned long long *__restrict__ hsize, const unsigned int *__restrict__ hcount,
-                                             unsigned char *lut) {
+                                             unsigned char *lut, const int fault) {
     __shared__ double sd[4 * 16];
     __shared__ unsigned long long su[2 * 16];
     __shared__ double best_v[8];
@@ -508,13 +510,20 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         double ov = __shfl_down(bv, o, 64); int oi = __shfl_down(bi, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        if (ov > bv || (ov == bv && (fault == 3 ? oi > bi : oi < bi))) { bv = ov; bi = oi; }
     }
     if ((b & 63) == 0) { best_v[b >> 6] = bv; best_i[b >> 6] = bi; }
     __syncthreads();
     if (b == 0) {
         for (int w = 1; w < 8; w++)
-            if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
+            if (best_v[w] > bv || (best_v[w] == bv && (fault == 3 ? best_i[w] > bi : best_i[w] < bi))) { bv = best_v[w]; bi = best_i[w]; }
+        if (fault == 1) {                                       // patolette_amd_debug_fault(1): a WRONG cut -- one more occupied bucket goes left
+            unsigned long long upto = 0;
+            for (int i = 0; i <= bi; i++) upto += hcount[slot * kBuckets + i];
+            int b2 = bi + 1;
+            while (b2 < kBuckets - 1 && hcount[slot * kBuckets + b2] == 0u) b2++;
+            if (b2 < kBuckets - 1 && upto + hcount[slot * kBuckets + b2] < tots[0]) bi = b2;
+        }
         s_split = bi;
     }
     __syncthreads();
@@ -532,6 +541,7 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
             ch.buf = 1 - nd.buf;
             ch.slot = -1; ch.child0 = -1; ch.nchild = 0;
             ch.klin = nd.klin; ch.kquad = nd.kquad;
+            ch.psplit = split | (nd.degenerate ? 0x10000 : 0);
             double s0[NQ], s1[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
@@ -1220,12 +1230,15 @@ void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntile
            else launch_hist_t<false, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end); }
 }
 
+// patolette_amd_debug_fault: a deliberately wrong decision rule, for the tests that show the tie prover tells a tie from a bug
+std::atomic<int> g_debug_fault{0};
 void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int nround, const double *d_hist,
                 const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s) {
     if (!nround) return;
     KTIME("k_cut", s, (double)nround * kNQ_LQ * 2 * kBuckets * 8);
-    if (weighted) hipLaunchKernelGGL(k_cut<true>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut);
-    else hipLaunchKernelGGL(k_cut<false>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut);
+    const int fault = g_debug_fault.load(std::memory_order_relaxed);
+    if (weighted) hipLaunchKernelGGL(k_cut<true>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut, fault);
+    else hipLaunchKernelGGL(k_cut<false>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut, fault);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -31,10 +31,10 @@ def test_photograph_like_content_is_the_oracles_result(records, name):
 
 def test_posterised_content(records):
     """512 distinct colours at most (8 levels per channel): clusters of a few colours, where the reference's cut decisions hinge
-    on the rounding of its sequential f64 sums (local.c:118-134).  What holds is asserted; DESIGN.md 2 states it."""
+    on the rounding of its sequential f64 sums (local.c:118-134).  Identical, or the difference is PROVEN tie noise: every decision
+    of the HIP path's split trace within the rounding envelope of the exact optimum and the stages behind the quantisers reproduced
+    by the oracle from the HIP path's centres (tests/tie_prover.py; bench.content_parity records the proof)."""
     r = records["posterised"]
-    assert r["palette_rows"] == r["palette_rows_oracle"], r
-    if r["map_mismatches"] == 0 and r["palette_max_rel"] is not None and r["palette_max_rel"] <= 1e-9:
-        return                                                    # identical
-    # the quantised image must then still be the reference's to within the KMeans tolerance north_star states for palettes
-    assert r["quantised_image_mean_sq_diff"] <= 1e-6, r
+    if r["verdict"].startswith("identical"):
+        return
+    assert r["tie_proof"]["proven"], r
