@@ -194,6 +194,13 @@ int patolette_amd_set_invariant_sums(int on);
  * the previous setting.  Environment default: PAMD_KMEANS_UPDATE=1. */
 int patolette_amd_set_kmeans_update(int mode);
 
+/* Who drives the split loop of the local quantiser (quantize/local.c:318-404).  1 (default): the device -- one single-block kernel
+ * per round does what the host did between two rounds (the children's eigen-solves, the greedy replay of local.c:347-390, the next
+ * round's node list), the sweep kernels read their sizes from device memory, and the host synchronises once; taken for palettes of
+ * up to 256 colours on one GPU.  0: the host-driven loop everywhere (what sliced images, larger palettes and verbose calls always
+ * take).  Same decisions, same results, bit for bit.  Process-wide; returns the previous setting.  Environment: PAMD_LQ_DEVICE=0. */
+int patolette_amd_set_split_loop(int on_device);
+
 /* The KMeans subsample list (faiss rand_perm(N, seed 1234), Clustering.cpp:311-319: a pure function of the pixel count) is made
  * on a helper thread that starts at call entry and is joined when the KMeans stage begins.  1 (default): the list stays on the
  * device between calls on images of one size; 0: every call makes it again -- the cost of a FIRST call of a size, call after
@@ -212,6 +219,9 @@ int patolette_amd_subsample_indices(size_t n, size_t take, int32_t *out);
  * sign (math/pca.c:122-149 takes column 2); 0 ok.  Pure host code (no device needed). */
 int patolette_amd_eigen_sym3(const double a_colmajor[9], double w[3], double z[9]);
 int patolette_amd_principal_axis(const double cov6[6], double axis[3]);
+/* the same solver as the DEVICE runs it inside the split loop's control kernel (one problem per lane): `count` column-major 3x3
+ * matrices in, w (3 per problem), z (9 per problem) and LAPACK's info out; host buffers.  Returns 0, or -1 on a HIP error. */
+int patolette_amd_eigen_sym3_device(const double *a_colmajor, size_t count, double *w, double *z, int *info);
 /* out[i] = pow(x[i], y) as the colour conversions evaluate it on the device (x >= 0; <= 0.51 ulp) */
 int patolette_amd_pow(const double *x, double y, double *out, size_t n);
 

@@ -84,6 +84,7 @@ SYMBOLS = {
     "patolette_amd_subsample_indices": (C.c_int, [C.c_size_t, C.c_size_t, C.POINTER(C.c_int32)]),
     "patolette_amd_eigen_sym3": (C.c_int, [dp, dp, dp]),
     "patolette_amd_principal_axis": (C.c_int, [dp, dp]),
+    "patolette_amd_eigen_sym3_device": (C.c_int, [dp, C.c_size_t, dp, dp, C.POINTER(C.c_int)]),
     "patolette_amd_fill_image": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
     "patolette_amd_fill_weights": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64]),
     "patolette_amd_device": (None, [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -122,6 +123,7 @@ SYMBOLS = {
     "patolette_amd_last_split_trace": (C.c_size_t, [C.POINTER(SplitTrace), C.POINTER(SplitRecord), C.c_size_t]),
     "patolette_amd_last_cluster_centers": (C.c_size_t, [dp, C.c_size_t]),
     "patolette_amd_debug_fault": (C.c_int, [C.c_int]),
+    "patolette_amd_set_split_loop": (C.c_int, [C.c_int]),
     "patolette_amd_profile_enable": (None, [C.c_int]),
     "patolette_amd_profile_only": (None, [C.c_char_p]),
     "patolette_amd_profile_sample": (None, [C.c_int]),

@@ -37,7 +37,7 @@ constexpr double kDelta = 1e-16;     // reference: math/misc.h:5
 
 // ---- kernel timing (HIP events on the launch stream), enabled by patolette_amd_profile_enable ----
 struct KernelTimer {
-    struct Rec { hipEvent_t a, b; int id; double bytes; };
+    struct Rec { hipEvent_t a, b; int id; double bytes; const double *src; };   // src: bytes = bytes-per-unit x *src, read at collect()
     bool enabled = false;
     std::string only;                // when not empty: time just the kernel of this name
     unsigned sample_period = 1;      // ... and of that kernel every sample_period-th launch (two event records cost ~12 us)
@@ -49,7 +49,7 @@ struct KernelTimer {
     std::vector<hipEvent_t> pool;
     int id_of(const char *name);
     hipEvent_t get_event();
-    void begin(int id, hipStream_t s, double bytes);
+    void begin(int id, hipStream_t s, double bytes, const double *src = nullptr);
     void end(hipStream_t s);
     void collect();          // call after the stream is synchronised
     void reset();
@@ -59,10 +59,10 @@ KernelTimer &ktimer();
 struct ScopedKernel {
     bool on;
     hipStream_t s;
-    ScopedKernel(const char *name, hipStream_t stream, double bytes)
+    ScopedKernel(const char *name, hipStream_t stream, double bytes, const double *src = nullptr)
         : on(ktimer().enabled && (ktimer().only.empty() || ktimer().only == name)), s(stream) {
         if (on && !ktimer().only.empty() && ktimer().sample_period > 1) on = (ktimer().only_seen++ % ktimer().sample_period) == 0;
-        if (on) ktimer().begin(ktimer().id_of(name), s, bytes);
+        if (on) ktimer().begin(ktimer().id_of(name), s, bytes, src);
     }
     ~ScopedKernel() { if (on) ktimer().end(s); }
 };
@@ -70,6 +70,10 @@ struct ScopedKernel {
 #define PAMD_CAT(a, b) PAMD_CAT2(a, b)
 // bytes = ALGORITHMIC HBM bytes of the launch (DESIGN.md lists the per-unit figures)
 #define KTIME(name, stream, bytes) pamd::ScopedKernel PAMD_CAT(_ktime_scope_, __LINE__)(name, stream, (double)(bytes))
+// a launch whose extent only the device knows: `per_unit` bytes x the double at `src` (filled in by the time collect() runs);
+// src null = the plain form with `units` known on the host.  A launch that turned out empty (*src == 0) is not counted.
+#define KTIME_DYN(name, stream, per_unit, units, src) \
+    pamd::ScopedKernel PAMD_CAT(_ktime_scope_, __LINE__)(name, stream, (src) ? (double)(per_unit) : (double)(per_unit) * (double)(units), src)
 
 // ---- simple device buffer with capacity reuse ----
 template <typename T>

@@ -6,13 +6,21 @@
 //     with libm so the final sRGB palette follows the reference's own arithmetic;
 //   * the global-quantiser DP over 512 bucket moments (lib/src/quantize/global.c:99-298,
 //     cells.c:141-328) -- O(12*512^2) scalar work on 45 KB of data, not worth a launch.
-// Compiled with -ffp-contract=off; FMAs appear only where written.
+// Compiled with -ffp-contract=off; FMAs appear only where written.  The eigen-solver is __host__ __device__: the split loop's
+// device-side control kernel (pipeline.hip k_lq_control) runs the very same code, one problem per lane (IEEE f64 add / mul /
+// fma / div / sqrt are correctly rounded on gfx950 as on the host, so the eigenvector signs are the same bits).
 #pragma once
 
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
+
+#if defined(__HIPCC__)
+#define PAMD_HD __host__ __device__
+#else
+#define PAMD_HD
+#endif
 
 namespace pamd {
 namespace hm {
@@ -23,15 +31,15 @@ namespace hm {
 constexpr double kEps = 0x1.0p-53;                        // dlamch('E')
 constexpr double kSafmin = 2.2250738585072014e-308;       // dlamch('S')
 
-inline double sgn(double a, double b) { return std::copysign(std::fabs(a), b); }
-inline double lapy2(double x, double y) {
+PAMD_HD inline double sgn(double a, double b) { return std::copysign(std::fabs(a), b); }
+PAMD_HD inline double lapy2(double x, double y) {
     double xa = std::fabs(x), ya = std::fabs(y);
     double w = xa > ya ? xa : ya, z = xa > ya ? ya : xa;
     if (z == 0.0 || w > 1.79769313486231571e308) return w;
     double q = z / w;
     return w * std::sqrt(1.0 + q * q);
 }
-inline void lartg(double f, double g, double &c, double &s, double &r) {   // LAPACK >= 3.10
+PAMD_HD inline void lartg(double f, double g, double &c, double &s, double &r) {   // LAPACK >= 3.10
     const double safmax = 1.0 / kSafmin;
     const double rtmin = std::sqrt(kSafmin), rtmax = std::sqrt(safmax / 2);
     double f1 = std::fabs(f), g1 = std::fabs(g);
@@ -47,7 +55,7 @@ inline void lartg(double f, double g, double &c, double &s, double &r) {   // LA
         c = std::fabs(fs) / d; r = sgn(d, f); s = gs / r; r = r * u;
     }
 }
-inline void laev2(double a, double b, double c, double &rt1, double &rt2, double &cs1, double &sn1) {
+PAMD_HD inline void laev2(double a, double b, double c, double &rt1, double &rt2, double &cs1, double &sn1) {
     double sm = a + c, df = a - c, adf = std::fabs(df), tb = b + b, ab = std::fabs(tb);
     double acmx, acmn, rt;
     int sgn1, sgn2;
@@ -66,7 +74,7 @@ inline void laev2(double a, double b, double c, double &rt1, double &rt2, double
     if (sgn1 == sgn2) { double tn = cs1; cs1 = -sn1; sn1 = tn; }
 }
 // dlasr('R','V',F|B) on a 3-row column-major block starting at column pointer z
-inline void lasr(bool forward, int mm, const double *c, const double *s, double *z) {
+PAMD_HD inline void lasr(bool forward, int mm, const double *c, const double *s, double *z) {
     for (int t = 0; t < mm - 1; t++) {
         int j = forward ? t : (mm - 2 - t);
         double ct = c[j], st = s[j];
@@ -80,7 +88,7 @@ inline void lasr(bool forward, int mm, const double *c, const double *s, double 
     }
 }
 
-inline int steqr3(double *dd, double *ee, double *z) {
+PAMD_HD inline int steqr3(double *dd, double *ee, double *z) {
     const int n = 3;
     const double eps2 = kEps * kEps, safmax = 1.0 / kSafmin;
     const double ssfmax = std::sqrt(safmax) / 3.0, ssfmin = std::sqrt(kSafmin) / eps2;
@@ -204,7 +212,7 @@ inline int steqr3(double *dd, double *ee, double *z) {
         for (int j = ii; j <= n; j++) if (D(j) < p) { k = j; p = D(j); }
         if (k != i) {
             D(k) = D(i); D(i) = p;
-            for (int r = 0; r < 3; r++) std::swap(Z(i)[r], Z(k)[r]);
+            for (int r = 0; r < 3; r++) { const double t_ = Z(i)[r]; Z(i)[r] = Z(k)[r]; Z(k)[r] = t_; }
         }
     }
     return 0;
@@ -213,7 +221,7 @@ inline int steqr3(double *dd, double *ee, double *z) {
 // a: column-major 3x3, lower triangle read; out: w ascending, a = eigenvectors (columns).
 // The level-1/2 BLAS steps inside dsytd2/dorg2r are written with the FMAs OpenBLAS' x86-64
 // kernels contract them to (validated against OpenBLAS 0.3.28 dsyev, tests/golden/eigen_*).
-inline int eigen_sym3(double a[9], double w[3]) {
+PAMD_HD inline int eigen_sym3(double a[9], double w[3]) {
     double a11 = a[0], a21 = a[1], a31 = a[2], a22 = a[4], a32 = a[5], a33 = a[8];
     double d[3], e[2], tau = 0.0, v2 = 0.0;
     {
@@ -265,12 +273,12 @@ inline int eigen_sym3(double a[9], double w[3]) {
     z[4] = 1.0 - tau;
     int info = steqr3(d, e, z);
     w[0] = d[0]; w[1] = d[1]; w[2] = d[2];
-    std::memcpy(a, z, sizeof z);
+    for (int i = 0; i < 9; i++) a[i] = z[i];
     return info;
 }
 
 // Principal axis of a covariance given as its 6 lower-triangle entries (xx,xy,xz,yy,yz,zz).
-inline bool principal_axis(const double c6[6], double axis[3]) {
+PAMD_HD inline bool principal_axis(const double c6[6], double axis[3]) {
     double a[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
     double w[3];
     if (eigen_sym3(a, w) != 0) return false;

@@ -56,8 +56,8 @@ hipEvent_t KernelTimer::get_event() {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
 }
-void KernelTimer::begin(int id, hipStream_t s, double bytes) {
-    Rec r; r.id = id; r.bytes = bytes; r.a = get_event(); r.b = get_event();
+void KernelTimer::begin(int id, hipStream_t s, double bytes, const double *src) {
+    Rec r; r.id = id; r.bytes = bytes; r.src = src; r.a = get_event(); r.b = get_event();
     HIP_CHECK(hipEventRecord(r.a, s));
     pending.push_back(r);
 }
@@ -65,8 +65,8 @@ void KernelTimer::end(hipStream_t s) { HIP_CHECK(hipEventRecord(pending.back().b
 void KernelTimer::collect() {
     for (auto &r : pending) {
         float ms = 0;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            total_ms[r.id] += ms; total_bytes[r.id] += r.bytes; launches[r.id] += 1;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && !(r.src && *r.src == 0.0)) {
+            total_ms[r.id] += ms; total_bytes[r.id] += r.src ? r.bytes * *r.src : r.bytes; launches[r.id] += 1;
         }
         pool.push_back(r.a); pool.push_back(r.b);
     }
@@ -160,6 +160,361 @@ __global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup 
     }
     for (size_t i = tid; i < a.nhist; i += stride) a.hist[i] = 0.0;
     for (size_t i = tid; i < a.nbk; i += stride) { a.hsize[i] = 0ULL; a.hcount[i] = 0u; }
+}
+
+
+// =============================================================================================
+// The split loop driven from the DEVICE (local.c:318-404 for K <= 256 on one GPU)
+// =============================================================================================
+// The host-driven loop further down pays, per round, a stream synchronisation, the host's turn (the children's 3x3 eigen-solves,
+// the greedy replay, the next round's packet) and an upload: 30-110 us of idle GPU nine times per image -- a third of a
+// 1920x1080 call.  Here ONE single-block kernel does the host's turn: it finalises the children's moments, solves their
+// eigen-problems (hm::eigen_sym3, the very code the host runs, one problem per lane), replays the greedy loop of
+// local.c:347-390 out of LDS (one wavefront, ~0.2 us per commit), selects the next round by the same rules as the host
+// (speculation factor, R-th largest known benefit), and writes the round's node list, tile prefixes and sizes.  The sweep
+// kernels are launched with upper-bound grids and read the sizes from device memory (RoundDyn), so the host enqueues
+// control -> setup -> minmax -> hist -> cut -> count -> scan -> scatter round after round without looking, and synchronises
+// once.  How many rounds to enqueue: as many as the previous image of this size needed (noise, K = 256: 9); a surplus round is
+// eight empty launches, a deficit one more synchronisation.  Same decisions as the host loop, bit for bit (same sums, same
+// solver, same comparisons in the same order).
+constexpr int kLqDevMaxK = 256;                       // palette sizes the device-driven loop takes (LDS: ~13 bytes per node)
+constexpr int kLqNodeCap = 16 * kLqDevMaxK + 256;     // candidate-tree nodes; beyond it the call starts over on the host-driven loop
+constexpr int kLqRoundCap = 512;                      // nodes evaluated per round (more candidates wait for the next one)
+constexpr int kLqMaxRounds = 96;
+
+struct LqCtl {                                        // device memory
+    int K, count, nnodes, nleaves, done, error, stopped_early, rounds;
+    int ncids, ntrace, pad0, pad1;
+    RoundDyn dyn;
+    unsigned long long split_evals, split_px;
+    int result[kLqDevMaxK];
+    int leaves[kLqNodeCap];
+    int round_ids[kLqRoundCap];
+    int cids[2 * kLqRoundCap];
+    int tA0[kLqRoundCap + 1], tP0[kLqRoundCap + 1];
+    double nval[kLqNodeCap];                          // per node: its split's benefit once known, else the bound `ub`
+    int nleft[kLqNodeCap];                            // left child (right = +1) once the node is in a round, else -1
+    unsigned char nkn[kLqNodeCap];                    // known: never splits (one member, solver failed) or its split is evaluated
+};
+struct LqOut {                                        // pinned host memory, written by the control kernel
+    int done, error, count, rounds, stopped_early, ntrace;
+    unsigned long long split_evals, split_px, max_members;
+    double round_px[kLqMaxRounds], round_nr[kLqMaxRounds];
+    double centers[3 * kLqDevMaxK];
+    patolette_amd__SplitRecord trace[kLqDevMaxK];
+};
+
+__global__ void k_lq_init(LqCtl *c, int K, int kbase, int first_base, int nnodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        c->K = K; c->count = kbase; c->nnodes = nnodes; c->nleaves = 0; c->done = 0; c->error = 0; c->stopped_early = 0; c->rounds = 0;
+        c->ncids = kbase; c->ntrace = 0; c->dyn = RoundDyn{0, 0, 0, 0}; c->split_evals = 0ULL; c->split_px = 0ULL;
+    }
+    if (i < kbase) { c->result[i] = first_base + i; c->cids[i] = first_base + i; }
+}
+
+__device__ __forceinline__ int block_excl_scan_256(const int v, int *sw /* [5] */, int &total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int inc = (int)wave_scan_incl_u32((unsigned)v);
+    __syncthreads();                                   // sw may still be read from the previous scan
+    if (lane == 63) sw[wid] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wid; w++) base += sw[w];
+    total = sw[0] + sw[1] + sw[2] + sw[3];
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_lq_control(NodeDev *nodes, LqCtl *c, LqOut *out, const double spec_beta, const int eigen_bound,
+                                                    const int fault) {
+    if (c->done) return;
+    extern __shared__ unsigned char lq_lds[];
+    double *s_val = (double *)lq_lds;                              // [kLqNodeCap]
+    double *s_tmp = s_val + kLqNodeCap;                            // [kLqDevMaxK]
+    int *s_left = (int *)(s_tmp + kLqDevMaxK);                     // [kLqNodeCap]
+    volatile int *f_res = s_left + kLqNodeCap;                     // [kLqDevMaxK] the frontier in the reference's order (`result`)
+    volatile int *s_commit = f_res + kLqDevMaxK;                   // [3 * kLqDevMaxK] (row, node, new_row) of this call's commits
+    unsigned char *s_kn = (unsigned char *)(s_commit + 3 * kLqDevMaxK);   // [kLqNodeCap]
+    __shared__ int sw[5];
+    __shared__ int s_count, s_nc, s_mode, s_best, s_stopped, s_nmarked, s_kth_set;
+    __shared__ double s_bv, s_mu, s_kth;
+    __shared__ unsigned long long s_maxgn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int K = c->K;
+
+    // ---- A. the last round's children (the first call: the base clusters): moments, principal axis, bound (leaf_bound)
+    const int ncids = c->ncids;
+    for (int i = tid; i < ncids; i += 256) {
+        const int id = c->cids[i];
+        NodeDev &d = nodes[id];
+        double cov[7];
+        for (int q = 0; q < 7; q++) {                               // slot sums are exact (binned parts), any order
+            double a0 = 0, a1 = 0;
+            for (int k = 0; k < kSlots; k++) { a0 += d.acc[k][q][0]; a1 += d.acc[k][q][1]; }
+            cov[q] = a0 + a1;
+        }
+        for (int q = 0; q < 6; q++) d.cov6[q] = cov[q];
+        d.dist = cov[6];
+        double ub = cov[6];
+        int st = 0;
+        const bool single = d.gn <= 1ULL;
+        if (single || !(d.sw > 0)) { ub = 0; st = single ? 0 : -1; }
+        else {
+            double c6[6];
+            for (int q = 0; q < 6; q++) c6[q] = cov[q] / d.sw;
+            double a[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+            double w[3];
+            if (hm::eigen_sym3(a, w) != 0) st = -1;
+            else {
+                d.axis[0] = a[6]; d.axis[1] = a[7]; d.axis[2] = a[8]; st = 1;
+                if (eigen_bound) {
+                    const double b = w[2] * d.sw * (1.0 + 1e-9) + 1e-9 * cov[6];
+                    if (b == b && b < ub) ub = b;
+                }
+            }
+        }
+        d.ub = ub; d.axis_state = st;
+        c->nval[id] = single ? 0.0 : ub; c->nkn[id] = single ? 1 : 0; c->nleft[id] = -1;
+        c->leaves[c->nleaves + i] = id;
+    }
+    __syncthreads();
+    // the nodes of that round are split now: benefit = distortion minus the children's (local.c:256-275)
+    const int nr_prev = c->dyn.nr;
+    for (int i = tid; i < nr_prev; i += 256) {
+        const int id = c->round_ids[i];
+        const NodeDev &d = nodes[id];
+        const int l = d.child0;
+        c->nval[id] = d.dist - (nodes[l].dist + nodes[l + 1].dist);
+        c->nkn[id] = 1;
+    }
+    __syncthreads();
+    int nleaves = c->nleaves + ncids;
+    const int nn = c->nnodes;
+    for (int i = tid; i < nn; i += 256) { s_val[i] = c->nval[i]; s_left[i] = c->nleft[i]; s_kn[i] = c->nkn[i]; }
+    for (int i = tid; i < c->count; i += 256) f_res[i] = c->result[i];
+    if (tid == 0) { s_count = c->count; s_nc = 0; s_stopped = 0; s_maxgn = 0ULL; }
+    __syncthreads();
+
+    int nr = 0;
+    bool finished = false;
+    for (;;) {
+        // ---- B. greedy steps (local.c:347-390), exact while every undecided node is provably not the arg-max; one wavefront, out of LDS
+        if (tid < 64) {
+            int count = s_count, nc = s_nc, mode = 0, best = -1;
+            double bv = 0, mu = -1;
+            for (;;) {
+                if (count >= K) { mode = 1; break; }
+                bv = 0; best = -1; mu = -1;
+                for (int j = lane; j < count; j += 64) {
+                    const int id = f_res[j];
+                    const double v = s_val[id];
+                    if (s_kn[id]) { if (best < 0 || v > bv) { bv = v; best = j; } }
+                    else if (v > mu) mu = v;
+                }
+                for (int o = 32; o > 0; o >>= 1) {                  // first maximum among the known (vector.c:26-46), largest bound among the unknown
+                    const double obv = __shfl_xor(bv, o, 64), omu = __shfl_xor(mu, o, 64);
+                    const int ob = __shfl_xor(best, o, 64);
+                    if (ob >= 0 && (best < 0 || obv > bv || (obv == bv && ob < best))) { bv = obv; best = ob; }
+                    if (omu > mu) mu = omu;
+                }
+                if (mu < 0 || (best >= 0 && bv > mu)) {
+                    if (fault == 2) {                               // patolette_amd_debug_fault(2): a WRONG step, the second best known one
+                        double sv = -1; int second = -1;
+                        for (int j = lane; j < count; j += 64) {
+                            const int id = f_res[j];
+                            if (j != best && s_kn[id] && s_val[id] > sv) { sv = s_val[id]; second = j; }
+                        }
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const double osv = __shfl_xor(sv, o, 64); const int os = __shfl_xor(second, o, 64);
+                            if (os >= 0 && (second < 0 || osv > sv || (osv == sv && os < second))) { sv = osv; second = os; }
+                        }
+                        if (second >= 0 && sv >= kDelta && sv < bv) { best = second; bv = sv; }
+                    }
+                    if (!(bv >= kDelta)) { s_stopped = 1; mode = 1; break; }      // benefit < DELTA: stop (local.c:365-370)
+                    const int id = f_res[best], l = s_left[id];
+                    if (lane == 0) {
+                        s_commit[3 * nc] = best; s_commit[3 * nc + 1] = id; s_commit[3 * nc + 2] = count;
+                        f_res[count] = l; f_res[best] = l + 1;      // local.c:375-376: palette ORDER
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    nc++; count++;
+                    continue;
+                }
+                if (fmax(best >= 0 ? bv : 0.0, mu) < kDelta) { s_stopped = 1; mode = 1; break; }   // nothing can reach DELTA
+                mode = 2;                                           // blocked: a round
+                break;
+            }
+            if (lane == 0) { s_count = count; s_nc = nc; s_mode = mode; s_best = best; s_bv = bv; s_mu = mu; s_nmarked = 0; s_kth_set = 0; }
+        }
+        __syncthreads();
+        if (s_mode == 1) { finished = true; break; }
+        // ---- C. which leaves of the candidate tree to evaluate: those whose bound reaches a quarter of the best candidate, and at
+        // least the R-th largest KNOWN benefit when R commits are left (the host loop's rules, quantize_clusters below)
+        const int count = s_count;
+        const double ref_b = fmax(s_best >= 0 ? s_bv : 0.0, s_mu);
+        double thr = fmax(kDelta, spec_beta * ref_b);
+        {
+            const int R = K - count;
+            double v = -INFINITY; int kn = 0;
+            if (tid < count) { const int id = f_res[tid]; kn = s_kn[id]; v = s_val[id]; }
+            s_tmp[tid] = kn ? v : -INFINITY;
+            int total;
+            (void)block_excl_scan_256(kn, sw, total);
+            if (total >= R && R > 0) {
+                if (kn) {
+                    int rank = 0;
+                    for (int u = 0; u < count; u++) { const double o = s_tmp[u]; rank += (o > v || (o == v && u < tid)) ? 1 : 0; }
+                    if (rank == R - 1) { s_kth = v; s_kth_set = 1; }
+                }
+                __syncthreads();
+                if (s_kth_set) thr = fmax(thr, s_kth * (1.0 - 1e-9));
+            }
+        }
+        int nkeep = 0;
+        nr = 0;
+        for (int base = 0; base < nleaves; base += 256) {
+            const int i = base + tid;
+            int id = -1, sel = 0, keep = 0;
+            if (i < nleaves) {
+                id = c->leaves[i];
+                if (!s_kn[id]) {
+                    if (s_val[id] >= thr) {
+                        if (nodes[id].axis_state < 0) { s_kn[id] = 1; s_val[id] = 0.0; c->nkn[id] = 1; c->nval[id] = 0.0; atomicAdd(&s_nmarked, 1); }   // the solver failed: never splits
+                        else sel = 1;
+                    } else keep = 1;
+                }
+            }
+            int tsel, tkeep;
+            const int psel = block_excl_scan_256(sel, sw, tsel);
+            const int pkeep = block_excl_scan_256(keep, sw, tkeep);
+            if (sel && nr + psel >= kLqRoundCap) { sel = 0; keep = 2; }          // the round is full: wait for the next one
+            int tkeep2;
+            const int pk2 = block_excl_scan_256(keep == 2 ? 1 : 0, sw, tkeep2);
+            if (sel) c->round_ids[nr + psel] = id;
+            if (keep == 1) c->leaves[nkeep + pkeep] = id;
+            __syncthreads();
+            if (keep == 2) c->leaves[nkeep + tkeep + pk2] = id;
+            nr = min(nr + tsel, kLqRoundCap);
+            nkeep += tkeep + tkeep2;
+            __syncthreads();
+        }
+        nleaves = nkeep;
+        if (nr > 0) break;
+        if (s_nmarked == 0) { if (tid == 0) c->error = 1; finished = true; break; }   // blocked without candidates
+        __syncthreads();
+    }
+
+    // ---- D. this call's commits -> the split trace (patolette_amd_last_split_trace), the frontier -> device memory
+    const int count = s_count, nc = s_nc, ntrace0 = c->ntrace;
+    for (int t = tid; t < nc; t += 256) {
+        const int row = s_commit[3 * t], id = s_commit[3 * t + 1], l = s_left[id];
+        const NodeDev &h = nodes[id], &hl = nodes[l], &hr = nodes[l + 1];
+        patolette_amd__SplitRecord tr;
+        tr.row = row; tr.new_row = s_commit[3 * t + 2];
+        tr.split = hl.psplit < 0 ? -1 : (hl.psplit & 0xffff); tr.degenerate = hl.psplit < 0 ? 0 : (hl.psplit >> 16) & 1;
+        tr.n = h.gn; tr.n_left = hl.gn; tr.n_right = hr.gn; tr.sw = h.sw;
+        for (int j = 0; j < 3; j++) tr.axis[j] = h.axis[j];
+        for (int q = 0; q < 6; q++) tr.cov6[q] = h.cov6[q] / h.sw;
+        tr.dist = h.dist; tr.dist_left = hl.dist; tr.dist_right = hr.dist; tr.benefit = h.dist - (hl.dist + hr.dist);
+        if (ntrace0 + t < kLqDevMaxK) out->trace[ntrace0 + t] = tr;
+    }
+    for (int i = tid; i < count; i += 256) c->result[i] = f_res[i];
+
+    if (finished) {
+        unsigned long long mg = 0ULL;
+        for (int i = tid; i < count; i += 256) {
+            const NodeDev &d = nodes[f_res[i]];
+            for (int j = 0; j < 3; j++) out->centers[(size_t)j * count + i] = d.mean[j];      // create.c:11-33
+            mg = d.gn > mg ? d.gn : mg;
+        }
+        atomicMax(&s_maxgn, mg);
+        __syncthreads();
+        if (tid == 0) {
+            c->done = 1; c->count = count; c->ntrace = ntrace0 + nc; c->nleaves = nleaves; c->ncids = 0; c->dyn = RoundDyn{0, 0, 0, 0};
+            out->count = count; out->rounds = c->rounds; out->stopped_early = s_stopped; out->ntrace = ntrace0 + nc; out->error = c->error;
+            out->split_evals = c->split_evals; out->split_px = c->split_px; out->max_members = s_maxgn;
+            __threadfence_system();
+            out->done = 1;
+        }
+        return;
+    }
+
+    // ---- E. the round: slots, children ids, tile prefixes of both tilings (what the host's packet carried)
+    if (nn + 2 * nr > kLqNodeCap) {                                // the candidate tree outgrew the table: the host-driven loop takes the call over
+        if (tid == 0) { c->done = 1; c->error = 2; c->dyn = RoundDyn{0, 0, 0, 0}; out->error = 2; __threadfence_system(); out->done = 1; }
+        return;
+    }
+    int runA = 0, runP = 0;
+    unsigned long long rpx = 0ULL;
+    for (int base = 0; base < nr; base += 256) {
+        const int r = base + tid;
+        int ta = 0, tp = 0;
+        unsigned long long n = 0ULL;
+        if (r < nr) {
+            const int id = c->round_ids[r];
+            NodeDev &d = nodes[id];
+            d.slot = r; d.child0 = nn + 2 * r; d.nchild = 2;
+            c->nleft[id] = nn + 2 * r;
+            c->cids[2 * r] = nn + 2 * r; c->cids[2 * r + 1] = nn + 2 * r + 1;
+            n = d.n;
+            ta = (int)((n + kTileA - 1) / kTileA); tp = (int)((n + kTileP - 1) / kTileP);
+        }
+        int totA, totP;
+        const int pa = block_excl_scan_256(ta, sw, totA);
+        const int pp = block_excl_scan_256(tp, sw, totP);
+        if (r < nr) { c->tA0[r] = runA + pa; c->tP0[r] = runP + pp; }
+        runA += totA; runP += totP;
+        // pixels of the round (a statistic): wave sums into one LDS word
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+        if (lane == 0 && n) atomicAdd(&s_maxgn, n);
+    }
+    __syncthreads();
+    rpx = s_maxgn;
+    if (tid == 0) {
+        const int round = c->rounds;
+        c->tA0[nr] = runA; c->tP0[nr] = runP;
+        c->count = count; c->ntrace = ntrace0 + nc; c->nleaves = nleaves; c->ncids = 2 * nr; c->nnodes = nn + 2 * nr;
+        c->dyn = RoundDyn{nr, runA, runP, 0};
+        c->split_evals += (unsigned long long)nr; c->split_px += rpx; c->rounds = round + 1;
+        if (round < kLqMaxRounds) { out->round_px[round] = (double)rpx; out->round_nr[round] = (double)nr; }
+    }
+}
+
+// what k_round_setup does from the host's packet, from the control kernel's lists: cleared outputs of the round's nodes, both tile
+// lists, zeroed histograms
+__global__ __launch_bounds__(256) void k_round_setup_dyn(NodeDev *table, const LqCtl *c, Tile *tilesA, Tile *tilesP, double *hist,
+                                                         unsigned long long *hsize, unsigned int *hcount, const size_t lqs) {
+    const int nr = c->dyn.nr;
+    if (nr == 0) return;
+    const int ntA = c->dyn.ntA, ntP = c->dyn.ntP;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < (size_t)nr * kNodeResetElems; i += stride)
+        node_reset_element(table[c->round_ids[i / kNodeResetElems]], (int)(i % kNodeResetElems));
+    for (size_t t = tid; t < (size_t)ntA; t += stride) {
+        const int r = node_of_tile(c->tA0, nr, (int)t);
+        const NodeDev &d = table[c->round_ids[r]];
+        const unsigned long long o = (unsigned long long)((int)t - c->tA0[r]) * kTileA, n = d.n;
+        tilesA[t] = Tile{d.begin + o, (unsigned)(n - o < (unsigned long long)kTileA ? n - o : kTileA), (unsigned)c->round_ids[r]};
+    }
+    for (size_t t = tid; t < (size_t)ntP; t += stride) {
+        const int r = node_of_tile(c->tP0, nr, (int)t);
+        const NodeDev &d = table[c->round_ids[r]];
+        const unsigned long long o = (unsigned long long)((int)t - c->tP0[r]) * kTileP, n = d.n;
+        tilesP[t] = Tile{d.begin + o, (unsigned)(n - o < (unsigned long long)kTileP ? n - o : kTileP), (unsigned)c->round_ids[r]};
+    }
+    for (size_t i = tid; i < lqs * (size_t)nr; i += stride) hist[i] = 0.0;
+    for (size_t i = tid; i < (size_t)nr * kBuckets; i += stride) { hsize[i] = 0ULL; hcount[i] = 0u; }
+}
+
+// the eigen-solver as the control kernel runs it, for the golden test (patolette_amd_eigen_sym3_device)
+__global__ void k_eigen_batch(const double *a9, size_t count, double *w3, double *z9, int *info) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double a[9], w[3];
+    for (int j = 0; j < 9; j++) a[j] = a9[i * 9 + j];
+    info[i] = hm::eigen_sym3(a, w);
+    for (int j = 0; j < 3; j++) w3[i * 3 + j] = w[j];
+    for (int j = 0; j < 9; j++) z9[i * 9 + j] = a[j];
 }
 
 // ---- one image over several GPUs (patolette_amd_slice): the node table's reductions, packed for ONE collective ----
@@ -281,6 +636,9 @@ struct Engine {
     DevBuf<double> wsal;
     DevBuf<GqDpDev> gq;
     PinBuf<GqDpDev> h_gq;
+    DevBuf<LqCtl> lqctl;                  // the device-driven split loop's state and what its control kernel reports (pinned)
+    PinBuf<LqOut> h_lqout;
+    size_t lq_hint_N = 0, lq_hint_K = 0; int lq_hint_rounds = 0;   // rounds the last image of this size and palette needed
     // KMeans subsample list = a prefix of rand_perm(N, seed 1234) (Clustering.cpp:311-319): a pure function of N, and the list
     // for FEWER samples is a prefix of the list for more.  perm_dev holds the first perm_nx entries for an image of perm_N pixels;
     // h_perm (pinned) the first hperm_nx for hperm_N, written by a helper thread (perm_job) that starts at call entry and is
@@ -606,8 +964,77 @@ static void gq_prepare(Engine &E, size_t N, bool weighted) {
     E.prep_N = N; E.prep_planes = planes;
 }
 
-static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const Bounds &bnd,
-                             std::vector<double> &centers, size_t &len, bool verbose = false, unsigned long long *max_members = nullptr) {
+
+// patolette_amd_set_split_loop: 1 (default) the device-driven loop where it applies, 0 the host-driven one everywhere
+std::atomic<int> g_lq_device{(getenv("PAMD_LQ_DEVICE") && atoi(getenv("PAMD_LQ_DEVICE")) == 0) ? 0 : 1};
+
+// The local quantiser driven from the device (k_lq_control above).  In: the base clusters are nodes first_base .. first_base + kbase - 1
+// of the table with their segments, means and moment accumulators complete on the stream (no synchronisation yet).  Returns 0 (centres,
+// trace, stats filled in), -1 on failure, -2 if the candidate tree outgrew the device's table (the caller starts over on the host loop).
+static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv_sums, const QuantBuffers &qlq, int kbase, int first_base,
+                          int nnodes, bool snake, std::vector<double> &centers, size_t &len, unsigned long long *max_members) {
+    hipStream_t s = E.stream;
+    static const double spec_beta = getenv("PAMD_SPEC_BETA") ? atof(getenv("PAMD_SPEC_BETA")) : 0.25;
+    const size_t lqs = (size_t)kNQ_LQ * 2 * kBuckets;
+    const int ntA_ub = (int)ceil_div(N, (size_t)kTileA) + kLqRoundCap, ntP_ub = (int)ceil_div(N, (size_t)kTileP) + kLqRoundCap;
+    E.lqctl.reserve(1); E.h_lqout.reserve(1);
+    E.hist.reserve(std::max(hist_slot_doubles(), lqs * kLqRoundCap)); E.hsize.reserve((size_t)kLqRoundCap * kBuckets);
+    E.hcount.reserve((size_t)kLqRoundCap * kBuckets); E.lut.reserve((size_t)kLqRoundCap * kBuckets);
+    E.tilesA.reserve(ntA_ub); E.tilesP.reserve(ntP_ub);
+    E.tilecnt.reserve((size_t)ntP_ub * kMaxChildren); E.tileoff.reserve((size_t)ntP_ub * kMaxChildren);
+    LqCtl *c = E.lqctl.p;
+    LqOut *out = E.h_lqout.p;
+    out->done = 0; out->error = 0; out->count = 0; out->rounds = 0; out->ntrace = 0;
+    for (int r = 0; r < kLqMaxRounds; r++) { out->round_px[r] = 0.0; out->round_nr[r] = 0.0; }
+    hipLaunchKernelGGL(k_lq_init, (kbase + 63) / 64, 64, 0, s, c, (int)K, kbase, first_base, nnodes);
+    HIP_CHECK(hipGetLastError());
+    constexpr size_t ctl_lds = (size_t)kLqNodeCap * (8 + 4 + 1) + (size_t)kLqDevMaxK * (8 + 4 + 12);
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) HIP_CHECK(hipFuncSetAttribute((const void *)k_lq_control, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctl_lds));
+    const int eigen_bound = (kUseEigenBound && g_lq_eigen_bound) ? 1 : 0;
+    const RoundDyn *dyn = &c->dyn;
+    const int *d_round = c->round_ids, *d_tP0 = c->tP0;
+    auto control = [&]() {
+        KTIME("k_lq_control", s, 0.0);
+        hipLaunchKernelGGL(k_lq_control, 1, 256, ctl_lds, s, E.nodes.p, c, out, spec_beta, eigen_bound, g_debug_fault.load(std::memory_order_relaxed));
+        HIP_CHECK(hipGetLastError());
+    };
+    int enq = 0;                                                   // rounds enqueued so far
+    auto round = [&]() {
+        if (enq >= kLqMaxRounds) throw HipError("patolette_amd: split loop exceeded its round limit");
+        const double *px_src = &out->round_px[enq], *nr_src = &out->round_nr[enq];
+        hipLaunchKernelGGL(k_round_setup_dyn, 1024, 256, 0, s, E.nodes.p, (const LqCtl *)c, E.tilesA.p, E.tilesP.p, E.hist.p, E.hsize.p, E.hcount.p, lqs);
+        HIP_CHECK(hipGetLastError());
+        const bool rev = snake && (enq % 2 == 1);                  // the sweeps alternate their direction (see the host loop)
+        launch_minmax(qlq, E.tilesA.p, ntA_ub, 0, E.nodes.p, s, rev, dyn, px_src);
+        launch_hist(qlq, false, E.tilesA.p, ntA_ub, 0, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake && !rev, false, dyn, px_src);
+        launch_cut(weighted, E.nodes.p, d_round, kLqRoundCap, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s, dyn, nr_src);
+        launch_partition(qlq, E.tilesP.p, ntP_ub, 0, d_round, d_tP0, kLqRoundCap, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s, inv_sums, rev, dyn, px_src);
+        enq++;
+        control();
+    };
+    control();                                                     // the base clusters' moments, the first greedy steps, round 1
+    int want = (E.lq_hint_N == N && E.lq_hint_K == K && E.lq_hint_rounds > 0) ? E.lq_hint_rounds : 8;
+    for (;;) {
+        while (enq < want) round();
+        E.sync();
+        if (out->done) break;
+        want = enq + 2;
+    }
+    if (out->error == 2) return -2;
+    if (out->error != 0) throw HipError("patolette_amd: split loop blocked without candidates");
+    E.lq_hint_N = N; E.lq_hint_K = K; E.lq_hint_rounds = out->rounds;
+    len = (size_t)out->count;
+    centers.assign(out->centers, out->centers + 3 * len);
+    if (max_members) *max_members = out->max_members;
+    E.stats.split_evals = (size_t)out->split_evals; E.stats.split_px = (size_t)out->split_px; E.stats.lq_rounds = (size_t)out->rounds;
+    E.trace.assign(out->trace, out->trace + std::min<int>(out->ntrace, kLqDevMaxK));
+    E.trace_hdr.stopped_early = out->stopped_early;
+    return 0;
+}
+
+static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, const Bounds &bnd,
+                                 std::vector<double> &centers, size_t &len, bool verbose, unsigned long long *max_members, bool allow_device) {
     hipStream_t s = E.stream;
     const size_t planes = weighted ? 4 : 3;
     const Shard *sh = E.shard;                                  // the image is dealt out over a group of GPUs: N is this GPU's part
@@ -615,7 +1042,9 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     const bool inv_sums = sh || E.invariant;
     if (E.prep_N != N || E.prep_planes != planes) gq_prepare(E, N, weighted);   // (the stage-level entry points come here unprepared)
     E.prep_N = 0;
-    E.nodes.reserve(4 * K + 64);
+    // PAMD_LQ_DEVICE=0: the host-driven split loop everywhere (A/B, and what sliced images, K > 256 and verbose calls always take)
+    const bool dev_eligible = allow_device && g_lq_device.load(std::memory_order_relaxed) != 0 && !sh && !verbose && K <= (size_t)kLqDevMaxK;
+    E.nodes.reserve(std::max<size_t>(4 * K + 64, dev_eligible ? (size_t)kLqNodeCap : 0));
     std::vector<HNode> hn;
     hn.reserve(4 * K + 64);
     double t0 = now_ms();
@@ -786,6 +1215,19 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     if (sh) { hipLaunchKernelGGL(k_shard_children_local, 1, 64, 0, s, E.nodes.p, E.round_nodes.p, 1); HIP_CHECK(hipGetLastError()); }
     if (!gq_binary) launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, snake && !mom_path);
     if (sh) shard_exchange_acc(E, shard_upload_ids(E, base_ids), (int)base_ids.size());
+    if (dev_eligible && (size_t)kbase < K) {
+        // the split loop runs from the device: no synchronisation here, the control kernel takes the base clusters' moments itself
+        E.stats.n_base_clusters = (size_t)kbase;
+        E.stats.ms_gq = now_ms() - t0;
+        t0 = now_ms();
+        const int rc = lq_device_loop(E, N, K, weighted, inv_sums, qlq, kbase, base_ids[0], (int)hn.size(), snake, centers, len, max_members);
+        if (rc != 0) return rc;
+        E.stats.n_clusters = len;
+        E.trace_hdr.n_clusters = (int32_t)len; E.trace_hdr.n_records = (int32_t)E.trace.size();
+        E.cluster_centers = centers;
+        E.stats.ms_lq = now_ms() - t0;
+        return 0;
+    }
     get_nodes(E, base_ids, got);
     for (size_t i = 0; i < base_ids.size(); i++) {
         absorb_moments(hn[base_ids[i]], got[i]);
@@ -1003,6 +1445,16 @@ static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const
     E.cluster_centers = centers;
     E.stats.ms_lq = now_ms() - t0;
     return 0;
+}
+
+static int quantize_clusters(Engine &E, size_t N, size_t K, bool weighted, const Bounds &bnd,
+                             std::vector<double> &centers, size_t &len, bool verbose = false, unsigned long long *max_members = nullptr) {
+    int rc = quantize_clusters_run(E, N, K, weighted, bnd, centers, len, verbose, max_members, true);
+    if (rc == -2) {                                             // the device-driven loop ran out of node records: once more, host-driven
+        E.prep_N = 0;
+        rc = quantize_clusters_run(E, N, K, weighted, bnd, centers, len, verbose, max_members, false);
+    }
+    return rc;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2048,6 +2500,20 @@ int patolette_amd_subsample_indices(size_t n, size_t take, int32_t *out) {
     hm::rand_perm_prefix(n, take, 1234u, out);                              // host code: needs no device
     return 0;
 }
+int patolette_amd_eigen_sym3_device(const double *a_colmajor, size_t count, double *w, double *z, int *info) {
+    try {
+        if (!count) return 0;
+        DevBuf<double> da, dw, dz; DevBuf<int> di;
+        da.reserve(9 * count); dw.reserve(3 * count); dz.reserve(9 * count); di.reserve(count);
+        HIP_CHECK(hipMemcpy(da.p, a_colmajor, 9 * count * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_eigen_batch, (unsigned)((count + 63) / 64), 64, 0, nullptr, da.p, count, dw.p, dz.p, di.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(w, dw.p, 3 * count * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(z, dz.p, 9 * count * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(info, di.p, count * sizeof(int), hipMemcpyDeviceToHost));
+        return 0;
+    } catch (const std::exception &e) { engine().last_error = e.what(); return -1; }
+}
 int patolette_amd_eigen_sym3(const double a_colmajor[9], double w[3], double z[9]) {
     std::memcpy(z, a_colmajor, 9 * sizeof(double));
     return hm::eigen_sym3(z, w);                                           // LAPACK info: 0 = converged
@@ -2168,6 +2634,7 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
 }
 
 int patolette_amd_debug_fault(int which) { return g_debug_fault.exchange(which); }
+int patolette_amd_set_split_loop(int on_device) { return g_lq_device.exchange(on_device ? 1 : 0); }
 void patolette_amd_dither_config(int segments, int warm) { dither_config(segments, warm); }
 void patolette_amd_dither_layout(int lanes) { dither_layout(lanes); }
 void patolette_amd_last_stats(patolette_amd__Stats *out) { *out = engine().stats; }

@@ -55,7 +55,9 @@ struct NodeDev {
     unsigned long long minkey[kSlots], maxkey[kSlots];   // ordered keys of the projection extrema
     int degenerate;                    // max - min < 1e-16 -> round-robin buckets (sort.c:61-79)
     int split;                         // optimal bucket index (local.c:171)
-    int psplit, pad_;                  // the PARENT's cut as k_cut took it: bucket | degenerate << 16 (for the split trace; -1: a base cluster)
+    int psplit;                        // the PARENT's cut as k_cut took it: bucket | degenerate << 16 (for the split trace; -1: a base cluster)
+    int axis_state;                    // device-driven split loop: 0 moments not final yet, 1 axis solved, -1 the eigen-solver failed
+    double cov6[6], dist, ub;          // ... the node's centred sums (xx,yx,zx,yy,zy,zz), distortion, upper bound of any split's benefit
     unsigned long long cbegin[kMaxChildren + 1];   // children segments in the other buffer
     // ---- moments about `mean` (k_cov / k_scatter): 6 covariance sums + distortion, 2 parts each
     double acc[kSlots][7][2];
@@ -79,6 +81,14 @@ __device__ __forceinline__ void node_minmax(const NodeDev &d, double &mn, double
     for (int i = 0; i < kSlots; i++) { a = d.minkey[i] < a ? d.minkey[i] : a; b = d.maxkey[i] > b ? d.maxkey[i] : b; }
     mn = key_f64(a); mx = key_f64(b);
 }
+
+// Sizes of a split round that only the DEVICE knows (the split loop's control kernel, pipeline.hip k_lq_control, writes them):
+// the sweep kernels are then launched with upper bounds and read the real extent here.  A null pointer everywhere else.
+struct RoundDyn {
+    int nr;                            // nodes evaluated in this round
+    int ntA, ntP;                      // tiles of both tilings
+    int pad;
+};
 
 struct Tile {
     unsigned long long start;          // absolute pixel slot
@@ -108,18 +118,22 @@ void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, 
 
 // from_end (every sweep launcher): the blocks take the tiles from the end of the list.  The sweeps of a split round alternate,
 // so that each starts on the lines the previous one touched last
-void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end = false);
+// dyn (every launcher below): the launch covers `ntiles` / `nround` as UPPER BOUNDS and the kernels take the real sizes from *dyn;
+// px_src then points at the round's pixel count (a double the control kernel wrote to pinned host memory) for the kernel timer
+void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end = false,
+                   const RoundDyn *dyn = nullptr, const double *px_src = nullptr);
 // fixed_point (global quantiser only): block-local sums as 64-bit integers (k_hist_fix); a property of the IMAGE (its total
 // pixel count), so that every GPU sharing an image takes the same path
 void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
                  double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end = false,
-                 bool fixed_point = false);
+                 bool fixed_point = false, const RoundDyn *dyn = nullptr, const double *px_src = nullptr);
 void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int nround, const double *d_hist,
-                const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s);
+                const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s,
+                const RoundDyn *dyn = nullptr, const double *nr_src = nullptr);
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
                       unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s,
-                      bool invariant = false, bool from_end = false);
+                      bool invariant = false, bool from_end = false, const RoundDyn *dyn = nullptr, const double *px_src = nullptr);
 void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end = false);
 void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
                       NodeDev *d_nodes, hipStream_t s, bool from_end = false);

@@ -102,10 +102,13 @@ __device__ __forceinline__ double project(double x, double y, double z, const do
     return (x * a0 + y * a1) + z * a2;
 }
 
-__global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes, const int from_end) {
+__global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes, const int from_end,
+                                                const RoundDyn *__restrict__ dyn) {
     // tiles are taken from the END: this sweep follows the partition kernel, whose most recently written lines are the last
     // tiles' (what is still in flight towards HBM is read last; measured on a replica: 80 -> 73 us behind a copy of 403 MB)
-    const Tile t = tiles[from_end ? gridDim.x - 1u - blockIdx.x : blockIdx.x];
+    const unsigned nt = dyn ? (unsigned)dyn->ntA : gridDim.x;   // dyn: the launch is an upper bound, the control kernel knows the extent
+    if (blockIdx.x >= nt) return;
+    const Tile t = tiles[from_end ? nt - 1u - blockIdx.x : blockIdx.x];
     NodeDev &nd = nodes[t.node];
     const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
     const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N;
@@ -147,8 +150,15 @@ __global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__r
 constexpr int kHistCombineMin = 12;    // lanes of a wavefront sharing a bucket from which their addends are summed before the LDS atomics
 template <bool W, bool GQ>
 __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
-                                              double *hist, unsigned long long *hsize, unsigned int *hcount, const int from_end) {
+                                              double *hist, unsigned long long *hsize, unsigned int *hcount, const int from_end,
+                                              const RoundDyn *__restrict__ dyn) {
     constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
+    int nblk = (int)gridDim.x;
+    if (dyn) {                                             // the launch is an upper bound: as many blocks work as a launch sized by the host would have had
+        ntiles = dyn->ntA;
+        nblk = min(ntiles, nblk);
+        if ((int)blockIdx.x >= nblk) return;
+    }
     constexpr int NQS = GQ ? kNQ_GQ : kNQ_LQ;            // slot stride in quantities
     extern __shared__ double lds[];
     double *h = lds;                                       // [NQ][2][512]
@@ -162,8 +172,8 @@ __global__ __launch_bounds__(512) void k_hist(QuantBuffers qb, const Tile *__res
     // only when the node changes: far fewer global f64 atomics than one flush per tile
     // from_end: the blocks take their runs of tiles from the end of the list -- each sweep of a split round starts where the
     // previous one stopped, on the lines that are still in the caches (k_minmax)
-    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int bid = (from_end & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int per = (ntiles + nblk - 1) / nblk;
+    const int bid = (from_end & 1) ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
     for (int ti = tfirst; ti < tlast; ti++) {
         const Tile t = tiles[ti];
@@ -457,7 +467,8 @@ __global__ __launch_bounds__(512) void k_hist_fix(QuantBuffers qb, const Tile *_
 template <bool W>
 __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restrict__ round_nodes, const double *__restrict__ hist,
                                              const unsigned long long *__restrict__ hsize, const unsigned int *__restrict__ hcount,
-                                             unsigned char *lut, const int fault) {
+                                             unsigned char *lut, const int fault, const RoundDyn *__restrict__ dyn) {
+    if (dyn && (int)blockIdx.x >= dyn->nr) return;
     __shared__ double sd[4 * 16];
     __shared__ unsigned long long su[2 * 16];
     __shared__ double best_v[8];
@@ -566,10 +577,13 @@ __global__ __launch_bounds__(512) void k_cut(NodeDev *nodes, const int *__restri
 // parent, as the reference's index lists have it.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_count(QuantBuffers qb, const Tile *__restrict__ tiles, const NodeDev *__restrict__ nodes,
-                                               const unsigned char *__restrict__ lut, unsigned int *tilecnt, const int from_end) {
+                                               const unsigned char *__restrict__ lut, unsigned int *tilecnt, const int from_end,
+                                               const RoundDyn *__restrict__ dyn) {
     __shared__ unsigned int c[kMaxChildren];
     __shared__ unsigned char sl[kBuckets];
-    const unsigned tix = from_end ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    const unsigned nt = dyn ? (unsigned)dyn->ntP : gridDim.x;
+    if (blockIdx.x >= nt) return;
+    const unsigned tix = from_end ? nt - 1u - blockIdx.x : blockIdx.x;
     const Tile t = tiles[tix];
     const NodeDev &nd = nodes[t.node];
     const unsigned char *l = lut + (size_t)nd.slot * kBuckets;
@@ -626,7 +640,9 @@ __global__ __launch_bounds__(256) void k_count(QuantBuffers qb, const Tile *__re
     if (threadIdx.x < kMaxChildren) tilecnt[(size_t)tix * kMaxChildren + threadIdx.x] = c[threadIdx.x];
 }
 __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ round_nodes, const int *__restrict__ node_tile0, NodeDev *nodes,
-                                              const unsigned int *__restrict__ tilecnt, unsigned long long *tileoff) {
+                                              const unsigned int *__restrict__ tilecnt, unsigned long long *tileoff,
+                                              const RoundDyn *__restrict__ dyn) {
+    if (dyn && (int)blockIdx.x >= dyn->nr) return;
     // Exclusive prefix of the per-tile child counts of one node (one block per node).  Every thread owns a run of
     // consecutive tiles: it sums them (eight independent loads in flight at a time), ONE block scan per child orders the
     // thread totals, and the thread writes the offsets of its tiles -- two block scans for a binary split instead of one
@@ -858,15 +874,22 @@ __global__ __launch_bounds__(256, INV ? 4 : 5) void k_scatter(QuantBuffers qb, c
 template <bool W, bool INV>
 __global__ __launch_bounds__(256, (W || INV) ? 2 : 3) void k_scatter_bin(QuantBuffers qb, const Tile *__restrict__ tiles, int ntiles, NodeDev *nodes,
                                                                         const NodeDev *__restrict__ nodes_ro,
-                                                                        const unsigned long long *__restrict__ tileoff, const int from_end) {
+                                                                        const unsigned long long *__restrict__ tileoff, const int from_end,
+                                                                        const RoundDyn *__restrict__ dyn) {
     constexpr int R = kTileP / 256;
     static_assert(R * 4 == 32, "one 32-lane group per child");
     __shared__ unsigned int wcnt[2][2][R * 4];               // [tile parity][child][r * 4 + wavefront]: members per (round, wavefront)
     __shared__ double sm[28 * 4];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned long long ltmask = (1ULL << lane) - 1ULL;
-    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int bid = from_end ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    int nblk = (int)gridDim.x;
+    if (dyn) {                                               // the launch is an upper bound (see k_hist)
+        ntiles = dyn->ntP;
+        nblk = min(ntiles, nblk);
+        if ((int)blockIdx.x >= nblk) return;
+    }
+    const int per = (ntiles + nblk - 1) / nblk;
+    const int bid = from_end ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
     if (tfirst >= tlast) return;
     constexpr int NP = INV ? 14 : 7;
@@ -1093,10 +1116,11 @@ void launch_sum3(const double *planar, size_t N, BinK k, double *d_out6, hipStre
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end) {
+void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end,
+                   const RoundDyn *dyn, const double *px_src) {
     if (!ntiles) return;
-    KTIME("k_minmax", s, 24.0 * px);
-    hipLaunchKernelGGL(k_minmax, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0);
+    KTIME_DYN("k_minmax", s, 24.0, px, px_src);
+    hipLaunchKernelGGL(k_minmax, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0, dyn);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1115,12 +1139,13 @@ static void launch_hist_fix(const QuantBuffers &qb, const Tile *d_tiles, int nti
 
 template <bool W, bool GQ>
 static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, double *d_hist,
-                          unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end) {
+                          unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end,
+                          const RoundDyn *dyn = nullptr, const double *px_src = nullptr) {
     constexpr int NQ = GQ ? (W ? 14 : 10) : (W ? 4 : 3);
     size_t lds = (size_t)NQ * 2 * kBuckets * sizeof(double) + kBuckets * (sizeof(unsigned int) + sizeof(unsigned long long));
     static PerDeviceOnce attr_set;
     if (attr_set.first()) HIP_CHECK(hipFuncSetAttribute((const void *)k_hist<W, GQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    KTIME(GQ ? "k_hist_gq" : "k_hist_lq", s, (W ? 34.0 : 26.0) * px);
+    KTIME_DYN(GQ ? "k_hist_gq" : "k_hist_lq", s, (W ? 34.0 : 26.0), px, px_src);
     // resident blocks per CU by LDS footprint (4 for the local quantiser's 29 KB, 1 for the global quantiser's 82+ KB);
     // each block walks its run of tiles and flushes once per node run
     const int g = std::min(ntiles, 256 * (GQ ? 1 : 4));
@@ -1128,7 +1153,7 @@ static void launch_hist_t(const QuantBuffers &qb, const Tile *d_tiles, int ntile
 #ifdef PAMD_KM_TRACE
     if (getenv("PAMD_HIST_NOATOMIC") && atoi(getenv("PAMD_HIST_NOATOMIC"))) fe |= 2;     // diagnostic: time the kernel without its LDS atomics (wrong results)
 #endif
-    hipLaunchKernelGGL((k_hist<W, GQ>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount, fe);
+    hipLaunchKernelGGL((k_hist<W, GQ>), g, 512, lds, s, qb, d_tiles, ntiles, d_nodes, d_hist, d_hsize, d_hcount, fe, dyn);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1217,7 +1242,8 @@ void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, 
 }
 
 void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,
-                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end, bool fixed_point) {
+                 double *d_hist, unsigned long long *d_hsize, unsigned int *d_hcount, hipStream_t s, bool from_end, bool fixed_point,
+                 const RoundDyn *dyn, const double *px_src) {
     if (!ntiles) return;
     if (gq && fixed_point) {
         if (qb.weighted) launch_hist_fix<true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
@@ -1225,42 +1251,44 @@ void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntile
         return;
     }
     if (qb.weighted) { if (gq) launch_hist_t<true, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
-                       else launch_hist_t<true, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end); }
+                       else launch_hist_t<true, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end, dyn, px_src); }
     else { if (gq) launch_hist_t<false, true>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end);
-           else launch_hist_t<false, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end); }
+           else launch_hist_t<false, false>(qb, d_tiles, ntiles, px, d_nodes, d_hist, d_hsize, d_hcount, s, from_end, dyn, px_src); }
 }
 
 // patolette_amd_debug_fault: a deliberately wrong decision rule, for the tests that show the tie prover tells a tie from a bug
 std::atomic<int> g_debug_fault{0};
 void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int nround, const double *d_hist,
-                const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s) {
+                const unsigned long long *d_hsize, const unsigned int *d_hcount, unsigned char *d_lut, hipStream_t s, const RoundDyn *dyn, const double *nr_src) {
     if (!nround) return;
-    KTIME("k_cut", s, (double)nround * kNQ_LQ * 2 * kBuckets * 8);
+    KTIME_DYN("k_cut", s, (double)kNQ_LQ * 2 * kBuckets * 8, nround, nr_src);
     const int fault = g_debug_fault.load(std::memory_order_relaxed);
-    if (weighted) hipLaunchKernelGGL(k_cut<true>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut, fault);
-    else hipLaunchKernelGGL(k_cut<false>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut, fault);
+    if (weighted) hipLaunchKernelGGL(k_cut<true>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut, fault, dyn);
+    else hipLaunchKernelGGL(k_cut<false>, nround, 512, 0, s, d_nodes, d_round_nodes, d_hist, d_hsize, d_hcount, d_lut, fault, dyn);
     HIP_CHECK(hipGetLastError());
 }
 
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
-                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s, bool invariant, bool from_end) {
+                      unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s, bool invariant, bool from_end,
+                      const RoundDyn *dyn, const double *px_src) {
     const int fe = from_end ? 1 : 0;
     if (!nround) return;
-    if (nptiles) { KTIME("k_count", s, 2.0 * px); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt, fe); }
+    if (nptiles) { KTIME_DYN("k_count", s, 2.0, px, px_src); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt, fe, dyn); }
     // (a GPU holding none of the round's pixels still needs the children's -- empty -- segments: k_scan runs regardless)
-    { KTIME("k_scan", s, 12.0 * kMaxChildren * nptiles); hipLaunchKernelGGL(k_scan, nround, 1024, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff); }
+    { KTIME_DYN("k_scan", s, 12.0 * kMaxChildren / (double)kTileP, dyn ? px : (size_t)nptiles * kTileP, px_src);
+      hipLaunchKernelGGL(k_scan, nround, 1024, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff, dyn); }
     if (nptiles) {
-        KTIME(fuse_cov ? "k_scatter_cov" : "k_scatter", s, (qb.weighted ? 66.0 : 50.0) * px);
+        KTIME_DYN(fuse_cov ? "k_scatter_cov" : "k_scatter", s, (qb.weighted ? 66.0 : 50.0), px, px_src);
         if (fuse_cov) {
             static const bool v1 = getenv("PAMD_SCATTER_V1") && atoi(getenv("PAMD_SCATTER_V1")) != 0;   // the round-trip-per-round kernel (A/B)
-            if (!v1) {
+            if (!v1 || dyn) {
                 const int gb = std::min(nptiles, 256 * ((invariant || qb.weighted) ? 2 : 3));
                 if (invariant) {
-                    if (qb.weighted) hipLaunchKernelGGL((k_scatter_bin<true, true>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe);
-                    else hipLaunchKernelGGL((k_scatter_bin<false, true>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe);
-                } else if (qb.weighted) hipLaunchKernelGGL((k_scatter_bin<true, false>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe);
-                else hipLaunchKernelGGL((k_scatter_bin<false, false>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe);
+                    if (qb.weighted) hipLaunchKernelGGL((k_scatter_bin<true, true>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe, dyn);
+                    else hipLaunchKernelGGL((k_scatter_bin<false, true>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe, dyn);
+                } else if (qb.weighted) hipLaunchKernelGGL((k_scatter_bin<true, false>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe, dyn);
+                else hipLaunchKernelGGL((k_scatter_bin<false, false>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe, dyn);
                 HIP_CHECK(hipGetLastError());
                 return;
             }

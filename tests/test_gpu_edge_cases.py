@@ -221,6 +221,46 @@ def test_product_eigen_solver_vs_lapack_golden_and_oracle(gpu, native, ob):
         assert i1 == i2 and np.array_equal(bits(w1), bits(w2)) and np.array_equal(bits(v1), bits(v2))
 
 
+def test_device_eigen_solver_is_the_hosts_bit_for_bit(gpu, native, ob):
+    """The split loop's control kernel solves the children's 3x3 problems ON THE DEVICE (pipeline.hip k_lq_control -> hm::eigen_sym3, the
+    host's code compiled for gfx950, one problem per lane).  Same bits as the host / the oracle's dsyev restatement on the LAPACK
+    golden matrices, on 20 000 random covariance-like ones, and on rank-deficient / axis-aligned / zero ones (eigen.c:83-140)."""
+    import ctypes as C
+    from tests.util import bits, golden
+    L = native.lib()
+    rng = np.random.default_rng(1)
+    mats = [np.array(a, dtype=np.float64) for a in golden("eigen_lapack.npz")["A"]]
+    for _ in range(20000):
+        m = rng.normal(size=(3, 3)) * 10.0 ** rng.integers(-6, 3)
+        mats.append(m @ m.T)
+    for _ in range(2000):                                        # rank one, rank two, axis-aligned, zero, tiny off-diagonals
+        kind = rng.integers(0, 5)
+        v = rng.normal(size=3)
+        if kind == 0:
+            a = np.outer(v, v)
+        elif kind == 1:
+            u = rng.normal(size=3)
+            a = np.outer(v, v) + np.outer(u, u)
+        elif kind == 2:
+            a = np.diag(np.abs(rng.normal(size=3)))
+        elif kind == 3:
+            a = np.zeros((3, 3))
+        else:
+            a = np.diag(np.abs(rng.normal(size=3))) + 1e-17 * (np.outer(v, v))
+        mats.append(a * 10.0 ** rng.integers(-12, 2))
+    count = len(mats)
+    flat = np.concatenate([np.asfortranarray(a).reshape(-1, order="F") for a in mats])
+    w = np.zeros(3 * count)
+    z = np.zeros(9 * count)
+    info = np.zeros(count, dtype=np.int32)
+    assert L.patolette_amd_eigen_sym3_device(_d(flat), count, _d(w), _d(z), info.ctypes.data_as(C.POINTER(C.c_int))) == 0
+    for i, a in enumerate(mats):
+        i2, w2, v2 = ob.eigen_sym3(a)
+        assert info[i] == i2
+        assert np.array_equal(bits(w[3 * i:3 * i + 3]), bits(w2)), (i, a)
+        assert np.array_equal(bits(z[9 * i:9 * i + 9].reshape(3, 3, order="F")), bits(v2)), (i, a)
+
+
 def test_release_workspace_and_thread_engines(gpu, native, ob):
     """Engines are pooled: a short-lived thread hands its engine back at exit, release_workspace frees the idle ones, and
     the next call works (and gives the same answer) on a fresh workspace."""
