@@ -445,23 +445,36 @@ def small_image(L, native, reps=7):
         opts = native.QuantizationOptions(dither, False, cs, niter, max_samples, False)
         pal = np.zeros((K, 3), dtype=np.float64, order="F")
         code = C.c_int(0)
-        times = []
-        for i in range(reps + 2):
-            L.patolette_amd_synchronize()
-            t0 = time.perf_counter()
-            L.patolette_amd_device(width, height, d, None, K, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
-            L.patolette_amd_synchronize()
-            if code.value != 0:
-                return None
-            if i >= 2:
-                times.append(time.perf_counter() - t0)
-        st = native.last_stats()
+
+        def timed():
+            times = []
+            for i in range(reps + 2):
+                L.patolette_amd_synchronize()
+                t0 = time.perf_counter()
+                L.patolette_amd_device(width, height, d, None, K, C.byref(opts), pal.ctypes.data_as(native.dp), dmap, 1, C.byref(code))
+                L.patolette_amd_synchronize()
+                if code.value != 0:
+                    return None, None
+                if i >= 2:
+                    times.append(time.perf_counter() - t0)
+            return sorted(times)[len(times) // 2], native.last_stats()
+        med, st = timed()
+        if med is None:
+            return None
+        # the same call with the split loop driven by the host (a synchronisation, the host's turn and an upload per round): the A/B
+        prev = L.patolette_amd_set_split_loop(0)
+        try:
+            med_h, st_h = timed()
+        finally:
+            L.patolette_amd_set_split_loop(prev)
     finally:
         L.patolette_amd_free(d)
         L.patolette_amd_free(dmap)
-    med = sorted(times)[len(times) // 2]
     return {"config": desc, "ms": round(1e3 * med, 3), "value": round(n / med / 1e6, 1), "unit": "Mpx/s", "reps": reps,
-            "stages_ms": {k: round(v, 3) for k, v in st.items() if k.startswith("ms_") and v}, "lq_rounds": st["lq_rounds"]}
+            "stages_ms": {k: round(v, 3) for k, v in st.items() if k.startswith("ms_") and v}, "lq_rounds": st["lq_rounds"],
+            "split_evals": st["split_evals"], "split_loop": "device-driven (the default below 12 Mpixel): one host synchronisation per image",
+            "host_driven_split_loop": None if med_h is None else {"ms": round(1e3 * med_h, 3), "ms_lq": round(st_h["ms_lq"], 3),
+                                                                    "lq_rounds": st_h["lq_rounds"], "split_evals": st_h["split_evals"]}}
 
 
 def host_to_host_u8(L, native, cfg, reps=3):

@@ -194,12 +194,16 @@ int patolette_amd_set_invariant_sums(int on);
  * the previous setting.  Environment default: PAMD_KMEANS_UPDATE=1. */
 int patolette_amd_set_kmeans_update(int mode);
 
-/* Who drives the split loop of the local quantiser (quantize/local.c:318-404).  1 (default): the device -- one single-block kernel
- * per round does what the host did between two rounds (the children's eigen-solves, the greedy replay of local.c:347-390, the next
- * round's node list), the sweep kernels read their sizes from device memory, and the host synchronises once; taken for palettes of
- * up to 256 colours on one GPU.  0: the host-driven loop everywhere (what sliced images, larger palettes and verbose calls always
- * take).  Same decisions, same results, bit for bit.  Process-wide; returns the previous setting.  Environment: PAMD_LQ_DEVICE=0. */
-int patolette_amd_set_split_loop(int on_device);
+/* Who drives the split loop of the local quantiser (quantize/local.c:318-404).  The device-driven loop enqueues round after round
+ * without a host turn: the children's moments, bounds and eigen-solves and the next round's node list are made by two small
+ * kernels, the sweep kernels read their sizes from device memory, which candidate nodes to evaluate is decided by a rule that
+ * provably never skips a node the greedy loop commits, and the greedy loop of local.c:347-390 is replayed once, on the host, over
+ * the evaluated tree; the host synchronises once per image instead of once per round.  Taken for palettes of up to 256 colours
+ * on one GPU.  mode 2 (default): for images below 12 Mpixel, where the nine host turns are a third of the call; 1: wherever it
+ * applies; 0: the host-driven loop everywhere (what sliced images, larger palettes and verbose calls always take).  Same
+ * decisions and results either way (the children's moments may differ in their last bit: DESIGN.md 4.2).  Process-wide; returns
+ * the previous setting.  Environment: PAMD_LQ_DEVICE=0|1|2. */
+int patolette_amd_set_split_loop(int mode);
 
 /* The KMeans subsample list (faiss rand_perm(N, seed 1234), Clustering.cpp:311-319: a pure function of the pixel count) is made
  * on a helper thread that starts at call entry and is joined when the KMeans stage begins.  1 (default): the list stays on the

@@ -286,6 +286,31 @@ PAMD_HD inline bool principal_axis(const double c6[6], double axis[3]) {
     return true;
 }
 
+// An UPPER bound of the largest eigenvalue of a symmetric positive semi-definite 3x3 (xx,yx,zx,yy,zy,zz) without the eigen-solve:
+// with m = trace / 3 and q = sqrt(|A - m I|_F^2 / 6) the eigenvalues are m + 2 q cos(phi + 2 pi k / 3), so lambda_max <= m + 2 q
+// (exact for an isotropic and for a rank-one matrix); a few Newton steps on the characteristic polynomial, which is convex and
+// increasing above its largest root, come down towards it FROM ABOVE and are taken only while p(x) is clearly positive
+// (1e-10 x^3: far beyond the rounding of the evaluation), so every iterate stays an upper bound.  Used where only a bound is
+// needed at once and the exact solve can run beside other work (the device-driven split loop).  NaN in -> NaN out.
+PAMD_HD inline double lambda_max_bound(const double c[6]) {
+    const double tr = c[0] + c[3] + c[5], m = tr / 3.0;
+    const double d0 = c[0] - m, d1 = c[3] - m, d2 = c[5] - m;
+    const double fro = d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * (c[1] * c[1] + c[2] * c[2] + c[4] * c[4]);
+    double x = m + 2.0 * std::sqrt(fro / 6.0);
+    x = x * (1.0 + 1e-12);
+    const double c2 = tr;
+    const double c1 = (c[0] * c[3] - c[1] * c[1]) + (c[0] * c[5] - c[2] * c[2]) + (c[3] * c[5] - c[4] * c[4]);
+    const double c0 = c[0] * (c[3] * c[5] - c[4] * c[4]) - c[1] * (c[1] * c[5] - c[4] * c[2]) + c[2] * (c[1] * c[4] - c[3] * c[2]);
+    for (int it = 0; it < 4; it++) {
+        const double px = ((x - c2) * x + c1) * x - c0, dpx = (3.0 * x - 2.0 * c2) * x + c1;
+        if (!(px > 1e-10 * x * x * x) || !(dpx > 0.0)) break;
+        const double xn = x - px / dpx;
+        if (!(xn > 0.0) || !(xn < x)) break;
+        x = xn;
+    }
+    return x;
+}
+
 // --------------------------------------------------------------------------------------------
 // Scalar colour conversions for palette rows (reference: lib/src/color/*.c)
 // --------------------------------------------------------------------------------------------

@@ -168,49 +168,115 @@ __global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup 
 // =============================================================================================
 // The host-driven loop further down pays, per round, a stream synchronisation, the host's turn (the children's 3x3 eigen-solves,
 // the greedy replay, the next round's packet) and an upload: 30-110 us of idle GPU nine times per image -- a third of a
-// 1920x1080 call.  Here ONE single-block kernel does the host's turn: it finalises the children's moments, solves their
-// eigen-problems (hm::eigen_sym3, the very code the host runs, one problem per lane), replays the greedy loop of
-// local.c:347-390 out of LDS (one wavefront, ~0.2 us per commit), selects the next round by the same rules as the host
-// (speculation factor, R-th largest known benefit), and writes the round's node list, tile prefixes and sizes.  The sweep
-// kernels are launched with upper-bound grids and read the sizes from device memory (RoundDyn), so the host enqueues
-// control -> setup -> minmax -> hist -> cut -> count -> scan -> scatter round after round without looking, and synchronises
-// once.  How many rounds to enqueue: as many as the previous image of this size needed (noise, K = 256: 9); a surplus round is
-// eight empty launches, a deficit one more synchronisation.  Same decisions as the host loop, bit for bit (same sums, same
-// solver, same comparisons in the same order).
-constexpr int kLqDevMaxK = 256;                       // palette sizes the device-driven loop takes (LDS: ~13 bytes per node)
+// 1920x1080 call.  Here the rounds follow each other on the stream without the host looking, and the greedy loop of
+// local.c:347-390 is replayed ONCE, afterwards, over the evaluated candidate tree (split_cluster(c) depends only on c's members,
+// never on the greedy order).  Which leaves to evaluate is decided on the device by a rule that needs no replay and never
+// misses a node the replay will commit:
+//   the priority of an evaluated node is p(v) = min(benefit(v), p(parent(v))) (its ancestors are committed before it, so the
+//   replay reaches v only after benefits >= p(v)).  If M = K - (base clusters) evaluated nodes have p >= tau, the replay's M
+//   commits all have benefit >= tau (those M nodes and their ancestors are always available to it), so a leaf u with
+//   min(ub(u), p(parent(u))) < tau -- ub an upper bound of any split's benefit -- is never committed and never blocks the
+//   replay's exactness test (its bound is below every committed benefit).  tau = a lower estimate of the M-th largest p.
+// Per round: k_lq_children (one wavefront per child: moment slots summed, distortion, the bound), k_lq_select (block 0: benefits and
+// priorities of the nodes just split, tau, the next round's node list, tile prefixes and sizes; the other blocks meanwhile solve
+// the children's eigen-problems with hm::eigen_sym3, the host's own code, whose ~12 us of dependent divisions and square roots
+// would otherwise sit on the critical path), then the sweeps, launched with upper-bound grids and reading their sizes from
+// device memory (RoundDyn).  The host synchronises once (as many rounds are enqueued as the previous image of this size needed;
+// a surplus round is nine empty launches, a deficit one more synchronisation), downloads 16 bytes per node and replays.
+// Same decisions as the host-driven loop: same sums, same solver, same comparisons; only the SET of evaluated nodes differs
+// (a few more: the host prunes with a heuristic a replay in lock-step can afford).
+constexpr int kLqDevMaxK = 256;                       // palette sizes the device-driven loop takes
 constexpr int kLqNodeCap = 16 * kLqDevMaxK + 256;     // candidate-tree nodes; beyond it the call starts over on the host-driven loop
 constexpr int kLqRoundCap = 512;                      // nodes evaluated per round (more candidates wait for the next one)
 constexpr int kLqMaxRounds = 96;
 
-struct LqCtl {                                        // device memory
-    int K, count, nnodes, nleaves, done, error, stopped_early, rounds;
-    int ncids, ntrace, pad0, pad1;
-    RoundDyn dyn;
+struct LqRec {
+    double val;                                       // the split's benefit once known, else the bound `ub`
+    int left;                                         // left child (right = +1) once the node is in a round, else -1
+    int kn;                                           // known: never splits (one member, solver failed) or its split is evaluated
+};
+struct LqCen { double mean[3]; double gn; };          // what PALETTE_create needs of a node (create.c:11-33) + its member count
+struct LqHead {                                       // copied to the host at every check
+    int done, error, rounds, nnodes, neval, pad;
     unsigned long long split_evals, split_px;
-    int result[kLqDevMaxK];
+    double tau;
+    double round_px[kLqMaxRounds], round_nr[kLqMaxRounds];
+};
+struct LqCtl {                                        // device memory
+    LqHead h;
+    int K, M, nleaves, pad;
+    int ncids[2];                                     // children awaiting finalisation; [control call & 1]: k_lq_select's block 0 writes the NEXT
+    RoundDyn dyn;                                     // call's list while the other blocks still read this one's
     int leaves[kLqNodeCap];
     int round_ids[kLqRoundCap];
-    int cids[2 * kLqRoundCap];
+    int cids[2][2 * kLqRoundCap];
     int tA0[kLqRoundCap + 1], tP0[kLqRoundCap + 1];
-    double nval[kLqNodeCap];                          // per node: its split's benefit once known, else the bound `ub`
-    int nleft[kLqNodeCap];                            // left child (right = +1) once the node is in a round, else -1
-    unsigned char nkn[kLqNodeCap];                    // known: never splits (one member, solver failed) or its split is evaluated
-};
-struct LqOut {                                        // pinned host memory, written by the control kernel
-    int done, error, count, rounds, stopped_early, ntrace;
-    unsigned long long split_evals, split_px, max_members;
-    double round_px[kLqMaxRounds], round_nr[kLqMaxRounds];
-    double centers[3 * kLqDevMaxK];
-    patolette_amd__SplitRecord trace[kLqDevMaxK];
+    int nparent[kLqNodeCap];
+    double np[kLqNodeCap];                            // priority of the evaluated nodes
+    LqRec nrec[kLqNodeCap];                           // -> host: the replay's table
+    LqCen ncen[kLqNodeCap];                           // -> host: centres
 };
 
-__global__ void k_lq_init(LqCtl *c, int K, int kbase, int first_base, int nnodes) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        c->K = K; c->count = kbase; c->nnodes = nnodes; c->nleaves = 0; c->done = 0; c->error = 0; c->stopped_early = 0; c->rounds = 0;
-        c->ncids = kbase; c->ntrace = 0; c->dyn = RoundDyn{0, 0, 0, 0}; c->split_evals = 0ULL; c->split_px = 0ULL;
+// wave-wide maximum of a double through DPP row shifts and row broadcasts (lanes without a source keep their own value)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_f64(const double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int tlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int thi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmax(v, __hiloint2double(thi, tlo));
+}
+
+// The children the last round produced (first launch of a call: the base clusters), ONE WAVEFRONT EACH: the sixteen slots of the
+// moment accumulators summed (exact parts: any order), the distortion, and an upper bound of any split's benefit
+// (hm::lambda_max_bound x sum of weights: the scatter between two groups along their mean difference cannot exceed the node's
+// scatter along that direction; see leaf_bound).  init_kbase > 0: the call's first launch, which also sets the loop's state up
+// (the base clusters are nodes init_first .. init_first + init_kbase - 1).
+__global__ __launch_bounds__(256) void k_lq_children(NodeDev *nodes, LqCtl *c, const int call, const int eigen_bound, const int init_kbase,
+                                                     const int init_first, const int init_nnodes, const int init_K) {
+    const bool init = init_kbase > 0;
+    if (!init && c->h.done) return;
+    const int ncids = init ? init_kbase : c->ncids[call & 1];
+    const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (init && blockIdx.x == 0 && threadIdx.x == 0) {
+        c->K = init_K; c->M = init_K - init_kbase; c->nleaves = 0; c->ncids[0] = init_kbase; c->dyn = RoundDyn{0, 0, 0, 0};
+        c->h.done = 0; c->h.error = 0; c->h.rounds = 0; c->h.nnodes = init_nnodes; c->h.neval = 0; c->h.split_evals = 0ULL; c->h.split_px = 0ULL;
+        c->h.tau = 0.0;
     }
-    if (i < kbase) { c->result[i] = first_base + i; c->cids[i] = first_base + i; }
+    if (wave >= ncids) return;
+    const int id = init ? init_first + wave : c->cids[call & 1][wave];
+    if (init && lane == 0) c->cids[0][wave] = id;
+    NodeDev &d = nodes[id];
+    const double *acc = &d.acc[0][0][0];                            // acc[k][q][p]: 224 consecutive doubles; lane r < 14 sums element r of every slot
+    double sum = 0;
+    if (lane < 14) {
+        double v[kSlots];
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) v[k] = acc[k * 14 + lane];
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) sum += v[k];
+    }
+    const double pair = sum + __shfl_down(sum, 1, 64);             // lanes 0, 2, .., 12: first + second part of quantity q = lane / 2
+    double cov[7];
+#pragma unroll
+    for (int q = 0; q < 7; q++)
+        cov[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pair), 2 * q), __builtin_amdgcn_readlane(__double2loint(pair), 2 * q));
+    if (lane != 0) return;
+    double ub = cov[6];
+    const bool single = d.gn <= 1ULL;
+    const double sw = d.sw;
+    if (single || !(sw > 0)) ub = 0;
+    else if (eigen_bound) {
+        double c6[6];
+        for (int q = 0; q < 6; q++) c6[q] = cov[q] / sw;
+        const double b = hm::lambda_max_bound(c6) * sw * (1.0 + 1e-9) + 1e-9 * cov[6];
+        if (b == b && b < ub) ub = b;
+    }
+    for (int q = 0; q < 6; q++) d.cov6[q] = cov[q];
+    d.dist = cov[6]; d.ub = ub; d.axis_state = 0;
+    c->nrec[id] = LqRec{single ? 0.0 : ub, -1, single ? 1 : 0};
+    c->nparent[id] = init ? -1 : c->round_ids[wave >> 1];
+    c->ncen[id] = LqCen{{d.mean[0], d.mean[1], d.mean[2]}, (double)d.gn};
+    c->leaves[(init ? 0 : c->nleaves) + wave] = id;
 }
 
 __device__ __forceinline__ int block_excl_scan_256(const int v, int *sw /* [5] */, int &total) {
@@ -225,227 +291,129 @@ __device__ __forceinline__ int block_excl_scan_256(const int v, int *sw /* [5] *
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void k_lq_control(NodeDev *nodes, LqCtl *c, LqOut *out, const double spec_beta, const int eigen_bound,
-                                                    const int fault) {
-    if (c->done) return;
-    extern __shared__ unsigned char lq_lds[];
-    double *s_val = (double *)lq_lds;                              // [kLqNodeCap]
-    double *s_tmp = s_val + kLqNodeCap;                            // [kLqDevMaxK]
-    int *s_left = (int *)(s_tmp + kLqDevMaxK);                     // [kLqNodeCap]
-    volatile int *f_res = s_left + kLqNodeCap;                     // [kLqDevMaxK] the frontier in the reference's order (`result`)
-    volatile int *s_commit = f_res + kLqDevMaxK;                   // [3 * kLqDevMaxK] (row, node, new_row) of this call's commits
-    unsigned char *s_kn = (unsigned char *)(s_commit + 3 * kLqDevMaxK);   // [kLqNodeCap]
-    __shared__ int sw[5];
-    __shared__ int s_count, s_nc, s_mode, s_best, s_stopped, s_nmarked, s_kth_set;
-    __shared__ double s_bv, s_mu, s_kth;
-    __shared__ unsigned long long s_maxgn;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int K = c->K;
+// order-preserving 64-bit key of a priority (negative or NaN -> 0: below every threshold that matters)
+__device__ __forceinline__ unsigned long long lq_key(const double p) { return p > 0.0 ? (unsigned long long)__double_as_longlong(p) : 0ULL; }
 
-    // ---- A. the last round's children (the first call: the base clusters): moments, principal axis, bound (leaf_bound)
-    const int ncids = c->ncids;
-    for (int i = tid; i < ncids; i += 256) {
-        const int id = c->cids[i];
-        NodeDev &d = nodes[id];
-        double cov[7];
-        for (int q = 0; q < 7; q++) {                               // slot sums are exact (binned parts), any order
-            double a0 = 0, a1 = 0;
-            for (int k = 0; k < kSlots; k++) { a0 += d.acc[k][q][0]; a1 += d.acc[k][q][1]; }
-            cov[q] = a0 + a1;
+__global__ __launch_bounds__(256) void k_lq_select(NodeDev *nodes, LqCtl *c, const int call, const int e_lin, const int e_quad) {
+    if (c->h.done) return;                                         // (set by an EARLIER launch only: every block of this one sees the same)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cur = call & 1, nxt = cur ^ 1;
+    const int ncids = c->ncids[cur];
+    if (blockIdx.x > 0) {
+        // ---- the other blocks: the children's principal axes (cluster.c:191-217 -> pca.c:122-149 -> dsyev), one wavefront per child,
+        // needed by the NEXT round's projection only -- solved here, beside the selection, instead of in front of it
+        const int w = ((int)blockIdx.x - 1) * 4 + (tid >> 6);
+        if (w >= ncids) return;
+        NodeDev &d = nodes[c->cids[cur][w]];
+        if (d.gn <= 1ULL || !(d.sw > 0)) { if (lane == 0) d.axis_state = d.gn <= 1ULL ? 0 : -1; return; }
+        double c6[6];
+        for (int q = 0; q < 6; q++) c6[q] = d.cov6[q] / d.sw;
+        double a[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+        double wv[3];
+        const int info = hm::eigen_sym3(a, wv);
+        if (lane == 0) {
+            if (info != 0) d.axis_state = -1;
+            else { d.axis[0] = a[6]; d.axis[1] = a[7]; d.axis[2] = a[8]; d.axis_state = 1; }
         }
-        for (int q = 0; q < 6; q++) d.cov6[q] = cov[q];
-        d.dist = cov[6];
-        double ub = cov[6];
-        int st = 0;
-        const bool single = d.gn <= 1ULL;
-        if (single || !(d.sw > 0)) { ub = 0; st = single ? 0 : -1; }
-        else {
-            double c6[6];
-            for (int q = 0; q < 6; q++) c6[q] = cov[q] / d.sw;
-            double a[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
-            double w[3];
-            if (hm::eigen_sym3(a, w) != 0) st = -1;
-            else {
-                d.axis[0] = a[6]; d.axis[1] = a[7]; d.axis[2] = a[8]; st = 1;
-                if (eigen_bound) {
-                    const double b = w[2] * d.sw * (1.0 + 1e-9) + 1e-9 * cov[6];
-                    if (b == b && b < ub) ub = b;
-                }
-            }
-        }
-        d.ub = ub; d.axis_state = st;
-        c->nval[id] = single ? 0.0 : ub; c->nkn[id] = single ? 1 : 0; c->nleft[id] = -1;
-        c->leaves[c->nleaves + i] = id;
+        return;
     }
-    __syncthreads();
-    // the nodes of that round are split now: benefit = distortion minus the children's (local.c:256-275)
+    __shared__ int sw[5];
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix, s_px;
+    __shared__ int s_need, s_neval;
+    const int M = c->M;
+    const int nn = c->h.nnodes;
+    // ---- A. the nodes of the last round are split now: benefit (local.c:256-275) and priority.  A node whose eigen-solve failed a round
+    // ago (never seen on finite input) was swept along a zero axis: it never splits, its children are dropped
     const int nr_prev = c->dyn.nr;
+    int evald = 0;
     for (int i = tid; i < nr_prev; i += 256) {
         const int id = c->round_ids[i];
         const NodeDev &d = nodes[id];
+        if (d.axis_state < 0) { c->nrec[id] = LqRec{0.0, -1, 1}; c->np[id] = 0.0; continue; }
         const int l = d.child0;
-        c->nval[id] = d.dist - (nodes[l].dist + nodes[l + 1].dist);
-        c->nkn[id] = 1;
+        const double b = d.dist - (nodes[l].dist + nodes[l + 1].dist);
+        const int par = c->nparent[id];
+        const double pp = par < 0 ? INFINITY : c->np[par];
+        c->nrec[id].val = b; c->nrec[id].kn = 1;
+        c->np[id] = b < pp ? b : pp;
+        evald++;
     }
+    if (tid == 0) { s_neval = 0; s_px = 0ULL; }
     __syncthreads();
-    int nleaves = c->nleaves + ncids;
-    const int nn = c->nnodes;
-    for (int i = tid; i < nn; i += 256) { s_val[i] = c->nval[i]; s_left[i] = c->nleft[i]; s_kn[i] = c->nkn[i]; }
-    for (int i = tid; i < c->count; i += 256) f_res[i] = c->result[i];
-    if (tid == 0) { s_count = c->count; s_nc = 0; s_stopped = 0; s_maxgn = 0ULL; }
+    if (evald) atomicAdd(&s_neval, evald);
     __syncthreads();
-
-    int nr = 0;
-    bool finished = false;
-    for (;;) {
-        // ---- B. greedy steps (local.c:347-390), exact while every undecided node is provably not the arg-max; one wavefront, out of LDS
-        if (tid < 64) {
-            int count = s_count, nc = s_nc, mode = 0, best = -1;
-            double bv = 0, mu = -1;
-            for (;;) {
-                if (count >= K) { mode = 1; break; }
-                bv = 0; best = -1; mu = -1;
-                for (int j = lane; j < count; j += 64) {
-                    const int id = f_res[j];
-                    const double v = s_val[id];
-                    if (s_kn[id]) { if (best < 0 || v > bv) { bv = v; best = j; } }
-                    else if (v > mu) mu = v;
+    const int neval = c->h.neval + s_neval;
+    // ---- B. tau: a lower estimate of the M-th largest priority among the evaluated nodes (three 8-bit radix passes on the order-preserving
+    // key: the lower edge of the 2^-12-wide bin that holds it)
+    double tau = 0.0;
+    if (neval >= M && M > 0) {
+        unsigned long long prefix = 0ULL;
+        int need = M;
+        for (int pass = 0; pass < 3; pass++) {
+            const int shift = 56 - 8 * pass;
+            hist[tid] = 0u;
+            __syncthreads();
+            for (int i = tid; i < nn; i += 256) {
+                const LqRec r = c->nrec[i];
+                if (r.kn && r.left >= 0) {
+                    const unsigned long long k = lq_key(c->np[i]);
+                    if (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255ULL], 1u);
                 }
-                for (int o = 32; o > 0; o >>= 1) {                  // first maximum among the known (vector.c:26-46), largest bound among the unknown
-                    const double obv = __shfl_xor(bv, o, 64), omu = __shfl_xor(mu, o, 64);
-                    const int ob = __shfl_xor(best, o, 64);
-                    if (ob >= 0 && (best < 0 || obv > bv || (obv == bv && ob < best))) { bv = obv; best = ob; }
-                    if (omu > mu) mu = omu;
-                }
-                if (mu < 0 || (best >= 0 && bv > mu)) {
-                    if (fault == 2) {                               // patolette_amd_debug_fault(2): a WRONG step, the second best known one
-                        double sv = -1; int second = -1;
-                        for (int j = lane; j < count; j += 64) {
-                            const int id = f_res[j];
-                            if (j != best && s_kn[id] && s_val[id] > sv) { sv = s_val[id]; second = j; }
-                        }
-                        for (int o = 32; o > 0; o >>= 1) {
-                            const double osv = __shfl_xor(sv, o, 64); const int os = __shfl_xor(second, o, 64);
-                            if (os >= 0 && (second < 0 || osv > sv || (osv == sv && os < second))) { sv = osv; second = os; }
-                        }
-                        if (second >= 0 && sv >= kDelta && sv < bv) { best = second; bv = sv; }
-                    }
-                    if (!(bv >= kDelta)) { s_stopped = 1; mode = 1; break; }      // benefit < DELTA: stop (local.c:365-370)
-                    const int id = f_res[best], l = s_left[id];
-                    if (lane == 0) {
-                        s_commit[3 * nc] = best; s_commit[3 * nc + 1] = id; s_commit[3 * nc + 2] = count;
-                        f_res[count] = l; f_res[best] = l + 1;      // local.c:375-376: palette ORDER
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    nc++; count++;
-                    continue;
-                }
-                if (fmax(best >= 0 ? bv : 0.0, mu) < kDelta) { s_stopped = 1; mode = 1; break; }   // nothing can reach DELTA
-                mode = 2;                                           // blocked: a round
-                break;
             }
-            if (lane == 0) { s_count = count; s_nc = nc; s_mode = mode; s_best = best; s_bv = bv; s_mu = mu; s_nmarked = 0; s_kth_set = 0; }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, b = 255;
+                for (; b > 0; b--) { if (acc + (int)hist[b] >= need) break; acc += (int)hist[b]; }
+                s_need = need - acc;
+                s_prefix = prefix | ((unsigned long long)b << shift);
+            }
+            __syncthreads();
+            need = s_need; prefix = s_prefix;
         }
+        tau = __longlong_as_double((long long)prefix);
+    }
+    const double thr = fmax(kDelta, tau * (1.0 - 1e-9));
+    // ---- C. the leaves to evaluate: the children just made (and what an earlier round had no room for) whose priority can still
+    // reach tau; the others never will (tau only grows) and are dropped for good
+    const int nleaves = c->nleaves + ncids;
+    int nkeep = 0, nr = 0;
+    for (int base = 0; base < nleaves; base += 256) {
+        const int i = base + tid;
+        int id = -1, sel = 0;
+        if (i < nleaves) {
+            id = c->leaves[i];
+            const LqRec r = c->nrec[id];
+            const int par = c->nparent[id];
+            if (!r.kn && !(par >= 0 && nodes[par].axis_state < 0)) {
+                const double pp = par < 0 ? INFINITY : c->np[par];
+                sel = (r.val < pp ? r.val : pp) >= thr ? 1 : 0;
+            }
+        }
+        int tsel;
+        const int psel = block_excl_scan_256(sel, sw, tsel);
+        int keep = 0, tkeep = 0, pkeep = 0;
+        if (nr + tsel > kLqRoundCap) {                              // the round is full: the rest waits for the next one (block-uniform branch)
+            if (sel && nr + psel >= kLqRoundCap) { sel = 0; keep = 1; }
+            pkeep = block_excl_scan_256(keep, sw, tkeep);
+        }
+        if (sel) c->round_ids[nr + psel] = id;
         __syncthreads();
-        if (s_mode == 1) { finished = true; break; }
-        // ---- C. which leaves of the candidate tree to evaluate: those whose bound reaches a quarter of the best candidate, and at
-        // least the R-th largest KNOWN benefit when R commits are left (the host loop's rules, quantize_clusters below)
-        const int count = s_count;
-        const double ref_b = fmax(s_best >= 0 ? s_bv : 0.0, s_mu);
-        double thr = fmax(kDelta, spec_beta * ref_b);
-        {
-            const int R = K - count;
-            double v = -INFINITY; int kn = 0;
-            if (tid < count) { const int id = f_res[tid]; kn = s_kn[id]; v = s_val[id]; }
-            s_tmp[tid] = kn ? v : -INFINITY;
-            int total;
-            (void)block_excl_scan_256(kn, sw, total);
-            if (total >= R && R > 0) {
-                if (kn) {
-                    int rank = 0;
-                    for (int u = 0; u < count; u++) { const double o = s_tmp[u]; rank += (o > v || (o == v && u < tid)) ? 1 : 0; }
-                    if (rank == R - 1) { s_kth = v; s_kth_set = 1; }
-                }
-                __syncthreads();
-                if (s_kth_set) thr = fmax(thr, s_kth * (1.0 - 1e-9));
-            }
-        }
-        int nkeep = 0;
-        nr = 0;
-        for (int base = 0; base < nleaves; base += 256) {
-            const int i = base + tid;
-            int id = -1, sel = 0, keep = 0;
-            if (i < nleaves) {
-                id = c->leaves[i];
-                if (!s_kn[id]) {
-                    if (s_val[id] >= thr) {
-                        if (nodes[id].axis_state < 0) { s_kn[id] = 1; s_val[id] = 0.0; c->nkn[id] = 1; c->nval[id] = 0.0; atomicAdd(&s_nmarked, 1); }   // the solver failed: never splits
-                        else sel = 1;
-                    } else keep = 1;
-                }
-            }
-            int tsel, tkeep;
-            const int psel = block_excl_scan_256(sel, sw, tsel);
-            const int pkeep = block_excl_scan_256(keep, sw, tkeep);
-            if (sel && nr + psel >= kLqRoundCap) { sel = 0; keep = 2; }          // the round is full: wait for the next one
-            int tkeep2;
-            const int pk2 = block_excl_scan_256(keep == 2 ? 1 : 0, sw, tkeep2);
-            if (sel) c->round_ids[nr + psel] = id;
-            if (keep == 1) c->leaves[nkeep + pkeep] = id;
-            __syncthreads();
-            if (keep == 2) c->leaves[nkeep + tkeep + pk2] = id;
-            nr = min(nr + tsel, kLqRoundCap);
-            nkeep += tkeep + tkeep2;
-            __syncthreads();
-        }
-        nleaves = nkeep;
-        if (nr > 0) break;
-        if (s_nmarked == 0) { if (tid == 0) c->error = 1; finished = true; break; }   // blocked without candidates
+        if (keep) c->leaves[nkeep + pkeep] = id;
+        nr = min(nr + tsel, kLqRoundCap);
+        nkeep += tkeep;
         __syncthreads();
     }
-
-    // ---- D. this call's commits -> the split trace (patolette_amd_last_split_trace), the frontier -> device memory
-    const int count = s_count, nc = s_nc, ntrace0 = c->ntrace;
-    for (int t = tid; t < nc; t += 256) {
-        const int row = s_commit[3 * t], id = s_commit[3 * t + 1], l = s_left[id];
-        const NodeDev &h = nodes[id], &hl = nodes[l], &hr = nodes[l + 1];
-        patolette_amd__SplitRecord tr;
-        tr.row = row; tr.new_row = s_commit[3 * t + 2];
-        tr.split = hl.psplit < 0 ? -1 : (hl.psplit & 0xffff); tr.degenerate = hl.psplit < 0 ? 0 : (hl.psplit >> 16) & 1;
-        tr.n = h.gn; tr.n_left = hl.gn; tr.n_right = hr.gn; tr.sw = h.sw;
-        for (int j = 0; j < 3; j++) tr.axis[j] = h.axis[j];
-        for (int q = 0; q < 6; q++) tr.cov6[q] = h.cov6[q] / h.sw;
-        tr.dist = h.dist; tr.dist_left = hl.dist; tr.dist_right = hr.dist; tr.benefit = h.dist - (hl.dist + hr.dist);
-        if (ntrace0 + t < kLqDevMaxK) out->trace[ntrace0 + t] = tr;
-    }
-    for (int i = tid; i < count; i += 256) c->result[i] = f_res[i];
-
-    if (finished) {
-        unsigned long long mg = 0ULL;
-        for (int i = tid; i < count; i += 256) {
-            const NodeDev &d = nodes[f_res[i]];
-            for (int j = 0; j < 3; j++) out->centers[(size_t)j * count + i] = d.mean[j];      // create.c:11-33
-            mg = d.gn > mg ? d.gn : mg;
-        }
-        atomicMax(&s_maxgn, mg);
-        __syncthreads();
-        if (tid == 0) {
-            c->done = 1; c->count = count; c->ntrace = ntrace0 + nc; c->nleaves = nleaves; c->ncids = 0; c->dyn = RoundDyn{0, 0, 0, 0};
-            out->count = count; out->rounds = c->rounds; out->stopped_early = s_stopped; out->ntrace = ntrace0 + nc; out->error = c->error;
-            out->split_evals = c->split_evals; out->split_px = c->split_px; out->max_members = s_maxgn;
-            __threadfence_system();
-            out->done = 1;
-        }
+    if (nr == 0) {                                                 // nothing left that the replay could commit: the loop is over
+        if (tid == 0) { c->h.done = 1; c->h.neval = neval; c->h.tau = tau; c->nleaves = 0; c->ncids[nxt] = 0; c->dyn = RoundDyn{0, 0, 0, 0}; }
         return;
     }
-
-    // ---- E. the round: slots, children ids, tile prefixes of both tilings (what the host's packet carried)
+    // ---- D. the round: slots, children ids, tile prefixes of both tilings (what the host's packet carries in the host-driven loop)
     if (nn + 2 * nr > kLqNodeCap) {                                // the candidate tree outgrew the table: the host-driven loop takes the call over
-        if (tid == 0) { c->done = 1; c->error = 2; c->dyn = RoundDyn{0, 0, 0, 0}; out->error = 2; __threadfence_system(); out->done = 1; }
+        if (tid == 0) { c->h.done = 1; c->h.error = 2; c->dyn = RoundDyn{0, 0, 0, 0}; }
         return;
     }
     int runA = 0, runP = 0;
-    unsigned long long rpx = 0ULL;
     for (int base = 0; base < nr; base += 256) {
         const int r = base + tid;
         int ta = 0, tp = 0;
@@ -454,8 +422,11 @@ __global__ __launch_bounds__(256) void k_lq_control(NodeDev *nodes, LqCtl *c, Lq
             const int id = c->round_ids[r];
             NodeDev &d = nodes[id];
             d.slot = r; d.child0 = nn + 2 * r; d.nchild = 2;
-            c->nleft[id] = nn + 2 * r;
-            c->cids[2 * r] = nn + 2 * r; c->cids[2 * r + 1] = nn + 2 * r + 1;
+            int P = 1;                                              // the grids of the exact sums follow the node's own size (make_nodedev)
+            while ((1ULL << P) < (d.gn > 1ULL ? d.gn : 2ULL)) P++;
+            d.klin = make_bink(e_lin, P); d.kquad = make_bink(e_quad, P);
+            c->nrec[id].left = nn + 2 * r;
+            c->cids[nxt][2 * r] = nn + 2 * r; c->cids[nxt][2 * r + 1] = nn + 2 * r + 1;
             n = d.n;
             ta = (int)((n + kTileA - 1) / kTileA); tp = (int)((n + kTileP - 1) / kTileP);
         }
@@ -464,20 +435,38 @@ __global__ __launch_bounds__(256) void k_lq_control(NodeDev *nodes, LqCtl *c, Lq
         const int pp = block_excl_scan_256(tp, sw, totP);
         if (r < nr) { c->tA0[r] = runA + pa; c->tP0[r] = runP + pp; }
         runA += totA; runP += totP;
-        // pixels of the round (a statistic): wave sums into one LDS word
-        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-        if (lane == 0 && n) atomicAdd(&s_maxgn, n);
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);     // pixels of the round (a statistic)
+        if (lane == 0 && n) atomicAdd(&s_px, n);
     }
     __syncthreads();
-    rpx = s_maxgn;
     if (tid == 0) {
-        const int round = c->rounds;
+        const int round = c->h.rounds;
+        const unsigned long long rpx = s_px;
         c->tA0[nr] = runA; c->tP0[nr] = runP;
-        c->count = count; c->ntrace = ntrace0 + nc; c->nleaves = nleaves; c->ncids = 2 * nr; c->nnodes = nn + 2 * nr;
+        c->nleaves = nkeep; c->ncids[nxt] = 2 * nr;
         c->dyn = RoundDyn{nr, runA, runP, 0};
-        c->split_evals += (unsigned long long)nr; c->split_px += rpx; c->rounds = round + 1;
-        if (round < kLqMaxRounds) { out->round_px[round] = (double)rpx; out->round_nr[round] = (double)nr; }
+        c->h.nnodes = nn + 2 * nr; c->h.neval = neval; c->h.tau = tau;
+        c->h.split_evals += (unsigned long long)nr; c->h.split_px += rpx; c->h.rounds = round + 1;
+        if (round < kLqMaxRounds) { c->h.round_px[round] = (double)rpx; c->h.round_nr[round] = (double)nr; }
     }
+}
+
+// the split trace's records of a device-driven call, made when somebody asks for them (patolette_amd_last_split_trace): one thread
+// per commit of the replay
+struct LqCommit { int row, node, new_row, left; };
+__global__ void k_lq_trace(const NodeDev *nodes, const LqCommit *commits, int n, patolette_amd__SplitRecord *out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const LqCommit cm = commits[t];
+    const NodeDev &h = nodes[cm.node], &hl = nodes[cm.left], &hr = nodes[cm.left + 1];
+    patolette_amd__SplitRecord tr;
+    tr.row = cm.row; tr.new_row = cm.new_row;
+    tr.split = hl.psplit < 0 ? -1 : (hl.psplit & 0xffff); tr.degenerate = hl.psplit < 0 ? 0 : (hl.psplit >> 16) & 1;
+    tr.n = h.gn; tr.n_left = hl.gn; tr.n_right = hr.gn; tr.sw = h.sw;
+    for (int j = 0; j < 3; j++) tr.axis[j] = h.axis[j];
+    for (int q = 0; q < 6; q++) tr.cov6[q] = h.cov6[q] / h.sw;
+    tr.dist = h.dist; tr.dist_left = hl.dist; tr.dist_right = hr.dist; tr.benefit = h.dist - (hl.dist + hr.dist);
+    out[t] = tr;
 }
 
 // what k_round_setup does from the host's packet, from the control kernel's lists: cleared outputs of the round's nodes, both tile
@@ -636,8 +625,12 @@ struct Engine {
     DevBuf<double> wsal;
     DevBuf<GqDpDev> gq;
     PinBuf<GqDpDev> h_gq;
-    DevBuf<LqCtl> lqctl;                  // the device-driven split loop's state and what its control kernel reports (pinned)
-    PinBuf<LqOut> h_lqout;
+    DevBuf<LqCtl> lqctl;                  // the device-driven split loop's state; the host's copies of what the replay needs
+    PinBuf<LqHead> h_lqhead;
+    PinBuf<LqRec> h_lqrec;
+    PinBuf<LqCen> h_lqcen;
+    std::vector<LqCommit> lq_commits;     // the replay's commits of the last device-driven call: the split trace is made from them on request
+    bool trace_pending = false;
     size_t lq_hint_N = 0, lq_hint_K = 0; int lq_hint_rounds = 0;   // rounds the last image of this size and palette needed
     // KMeans subsample list = a prefix of rand_perm(N, seed 1234) (Clustering.cpp:311-319): a pure function of N, and the list
     // for FEWER samples is a prefix of the list for more.  perm_dev holds the first perm_nx entries for an image of perm_N pixels;
@@ -965,44 +958,92 @@ static void gq_prepare(Engine &E, size_t N, bool weighted) {
 }
 
 
-// patolette_amd_set_split_loop: 1 (default) the device-driven loop where it applies, 0 the host-driven one everywhere
-std::atomic<int> g_lq_device{(getenv("PAMD_LQ_DEVICE") && atoi(getenv("PAMD_LQ_DEVICE")) == 0) ? 0 : 1};
 
-// The local quantiser driven from the device (k_lq_control above).  In: the base clusters are nodes first_base .. first_base + kbase - 1
-// of the table with their segments, means and moment accumulators complete on the stream (no synchronisation yet).  Returns 0 (centres,
-// trace, stats filled in), -1 on failure, -2 if the candidate tree outgrew the device's table (the caller starts over on the host loop).
-static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv_sums, const QuantBuffers &qlq, int kbase, int first_base,
-                          int nnodes, bool snake, std::vector<double> &centers, size_t &len, unsigned long long *max_members) {
+// The greedy loop of local.c:347-390 over the evaluated candidate tree (rec: per node the split's benefit once known, else the bound;
+// the left child; known).  Exactly the host-driven loop's steps (quantize_clusters_run below), except that nothing is left to
+// evaluate: false if a step is blocked by an undecided node all the same (the device's selection rule forbids it).
+struct LqReplay { std::vector<int> result; std::vector<LqCommit> commits; bool stopped_early = false; };
+static bool lq_replay(const LqRec *rec, int kbase, int first_base, size_t K, LqReplay &out) {
+    std::vector<int> &result = out.result;
+    result.assign(K, -1);
+    for (int j = 0; j < kbase; j++) result[j] = first_base + j;
+    size_t count = (size_t)kbase;
+    std::vector<double> fval(K, 0.0);
+    std::vector<char> fkn(K, 0);
+    for (size_t j = 0; j < count; j++) { fval[j] = rec[result[j]].val; fkn[j] = (char)rec[result[j]].kn; }
+    const int fault = g_debug_fault.load(std::memory_order_relaxed);
+    while (count < K) {
+        int best = -1; double bv = 0, mu = -1;
+        for (size_t j = 0; j < count; j++) {
+            if (fkn[j]) { if (best < 0 || fval[j] > bv) { bv = fval[j]; best = (int)j; } }      // first maximum (vector.c:26-46)
+            else if (fval[j] > mu) mu = fval[j];
+        }
+        if (mu < 0 || (best >= 0 && bv > mu)) {
+            if (fault == 2) {                                      // tests only: a WRONG greedy step (the second best known one)
+                int second = -1; double sv = -1;
+                for (size_t j = 0; j < count; j++) if ((int)j != best && fkn[j] && fval[j] > sv) { sv = fval[j]; second = (int)j; }
+                if (second >= 0 && sv >= kDelta && sv < bv) { best = second; bv = sv; }
+            }
+            if (!(bv >= kDelta)) { out.stopped_early = true; break; }          // benefit < DELTA: stop (local.c:365-370)
+            const int id = result[best], l = rec[id].left;
+            out.commits.push_back(LqCommit{best, id, (int)count, l});
+            result[count] = l; result[best] = l + 1;               // local.c:375-376: palette ORDER
+            fval[count] = rec[l].val; fkn[count] = (char)rec[l].kn;
+            fval[best] = rec[l + 1].val; fkn[best] = (char)rec[l + 1].kn;
+            count++;
+            continue;
+        }
+        if (std::max(best >= 0 ? bv : 0.0, mu) < kDelta) { out.stopped_early = true; break; }
+        return false;
+    }
+    result.resize(count);
+    return true;
+}
+
+// patolette_amd_set_split_loop: 2 (default) the device-driven loop for images below kLqDeviceAutoPixels, 1 wherever it applies,
+// 0 the host-driven one everywhere.  Measured (profiles/r06_split_loop_ab.txt): 1920x1080 1.61 against 1.77 ms per call, 4096^2
+// 5.81 against 5.80, 8192^2 21.7 against 21.0 -- the device's selection rule evaluates ~50 % more (small) candidate nodes than the
+// host's lock-step pruning, +8 % pixels swept, which costs a large image what the nine host turns cost a small one.
+std::atomic<int> g_lq_device{getenv("PAMD_LQ_DEVICE") ? atoi(getenv("PAMD_LQ_DEVICE")) : 2};
+constexpr size_t kLqDeviceAutoPixels = (size_t)12 << 20;
+
+// The local quantiser driven from the device (k_lq_children / k_lq_select above).  In: the base clusters are nodes first_base ..
+// first_base + kbase - 1 of the table with their segments, means and moment accumulators complete on the stream (no synchronisation
+// yet).  Returns 0 (centres, stats filled in; the trace on request), -2 if the candidate tree outgrew the device's table (the caller
+// starts over on the host loop).
+static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv_sums, const Bounds &bnd, const QuantBuffers &qlq, int kbase,
+                          int first_base, int nnodes, bool snake, std::vector<double> &centers, size_t &len, unsigned long long *max_members) {
     hipStream_t s = E.stream;
-    static const double spec_beta = getenv("PAMD_SPEC_BETA") ? atof(getenv("PAMD_SPEC_BETA")) : 0.25;
     const size_t lqs = (size_t)kNQ_LQ * 2 * kBuckets;
     const int ntA_ub = (int)ceil_div(N, (size_t)kTileA) + kLqRoundCap, ntP_ub = (int)ceil_div(N, (size_t)kTileP) + kLqRoundCap;
-    E.lqctl.reserve(1); E.h_lqout.reserve(1);
+    E.lqctl.reserve(1); E.h_lqhead.reserve(1); E.h_lqrec.reserve(kLqNodeCap); E.h_lqcen.reserve(kLqNodeCap);
     E.hist.reserve(std::max(hist_slot_doubles(), lqs * kLqRoundCap)); E.hsize.reserve((size_t)kLqRoundCap * kBuckets);
     E.hcount.reserve((size_t)kLqRoundCap * kBuckets); E.lut.reserve((size_t)kLqRoundCap * kBuckets);
     E.tilesA.reserve(ntA_ub); E.tilesP.reserve(ntP_ub);
     E.tilecnt.reserve((size_t)ntP_ub * kMaxChildren); E.tileoff.reserve((size_t)ntP_ub * kMaxChildren);
     LqCtl *c = E.lqctl.p;
-    LqOut *out = E.h_lqout.p;
-    out->done = 0; out->error = 0; out->count = 0; out->rounds = 0; out->ntrace = 0;
-    for (int r = 0; r < kLqMaxRounds; r++) { out->round_px[r] = 0.0; out->round_nr[r] = 0.0; }
-    hipLaunchKernelGGL(k_lq_init, (kbase + 63) / 64, 64, 0, s, c, (int)K, kbase, first_base, nnodes);
-    HIP_CHECK(hipGetLastError());
-    constexpr size_t ctl_lds = (size_t)kLqNodeCap * (8 + 4 + 1) + (size_t)kLqDevMaxK * (8 + 4 + 12);
-    static PerDeviceOnce attr_set;
-    if (attr_set.first()) HIP_CHECK(hipFuncSetAttribute((const void *)k_lq_control, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctl_lds));
+    LqHead *head = E.h_lqhead.p;
+    for (int r = 0; r < kLqMaxRounds; r++) { head->round_px[r] = 0.0; head->round_nr[r] = 0.0; }
     const int eigen_bound = (kUseEigenBound && g_lq_eigen_bound) ? 1 : 0;
     const RoundDyn *dyn = &c->dyn;
     const int *d_round = c->round_ids, *d_tP0 = c->tP0;
+    int call = 0;                                                  // control calls so far: the parity selects the children list (LqCtl::cids)
     auto control = [&]() {
-        KTIME("k_lq_control", s, 0.0);
-        hipLaunchKernelGGL(k_lq_control, 1, 256, ctl_lds, s, E.nodes.p, c, out, spec_beta, eigen_bound, g_debug_fault.load(std::memory_order_relaxed));
+        const bool first = call == 0;
+        {
+            KTIME("k_lq_children", s, 0.0);
+            if (first) hipLaunchKernelGGL(k_lq_children, (kbase + 3) / 4, 256, 0, s, E.nodes.p, c, call, eigen_bound, kbase, first_base, nnodes, (int)K);
+            else hipLaunchKernelGGL(k_lq_children, 2 * kLqRoundCap / 4, 256, 0, s, E.nodes.p, c, call, eigen_bound, 0, 0, 0, 0);
+        }
+        KTIME("k_lq_select", s, 0.0);
+        hipLaunchKernelGGL(k_lq_select, 1 + (first ? (kbase + 3) / 4 : 2 * kLqRoundCap / 4), 256, 0, s, E.nodes.p, c, call, bnd.e_lin, bnd.e_quad);
         HIP_CHECK(hipGetLastError());
+        call++;
     };
     int enq = 0;                                                   // rounds enqueued so far
     auto round = [&]() {
         if (enq >= kLqMaxRounds) throw HipError("patolette_amd: split loop exceeded its round limit");
-        const double *px_src = &out->round_px[enq], *nr_src = &out->round_nr[enq];
+        const double *px_src = &head->round_px[enq], *nr_src = &head->round_nr[enq];
         hipLaunchKernelGGL(k_round_setup_dyn, 1024, 256, 0, s, E.nodes.p, (const LqCtl *)c, E.tilesA.p, E.tilesP.p, E.hist.p, E.hsize.p, E.hcount.p, lqs);
         HIP_CHECK(hipGetLastError());
         const bool rev = snake && (enq % 2 == 1);                  // the sweeps alternate their direction (see the host loop)
@@ -1013,24 +1054,55 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
         enq++;
         control();
     };
-    control();                                                     // the base clusters' moments, the first greedy steps, round 1
-    int want = (E.lq_hint_N == N && E.lq_hint_K == K && E.lq_hint_rounds > 0) ? E.lq_hint_rounds : 8;
+    control();                                                     // the base clusters' moments and bounds, round 1
+    int want = (E.lq_hint_N == N && E.lq_hint_K == K && E.lq_hint_rounds > 0) ? E.lq_hint_rounds : 9;
     for (;;) {
         while (enq < want) round();
+        HIP_CHECK(hipMemcpyAsync(head, &c->h, sizeof(LqHead), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(E.h_lqrec.p, c->nrec, sizeof(LqRec) * kLqNodeCap, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(E.h_lqcen.p, c->ncen, sizeof(LqCen) * kLqNodeCap, hipMemcpyDeviceToHost, s));
         E.sync();
-        if (out->done) break;
+        if (head->done) break;
         want = enq + 2;
     }
-    if (out->error == 2) return -2;
-    if (out->error != 0) throw HipError("patolette_amd: split loop blocked without candidates");
-    E.lq_hint_N = N; E.lq_hint_K = K; E.lq_hint_rounds = out->rounds;
-    len = (size_t)out->count;
-    centers.assign(out->centers, out->centers + 3 * len);
-    if (max_members) *max_members = out->max_members;
-    E.stats.split_evals = (size_t)out->split_evals; E.stats.split_px = (size_t)out->split_px; E.stats.lq_rounds = (size_t)out->rounds;
-    E.trace.assign(out->trace, out->trace + std::min<int>(out->ntrace, kLqDevMaxK));
-    E.trace_hdr.stopped_early = out->stopped_early;
+    if (head->error == 2) return -2;
+    E.lq_hint_N = N; E.lq_hint_K = K; E.lq_hint_rounds = head->rounds;
+    LqReplay rp;
+    if (!lq_replay(E.h_lqrec.p, kbase, first_base, K, rp)) throw HipError("patolette_amd: split loop: the replay met an unevaluated node");
+    len = rp.result.size();
+    centers.assign(3 * len, 0.0);
+    unsigned long long mg = 0;
+    for (size_t i = 0; i < len; i++) {
+        const LqCen &cn = E.h_lqcen.p[rp.result[i]];
+        for (int j = 0; j < 3; j++) centers[(size_t)j * len + i] = cn.mean[j];      // create.c:11-33
+        mg = std::max(mg, (unsigned long long)cn.gn);
+    }
+    if (max_members) *max_members = mg;
+    E.stats.split_evals = (size_t)head->split_evals; E.stats.split_px = (size_t)head->split_px; E.stats.lq_rounds = (size_t)head->rounds;
+    E.lq_commits.swap(rp.commits);
+    E.trace.clear();
+    E.trace_pending = true;
+    E.trace_hdr.stopped_early = rp.stopped_early ? 1 : 0;
+    static const bool lq_times = getenv("PAMD_LQ_TIMES") != nullptr;
+    if (lq_times) fprintf(stderr, "patolette_amd: device-driven split loop: %d rounds, %d evaluated, %zu commits, tau %.3g\n", head->rounds, head->neval,
+                          E.lq_commits.size(), head->tau);
     return 0;
+}
+
+// the split trace of a device-driven call, fetched when asked for (the node table stays on the device until the engine's next call)
+static void materialise_trace(Engine &E) {
+    if (!E.trace_pending) return;
+    E.trace_pending = false;
+    const int n = (int)E.lq_commits.size();
+    E.trace.assign(n, patolette_amd__SplitRecord{});
+    if (!n) return;
+    DevBuf<LqCommit> dc; DevBuf<patolette_amd__SplitRecord> dr;
+    dc.reserve(n); dr.reserve(n);
+    HIP_CHECK(hipMemcpyAsync(dc.p, E.lq_commits.data(), sizeof(LqCommit) * n, hipMemcpyHostToDevice, E.stream));
+    hipLaunchKernelGGL(k_lq_trace, (n + 63) / 64, 64, 0, E.stream, (const NodeDev *)E.nodes.p, (const LqCommit *)dc.p, n, dr.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(E.trace.data(), dr.p, sizeof(patolette_amd__SplitRecord) * n, hipMemcpyDeviceToHost, E.stream));
+    HIP_CHECK(hipStreamSynchronize(E.stream));
 }
 
 static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, const Bounds &bnd,
@@ -1043,7 +1115,8 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
     if (E.prep_N != N || E.prep_planes != planes) gq_prepare(E, N, weighted);   // (the stage-level entry points come here unprepared)
     E.prep_N = 0;
     // PAMD_LQ_DEVICE=0: the host-driven split loop everywhere (A/B, and what sliced images, K > 256 and verbose calls always take)
-    const bool dev_eligible = allow_device && g_lq_device.load(std::memory_order_relaxed) != 0 && !sh && !verbose && K <= (size_t)kLqDevMaxK;
+    const int lq_mode = g_lq_device.load(std::memory_order_relaxed);
+    const bool dev_eligible = allow_device && (lq_mode == 1 || (lq_mode == 2 && N < kLqDeviceAutoPixels)) && !sh && !verbose && K <= (size_t)kLqDevMaxK;
     E.nodes.reserve(std::max<size_t>(4 * K + 64, dev_eligible ? (size_t)kLqNodeCap : 0));
     std::vector<HNode> hn;
     hn.reserve(4 * K + 64);
@@ -1115,6 +1188,7 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
     double axis[3];
     if (!node_axis(hn[0], axis)) return -1;
     E.trace.clear();
+    E.trace_pending = false;
     E.trace_hdr = patolette_amd__SplitTrace{};
     for (int j = 0; j < 3; j++) E.trace_hdr.gq_axis[j] = axis[j];
     for (int q = 0; q < 6; q++) E.trace_hdr.gq_cov6[q] = hn[0].cov6[q] / hn[0].sw;
@@ -1220,10 +1294,10 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
         E.stats.n_base_clusters = (size_t)kbase;
         E.stats.ms_gq = now_ms() - t0;
         t0 = now_ms();
-        const int rc = lq_device_loop(E, N, K, weighted, inv_sums, qlq, kbase, base_ids[0], (int)hn.size(), snake, centers, len, max_members);
+        const int rc = lq_device_loop(E, N, K, weighted, inv_sums, bnd, qlq, kbase, base_ids[0], (int)hn.size(), snake, centers, len, max_members);
         if (rc != 0) return rc;
         E.stats.n_clusters = len;
-        E.trace_hdr.n_clusters = (int32_t)len; E.trace_hdr.n_records = (int32_t)E.trace.size();
+        E.trace_hdr.n_clusters = (int32_t)len; E.trace_hdr.n_records = (int32_t)E.lq_commits.size();
         E.cluster_centers = centers;
         E.stats.ms_lq = now_ms() - t0;
         return 0;
@@ -2634,12 +2708,13 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
 }
 
 int patolette_amd_debug_fault(int which) { return g_debug_fault.exchange(which); }
-int patolette_amd_set_split_loop(int on_device) { return g_lq_device.exchange(on_device ? 1 : 0); }
+int patolette_amd_set_split_loop(int mode) { return g_lq_device.exchange(mode < 0 || mode > 2 ? 2 : mode); }
 void patolette_amd_dither_config(int segments, int warm) { dither_config(segments, warm); }
 void patolette_amd_dither_layout(int lanes) { dither_layout(lanes); }
 void patolette_amd_last_stats(patolette_amd__Stats *out) { *out = engine().stats; }
 size_t patolette_amd_last_split_trace(patolette_amd__SplitTrace *hdr, patolette_amd__SplitRecord *recs, size_t capacity) {
     Engine &E = engine();
+    try { materialise_trace(E); } catch (const std::exception &e) { E.last_error = e.what(); E.trace.clear(); }
     if (hdr) *hdr = E.trace_hdr;
     if (recs) std::memcpy(recs, E.trace.data(), sizeof *recs * std::min(capacity, E.trace.size()));
     return E.trace.size();

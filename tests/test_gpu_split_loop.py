@@ -1,7 +1,8 @@
-"""The split loop of the local quantiser (lib/src/quantize/local.c:318-404) driven from the DEVICE (pipeline.hip k_lq_control: the
-children's eigen-solves, the greedy replay of local.c:347-390 and the next round's node list in one single-block kernel, no host turn
-between rounds) against the host-driven loop: the same decisions -- split trace record for record -- the same centres bit for bit, the
-same number of evaluations, and both equal to the oracle."""
+"""The split loop of the local quantiser (lib/src/quantize/local.c:318-404) driven from the DEVICE (pipeline.hip k_lq_children /
+k_lq_select: the children's moments, bounds and eigen-solves and the next round's node list made on the device, round after round
+without a host turn; the greedy loop of local.c:347-390 replayed once at the end) against the host-driven loop: the same decisions --
+split trace record for record -- the same centres, palette and map bit for bit, and both equal to the oracle.  Only the SET of
+evaluated candidate nodes may differ (the device's selection rule is exact-safe, the host's a heuristic checked in lock-step)."""
 import numpy as np
 import pytest
 
@@ -14,6 +15,24 @@ pytestmark = pytest.mark.gpu
 def loop(gpu):
     yield lambda on_device: gpu.patolette_amd_set_split_loop(on_device)
     gpu.patolette_amd_set_split_loop(1)
+
+
+def _same_decisions(ta, tb):
+    """Two split traces take the same decisions: header and every record equal, the moments (distortions, covariance, hence
+    benefit and axis) to 1e-12 relative -- the children's centred sums are taken per run of tiles before they are split onto the
+    exact grids, so their last bits move with the round's tile list, which the two drivers compose differently."""
+    if any(ta[k] != tb[k] for k in ta if k not in ("splits", "gq_axis", "gq_cov6")) or len(ta["splits"]) != len(tb["splits"]):
+        return False
+    for a, b in zip(ta["splits"], tb["splits"]):
+        for k in ("row", "new_row", "split", "degenerate", "n", "n_left", "n_right", "sw"):
+            if a[k] != b[k]:
+                return False
+        for k in ("dist", "dist_left", "dist_right", "benefit"):
+            if abs(a[k] - b[k]) > 1e-12 * max(abs(a["dist"]), 1e-300):
+                return False
+        if not np.allclose(a["axis"], b["axis"], rtol=0, atol=1e-9) or not np.allclose(a["cov6"], b["cov6"], rtol=1e-10, atol=1e-300):
+            return False
+    return True
 
 
 def _run(p, native, w, h, colors, K, cs, wts):
@@ -41,9 +60,9 @@ def test_device_driven_loop_equals_host_driven_loop(gpu, native, ob, loop, seed)
         loop(1)
         pal_d, map_d, tr_d, cen_d, st_d = _run(p, native, w, h, colors, K, cs, wts)
         desc = (seed, case, w, h, kind, K, cs, wts is not None)
-        assert tr_h == tr_d, desc
+        assert _same_decisions(tr_h, tr_d), desc
         assert np.array_equal(cen_h, cen_d) and np.array_equal(pal_h, pal_d) and np.array_equal(map_h, map_d), desc
-        for key in ("n_base_clusters", "n_clusters", "split_evals", "split_px", "lq_rounds"):
+        for key in ("n_base_clusters", "n_clusters"):
             assert st_h[key] == st_d[key], (desc, key, st_h[key], st_d[key])
         rounds.append(st_d["lq_rounds"])
     assert max(rounds) >= 3
@@ -61,9 +80,8 @@ def test_device_driven_loop_at_bench_sizes(gpu, native, ob, loop):
         pal_h, map_h, tr_h, cen_h, st_h = _run(p, native, w, h, colors, 256, cs, wts)
         loop(1)
         pal_d, map_d, tr_d, cen_d, st_d = _run(p, native, w, h, colors, 256, cs, wts)
-        assert tr_h == tr_d and np.array_equal(pal_h, pal_d) and np.array_equal(map_h, map_d)
-        assert st_h["split_evals"] == st_d["split_evals"] and st_h["lq_rounds"] == st_d["lq_rounds"]
+        assert _same_decisions(tr_h, tr_d) and np.array_equal(pal_h, pal_d) and np.array_equal(map_h, map_d)
         ec, pal_o, map_o = ob.patolette(w, h, flat, wts, 256, dither=False, color_space=cs, kmeans_niter=0)
         assert ec == 0 and np.allclose(pal_d, pal_o, rtol=0, atol=1e-9) and np.array_equal(map_d, map_o)
-        print("%dx%d: %d rounds, %d evaluations; ms_lq host loop %.3f, device loop %.3f" %
-              (w, h, st_d["lq_rounds"], st_d["split_evals"], st_h["ms_lq"], st_d["ms_lq"]))
+        print("%dx%d: host loop %d rounds, %d evaluations, ms_lq %.3f; device loop %d rounds, %d evaluations, ms_lq %.3f" %
+              (w, h, st_h["lq_rounds"], st_h["split_evals"], st_h["ms_lq"], st_d["lq_rounds"], st_d["split_evals"], st_d["ms_lq"]))
