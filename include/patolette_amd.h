@@ -264,9 +264,19 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
  * single serial chain) and `warm` in-image pixels of speculative warm-up per run (< 0 = default; 0 forces every boundary to be
  * repaired).  The map is the reference's chain bit for bit for every setting. */
 void patolette_amd_dither_config(int segments, int warm);
-/* ... and which layout walks the runs (process-wide): 1 / -1 = one LANE per run wherever it applies (8 <= palette rows <= 256,
- * images of 65 536 pixels and more: the default), 0 = one WAVEFRONT per run everywhere.  Same map either way. */
+/* ... and which layout walks the runs (process-wide, 8 <= palette rows <= 256): -1 (default) = one LANE per run for images of
+ * 2^23 pixels and more, one WAVEFRONT per run below; 1 = lanes from 65 536 pixels on; 0 = wavefronts everywhere.  Same map. */
 void patolette_amd_dither_layout(int lanes);
+/* TESTS ONLY: after `cap` passes taken by one wavefront alone the lane layout gives the image up and the wavefront layout starts
+ * over (default 4096, never reached in practice; 0 forces that fall-back at the first stall); < 0 restores the default.  Returns
+ * the previous value. */
+int patolette_amd_debug_dither_solo_cap(int cap);
+/* TESTS ONLY: verification passes without progress (fewer than an eighth of the failing boundaries fixed) after which ONE wavefront
+ * walks alone from the lowest failing boundary (default 2; 0 = every repair pass is such a walk); < 0 restores the default.
+ * Returns the previous value.  The map is the reference's chain for every setting. */
+int patolette_amd_debug_dither_stall_passes(int n);
+/* which layout a dither of this image size and palette takes under the current knobs: 1 = one lane per run, 0 = one wavefront per run */
+int patolette_amd_dither_layout_in_use(size_t width, size_t height, size_t palette_rows);
 /* Where the dither cuts the curve (host-side copy of the kernel's function, runs without a GPU): *d = first curve position of the
  * aligned 64-position block that holds in-image pixel number t (curve order, 0-based), *c = in-image pixels before that block. */
 void patolette_amd_debug_dither_locate(size_t width, size_t height, unsigned long long t, unsigned long long *d, unsigned long long *c);
@@ -284,6 +294,8 @@ typedef struct patolette_amd__Stats {
     size_t dither_repairs;    /* runs walked again because their speculative starting state was not the chain's */
     size_t dither_rounds;     /* boundary-verification passes (the last one found nothing to repair) */
     size_t dither_through;    /* stalled verifications (a long flat stretch off the palette) resolved by walking one run through its successors */
+    size_t dither_jumps;      /* lane layout: periodic jumps -- a walk over pixels of ONE colour found its period and wrote the pattern to the stretch's end */
+    size_t dither_solo;       /* lane layout: passes taken by one wavefront alone after two passes without progress */
 } patolette_amd__Stats;
 void patolette_amd_last_stats(patolette_amd__Stats *out);
 /* The palette exactly as the mapping stage of the last full-path call on this thread used it: linear Rec2020 when dithering

@@ -25,7 +25,7 @@ class Stats(C.Structure):
                                           "ms_kmeans", "ms_map", "ms_download", "ms_saliency")] + \
                [(n, C.c_size_t) for n in ("n_base_clusters", "n_clusters", "split_evals", "split_px",
                                           "lq_rounds", "kmeans_samples", "dither_segments", "dither_repairs",
-                                          "dither_rounds", "dither_through")]
+                                          "dither_rounds", "dither_through", "dither_jumps", "dither_solo")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -116,6 +116,9 @@ SYMBOLS = {
     "patolette_amd_dither": (C.c_int, [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp]),
     "patolette_amd_dither_config": (None, [C.c_int, C.c_int]),
     "patolette_amd_dither_layout": (None, [C.c_int]),
+    "patolette_amd_debug_dither_solo_cap": (C.c_int, [C.c_int]),
+    "patolette_amd_debug_dither_stall_passes": (C.c_int, [C.c_int]),
+    "patolette_amd_dither_layout_in_use": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t]),
     "patolette_amd_debug_dither_locate": (None, [C.c_size_t, C.c_size_t, C.c_ulonglong, C.POINTER(C.c_ulonglong),
                                                  C.POINTER(C.c_ulonglong)]),
     "patolette_amd_last_stats": (None, [C.POINTER(Stats)]),

@@ -22,6 +22,8 @@ struct NNWork {                        // scratch of the pruned NN map
     DevBuf<unsigned char> dflag;       // ... [S + 1] which boundaries the last check listed
     size_t dither_segments = 0, dither_repairs = 0, dither_rounds = 0;   // of the last launch_dither
     size_t dither_through = 0;         // ... times a stalled verification was resolved by walking one run through its successors
+    size_t dither_jumps = 0;           // ... periodic jumps through flat stretches (lane layout's repair walks)
+    size_t dither_solo = 0;            // ... passes taken by one wavefront alone (lane layout)
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;   // lane-per-run dither: the record grids are built here while the pixels are gathered
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     int side_dev = -1;
@@ -43,12 +45,16 @@ void launch_nn_map(const double *d_colors, size_t plane_stride, size_t n, const 
 // (dither_lane_layout) converts on the fly; h_pal: the same palette on the host if the caller has it (else it is read back)
 bool dither_lane_layout(size_t width, size_t height, int k);
 void launch_dither(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,
-                   void *d_out, int elem_bytes, NNWork &w, hipStream_t s);
+                   void *d_out, int elem_bytes, NNWork &w, hipStream_t s, int layout = -1);   // layout: 1 lanes, 0 wavefronts, -1 decide here
 
 // test / tuning knob: runs the curve is cut into (0 = chosen from the image size) and in-image pixels of warm-up (< 0 = default)
 void dither_config(int segments, int warm);
 // which layout walks the runs: 1 = one lane per run where it applies (default), 0 = one wavefront per run, -1 = default
 void dither_layout(int lanes);
+// tests: solo passes after which the lane layout gives up and the wavefront layout takes the image (default 4096, never reached);
+// returns the previous value
+int dither_solo_cap(int cap);
+int dither_stall_passes(int n);
 // keep the curve order of an image size on the device between calls (default) or make it again in every call
 void dither_order_cache(bool on);
 

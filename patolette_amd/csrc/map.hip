@@ -19,6 +19,7 @@
 #include "dither_slots.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <type_traits>
 
@@ -1435,7 +1436,7 @@ struct DitherLanes {
     const double *sx, *sy, *sz;          // pixels, transposed layout
     unsigned char *smap;                 // choices, transposed layout
     unsigned short *side;                // [S][16] the choices a run's starting queue was built from (0xFFFF = none: the run is walked again)
-    unsigned *list;                      // runs whose boundary check failed; list[-1] = how many
+    unsigned *list;                      // runs whose boundary check failed; list[-1] = how many; list[-2] counts the periodic jumps taken (a statistic)
     unsigned char *flag;                 // [S + 1] the same per run: 1 = listed by the last check
     int solo;                            // k_dither_lane_repair: one wavefront alone, from the lowest listed boundary through everything in its way
     unsigned warm;                       // <= the shortest run
@@ -1934,6 +1935,7 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
         return 0u;
     };
     auto jump = [&](const unsigned P) {
+        if (lane == 0) atomicAdd(a.list - 2, 1u);                   // patolette_amd__Stats::dither_jumps
         unsigned step = T, p = base + head - 16u;                   // the next step's number; the run's next position
         const unsigned s1 = (head - 1u) & (kRing - 1);
         const double cx = rpx[s1], cy = rpx[kRing + s1], cz = rpx[2 * kRing + s1];
@@ -2062,12 +2064,18 @@ __global__ __launch_bounds__(64) void k_dither_lane_repair(DitherLanes a, const 
 }
 
 struct DitherConfig { int segments = 0, warm = -1, lanes = -1; };    // 0 / -1 = chosen by launch_dither
-static DitherConfig g_dither_cfg;
-void dither_config(int segments, int warm) { g_dither_cfg.segments = segments; g_dither_cfg.warm = warm; }
-void dither_layout(int lanes) { g_dither_cfg.lanes = lanes; }
+// process-wide knobs, set from any thread while batch workers read them: atomics (a reader takes ONE snapshot per call)
+static std::atomic<int> g_dither_segments{0}, g_dither_warm{-1}, g_dither_lanes{-1};
+static std::atomic<int> g_dither_solo_cap{4096};                     // patolette_amd_debug_dither_solo_cap: solo passes before the lane layout gives up
+static DitherConfig dither_cfg_snapshot() { return DitherConfig{g_dither_segments.load(), g_dither_warm.load(), g_dither_lanes.load()}; }
+void dither_config(int segments, int warm) { g_dither_segments = segments; g_dither_warm = warm; }
+void dither_layout(int lanes) { g_dither_lanes = lanes; }
+int dither_solo_cap(int cap) { return g_dither_solo_cap.exchange(cap < 0 ? 4096 : cap); }
+static std::atomic<int> g_dither_stall_passes{2};                    // passes without progress before one wavefront goes alone (tests: 0 = at once)
+int dither_stall_passes(int n) { return g_dither_stall_passes.exchange(n < 0 ? 2 : n); }
 
 static int current_device() { int d = -1; (void)hipGetDevice(&d); return d; }
-static bool g_dither_order_cache = true;
+static std::atomic<bool> g_dither_order_cache{true};
 void dither_order_cache(bool on) { g_dither_order_cache = on; }
 
 // One lane per run (k_dither_lanes): K in [8, 256], images of 2^16 pixels and more.  h_pal: the palette on the host, planar (k,3).
@@ -2145,7 +2153,7 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     w.dside.reserve(S + 16);
     w.dflag.reserve(S + 64);
     HIP_CHECK(hipMemsetAsync(w.dflag.p, 0, S + 64, s));                 // (the check writes entries 1 .. S - 1; 0 and S stay 0)
-    w.hrep.reserve(1);
+    w.hrep.reserve(2);
     HIP_CHECK(hipMemcpyAsync(w.dtab.p, wp.data(), wp.size() * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));                               // (wp is a local: the copy must have left the host)
     // the two record grids depend on the palette alone, the gather on the image alone: the grids are built on a side stream
@@ -2212,7 +2220,7 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
     HIP_CHECK(hipStreamWaitEvent(s, w.ev_join2, 0));
     a.sx = sx; a.sy = sy; a.sz = sz;
     a.smap = w.dsmap.p; a.side = reinterpret_cast<unsigned short *>(w.dsmap.p + ((cells + 63) & ~(size_t)63));
-    a.list = w.dside.p + 1;
+    a.list = w.dside.p + 2;                                          // [0] jumps taken, [1] failing boundaries, then their list
     a.flag = w.dflag.p;
     a.lut = l1; a.lut2 = l2; a.g = g;
     const size_t lds = (size_t)6 * k * sizeof(double) + (size_t)k * sizeof(float4);
@@ -2221,27 +2229,30 @@ static bool launch_dither_lanes(const double *d_img, size_t plane_stride, int wh
         hipLaunchKernelGGL(k_dither_lanes<0>, (unsigned)ceil_div(S, 256), 256, lds, s, a, d_pal, k, wts);
     }
     HIP_CHECK(hipGetLastError());
-    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0; w.dither_through = 0;
+    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0; w.dither_through = 0; w.dither_jumps = 0; w.dither_solo = 0;
     unsigned prev_nf = 0xFFFFFFFFu;
     int stalled = 0;
+    HIP_CHECK(hipMemsetAsync(w.dside.p, 0, sizeof(unsigned), s));
     for (size_t round = 0; S > 1; round++) {
-        HIP_CHECK(hipMemsetAsync(w.dside.p, 0, sizeof(unsigned), s));
+        HIP_CHECK(hipMemsetAsync(w.dside.p + 1, 0, sizeof(unsigned), s));
         {
             KTIME("k_dither_fix", s, 0.0);
             hipLaunchKernelGGL(k_dither_lane_check, (unsigned)ceil_div(S - 1, 256), 256, 0, s, a);
         }
-        HIP_CHECK(hipMemcpyAsync(w.hrep.p, w.dside.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(w.hrep.p, w.dside.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-        const unsigned nf = *w.hrep.p;
+        const unsigned nf = w.hrep.p[1];
+        w.dither_jumps = w.hrep.p[0];
         w.dither_rounds = round + 1;
         static const bool trace = getenv("PAMD_DITHER_TRACE") != nullptr;      // one line per verification pass on stderr
         if (trace) fprintf(stderr, "patolette_amd: dither, lane layout: pass %zu, %u of %zu boundaries fail\n", round + 1, nf, S - 1);
         if (nf == 0) break;
         stalled = (prev_nf != 0xFFFFFFFFu && nf + std::max(1u, prev_nf / 8) >= prev_nf) ? stalled + 1 : 0;
         prev_nf = nf;
-        const bool solo = stalled >= 2;                              // no progress twice in a row: one wavefront alone, then the passes resume
+        const bool solo = stalled >= g_dither_stall_passes.load(std::memory_order_relaxed);   // no progress twice in a row: one wavefront alone, then the passes resume
         if (solo) {
-            if (++w.dither_through > 4096) return false;            // (never seen; the wavefront layout takes the image then)
+            w.dither_solo++;
+            if (++w.dither_through > (size_t)g_dither_solo_cap.load(std::memory_order_relaxed)) return false;   // (never seen at 4096; the wavefront layout takes the image then)
             stalled = 0; prev_nf = 0xFFFFFFFFu;
         }
         a.solo = solo ? 1 : 0;
@@ -2300,7 +2311,7 @@ static void launch_dither_t(int mode, unsigned blocks, const double *d_img, size
 }
 
 static DitherConfig dither_settings() {
-    DitherConfig cfg = g_dither_cfg;
+    DitherConfig cfg = dither_cfg_snapshot();
     if (const char *e = getenv("PAMD_DITHER_SEGMENTS")) cfg.segments = atoi(e);
     if (const char *e = getenv("PAMD_DITHER_WARM")) cfg.warm = atoi(e);
     if (const char *e = getenv("PAMD_DITHER_LANES")) cfg.lanes = atoi(e);
@@ -2320,12 +2331,13 @@ static void launch_dither_waves(const double *d_img, size_t plane_stride, size_t
                                 void *d_out, int elem_bytes, NNWork &w, hipStream_t s);
 
 void launch_dither(const double *d_img, size_t plane_stride, int which, size_t width, size_t height, const double *d_pal, const double *h_pal, int k,
-                   void *d_out, int elem_bytes, NNWork &w, hipStream_t s) {
+                   void *d_out, int elem_bytes, NNWork &w, hipStream_t s, int layout) {
     if (width * height >> 32) throw HipError("patolette_amd: the dither kernel numbers pixels with 32 bits");
     if (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8) throw HipError("patolette_amd: map element size must be 1, 4 or 8");
     {
         const DitherConfig cfg = dither_settings();
-        if (dither_lane_layout(width, height, k)) {
+        // layout: what the caller decided when it chose the pixels' form (the knobs may change between its look and this one)
+        if (layout >= 0 ? layout != 0 : dither_lane_layout(width, height, k)) {
             DitherWeights wts;
             const double m = std::exp(std::log(16.0) / (16.0 - 1));
             double v = 1;
@@ -2379,9 +2391,7 @@ static void launch_dither_waves(const double *d_img, size_t plane_stride, size_t
     // Runs: two wavefronts per SIMD fill the issue slots of the chip (one chain alone uses ~2/3 of its SIMD's); never shorter than
     // the warm-up -- below that the speculative steps outnumber the useful ones.
     const size_t npix = width * height;
-    DitherConfig cfg = g_dither_cfg;
-    if (const char *e = getenv("PAMD_DITHER_SEGMENTS")) cfg.segments = atoi(e);
-    if (const char *e = getenv("PAMD_DITHER_WARM")) cfg.warm = atoi(e);
+    const DitherConfig cfg = dither_settings();
     DitherSeg sg{};
     sg.warm = cfg.warm >= 0 ? (unsigned)cfg.warm : 1024u;
     size_t S = cfg.segments > 0 ? (size_t)cfg.segments : (size_t)num_cus() * 8;
@@ -2390,7 +2400,7 @@ static void launch_dither_waves(const double *d_img, size_t plane_stride, size_t
     if (std::max(width, height) < 16) S = 1;
     if (S < 1) S = 1;
     sg.S = (unsigned)S;
-    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0; w.dither_through = 0;
+    w.dither_segments = S; w.dither_repairs = 0; w.dither_rounds = 0; w.dither_through = 0; w.dither_jumps = 0; w.dither_solo = 0;
     if (S > 1) {
         w.dside.reserve(16 * S + 16);
         w.hrep.reserve(2);

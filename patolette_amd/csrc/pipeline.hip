@@ -1804,15 +1804,16 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
             if (d_map) {
                 HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                if (dither_lane_layout(width, height, (int)len)) {
+                if (dither_lane_layout(width, height, (int)len)) {               // decided ONCE: launch_dither is told
                     // the pixels go into curve order anyway: their conversion to linear Rec2020 rides on that pass
-                    launch_dither(E.cvt.p, N, pix, width, height, E.dpal.p, pal.data(), (int)len, d_map, map_elem, E.nn, s);
+                    launch_dither(E.cvt.p, N, pix, width, height, E.dpal.p, pal.data(), (int)len, d_map, map_elem, E.nn, s, 1);
                 } else {
                     E.aux.reserve(3 * N);
                     launch_convert(pix, E.cvt.p, E.aux.p, N, nullptr, s);      // plane stride of cvt is N for x,y,z
-                    launch_dither(E.aux.p, N, PAMD_COPY, width, height, E.dpal.p, pal.data(), (int)len, d_map, map_elem, E.nn, s);
+                    launch_dither(E.aux.p, N, PAMD_COPY, width, height, E.dpal.p, pal.data(), (int)len, d_map, map_elem, E.nn, s, 0);
                 }
                 E.stats.dither_segments = E.nn.dither_segments; E.stats.dither_repairs = E.nn.dither_repairs; E.stats.dither_rounds = E.nn.dither_rounds; E.stats.dither_through = E.nn.dither_through;
+    E.stats.dither_jumps = E.nn.dither_jumps; E.stats.dither_solo = E.nn.dither_solo;
             }
             palette_rows(pal, len, hm::color::rec2020_to_srgb);
         } else {                                                               // patolette.c:300-324
@@ -2697,6 +2698,7 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
     HIP_CHECK(hipMemcpy(E.dpal.p, palette, 3 * k * sizeof(double), hipMemcpyHostToDevice));
     launch_dither(E.src.p, n, PAMD_COPY, width, height, E.dpal.p, palette, (int)k, E.dmap.p, 4, E.nn, E.stream);
     E.stats.dither_segments = E.nn.dither_segments; E.stats.dither_repairs = E.nn.dither_repairs; E.stats.dither_rounds = E.nn.dither_rounds; E.stats.dither_through = E.nn.dither_through;
+    E.stats.dither_jumps = E.nn.dither_jumps; E.stats.dither_solo = E.nn.dither_solo;
     E.sync();
     if (std::max(width, height) > 1) {
         std::vector<unsigned int> tmp(n);
@@ -2711,6 +2713,9 @@ int patolette_amd_debug_fault(int which) { return g_debug_fault.exchange(which);
 int patolette_amd_set_split_loop(int mode) { return g_lq_device.exchange(mode < 0 || mode > 2 ? 2 : mode); }
 void patolette_amd_dither_config(int segments, int warm) { dither_config(segments, warm); }
 void patolette_amd_dither_layout(int lanes) { dither_layout(lanes); }
+int patolette_amd_debug_dither_solo_cap(int cap) { return dither_solo_cap(cap); }
+int patolette_amd_debug_dither_stall_passes(int n) { return dither_stall_passes(n); }
+int patolette_amd_dither_layout_in_use(size_t width, size_t height, size_t k) { return dither_lane_layout(width, height, (int)k) ? 1 : 0; }
 void patolette_amd_last_stats(patolette_amd__Stats *out) { *out = engine().stats; }
 size_t patolette_amd_last_split_trace(patolette_amd__SplitTrace *hdr, patolette_amd__SplitRecord *recs, size_t capacity) {
     Engine &E = engine();

@@ -25,7 +25,8 @@ def _d(a):
 @pytest.fixture(params=[1, 0], ids=["lane-per-run", "wavefront-per-run"])
 def cfg(gpu, request):
     """Sets the dither knob for one test and always puts the defaults back.  Every test runs under both layouts: one lane per
-    run wherever it applies (8 <= K <= 256, >= 65 536 pixels; the default) and one wavefront per run everywhere."""
+    run wherever it applies (8 <= K <= 256; from 65 536 pixels on under this knob, from 2^23 by default) and one wavefront per run
+    everywhere."""
     gpu.patolette_amd_dither_layout(request.param)
 
     def set_(segments, warm=-1):
@@ -132,8 +133,11 @@ def test_four_megapixels_default_knob(gpu, native, ob, cfg):
 
 
 @pytest.mark.parametrize("cs,weighted", [(1, True), (2, False), (0, False)])
-def test_full_path_with_dither_on_through_the_c_abi(gpu, native, ob, cs, weighted):
-    """patolette() with dither = true (the reference's default, patolette.c:112): palette and every map entry."""
+def test_full_path_with_dither_on_through_the_c_abi(gpu, native, ob, cfg, cs, weighted):
+    """patolette() with dither = true (the reference's default, patolette.c:112): palette and every map entry -- under both layouts
+    (`cfg`): with one lane per run the conversion of the pixels to linear Rec2020 (patolette.c:274-287) rides on the gather into
+    curve order (k_dither_streams<sRGB | CIELuv | ICtCp>), with one wavefront per run it is a pass of its own."""
+    cfg(0)
     w, h, K = 640, 480, 256
     n = w * h
     flat = ob.image(n, 31)
@@ -179,4 +183,125 @@ def test_flat_stretches_off_the_palette(gpu, native, ob, cfg, shape, k):
         got, st = _dither(gpu, native, flat, w, h, pal)
         assert np.array_equal(got, want), "%s k=%d S=%d: %d mismatches, %s" % (shape, k, seg, int(np.sum(got != want)), st)
         assert st["dither_rounds"] <= 40, st                        # (not one pass per run)
-        print("%s k=%d S=%d: %s" % (shape, k, seg, {q: st[q] for q in ("dither_segments", "dither_repairs", "dither_rounds", "dither_through")}))
+        print("%s k=%d S=%d: %s" % (shape, k, seg, {q: st[q] for q in ("dither_segments", "dither_repairs", "dither_rounds", "dither_through",
+                                                                       "dither_jumps", "dither_solo")}))
+        # the machinery that makes this fast must have RUN (a change that silently disables it keeps the map right, ten times slower):
+        lanes = gpu.patolette_amd_dither_layout_in_use(w, h, pal.shape[0]) == 1
+        if lanes and st["dither_repairs"] > 0:
+            assert st["dither_jumps"] >= 1, st                      # a walk over one colour found its period and wrote the pattern
+        if not lanes and st["dither_rounds"] >= 5:
+            assert st["dither_through"] >= 1, st                    # the stalled passes were answered by a walk through the successors
+
+
+def test_bands_with_many_failing_boundaries(gpu, native, ob, cfg):
+    """Twelve flat bands, twelve palette rows, none of them a band's colour: every band is a periodic stretch with thousands of failing
+    boundaries.  Lane layout: the rows' wavefronts find the period and write the pattern (`dither_jumps`), a handful of passes;
+    wavefront layout: walks through the successors (`dither_through`).  Same map as the serial chain."""
+    w, h, k = 2048, 1536, 12
+    rng = np.random.default_rng(12)
+    pal = rng.random((k, 3))
+    img = np.zeros((h, w, 3))
+    for y0 in range(0, h, h // 12):
+        img[y0:y0 + h // 12] = rng.random(3)
+    flat = np.concatenate([img[:, :, c].reshape(-1) for c in range(3)])
+    want = ob.dither(flat, w, h, pal)
+    cfg(0)
+    got, st = _dither(gpu, native, flat, w, h, pal)
+    print("twelve bands: %s" % {q: st[q] for q in ("dither_segments", "dither_repairs", "dither_rounds", "dither_through", "dither_jumps", "dither_solo")})
+    assert np.array_equal(got, want), (int(np.sum(got != want)), st)
+    if gpu.patolette_amd_dither_layout_in_use(w, h, k) == 1:
+        assert st["dither_jumps"] >= 12 and st["dither_rounds"] <= 8, st
+    else:
+        assert st["dither_through"] >= 1, st
+
+
+@pytest.mark.parametrize("shape", ["bands", "noise+flat"])
+def test_one_wavefront_alone_gives_the_serial_chain(gpu, native, ob, shape):
+    """The lane layout's answer to passes that stop making progress: ONE wavefront from the lowest failing boundary through everything
+    in its way (k_dither_lane_repair, solo).  With the jumps in place no image found so far stalls the passes (tools/diag/solo_probe.py),
+    so the walk is forced here (patolette_amd_debug_dither_stall_passes(0): every repair pass is such a walk) and held to the oracle."""
+    w, h, k = 640, 400, 12
+    rng = np.random.default_rng(21)
+    pal = rng.random((k, 3))
+    img = rng.random((h, w, 3))
+    if shape == "bands":
+        for y0 in range(0, h, 40):
+            img[y0:y0 + 40] = rng.random(3)
+    else:
+        img[h // 3:2 * h // 3] = rng.random(3)
+    flat = np.concatenate([img[:, :, c].reshape(-1) for c in range(3)])
+    want = ob.dither(flat, w, h, pal)
+    gpu.patolette_amd_dither_layout(1)
+    gpu.patolette_amd_dither_config(0, 0)                            # no warm-up: every boundary fails the first check
+    prev = gpu.patolette_amd_debug_dither_stall_passes(0)
+    try:
+        got, st = _dither(gpu, native, flat, w, h, pal)
+    finally:
+        gpu.patolette_amd_debug_dither_stall_passes(prev)
+        gpu.patolette_amd_dither_config(0, -1)
+        gpu.patolette_amd_dither_layout(-1)
+    print("solo %s: %s" % (shape, {q: st[q] for q in ("dither_segments", "dither_repairs", "dither_rounds", "dither_through", "dither_jumps", "dither_solo")}))
+    assert np.array_equal(got, want), (int(np.sum(got != want)), st)
+    assert st["dither_solo"] >= 1, st
+
+
+@pytest.mark.parametrize("k", [8, 64])
+def test_adversarial_checkerboard_of_flat_tiles(gpu, native, ob, cfg, k):
+    """Tiles of one colour shorter than a run, none of the colours a palette entry (2048^2, tile sides 8 .. 64): every run starts inside
+    some flat stretch, the speculative chains settle into the stretch's cycle at the wrong phase and almost every boundary fails the
+    first check.  The map must be the serial chain's bit for bit, and the mapping stage must stay within 25x of what noise costs."""
+    w = h = 2048
+    n = w * h
+    rng = np.random.default_rng(300 + k)
+    pal = rng.random((k, 3))
+    img = np.zeros((h, w, 3))
+    y = 0
+    while y < h:
+        side = int(rng.integers(8, 65))
+        x = 0
+        while x < w:
+            sx = int(rng.integers(8, 65))
+            img[y:y + side, x:x + sx] = rng.random(3)
+            x += sx
+        y += side
+    flat = np.concatenate([img[:, :, c].reshape(-1) for c in range(3)])
+    want = ob.dither(flat, w, h, pal)
+    cfg(0)
+    noise, _ = _noise_case(ob, w, h, k, seed=9)
+    import time
+    _dither(gpu, native, noise, w, h, pal)                          # (warm-up: workspace, curve order)
+    t0 = time.perf_counter()
+    _dither(gpu, native, noise, w, h, pal)
+    t_noise = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    got, st = _dither(gpu, native, flat, w, h, pal)
+    t_adv = time.perf_counter() - t0
+    print("checkerboard k=%d: %.1f ms against %.1f ms for noise; %s" % (k, 1e3 * t_adv, 1e3 * t_noise, {q: st[q] for q in (
+        "dither_segments", "dither_repairs", "dither_rounds", "dither_through", "dither_jumps", "dither_solo")}))
+    assert np.array_equal(got, want), (int(np.sum(got != want)), st)
+    assert t_adv <= 25.0 * t_noise, (t_adv, t_noise, st)
+
+
+def test_lane_layout_gives_up_and_the_wavefront_layout_takes_over(gpu, native, ob):
+    """patolette_amd_debug_dither_solo_cap(0): the lane layout returns at its first stalled pass and the wavefront layout starts the
+    image over (launch_dither's fall-back, with the pixels converted by k_dither_convert) -- through the full path, CIELuv, so that the
+    fall-back's own conversion is what the oracle is compared with."""
+    import patolette_amd as p
+    w, h, K = 1024, 512, 8
+    rng = np.random.default_rng(77)
+    img = np.tile(rng.random(3), (h, w, 1))
+    img[:, 3 * w // 4:] = rng.random((h, w - 3 * w // 4, 3))       # three quarters one flat colour: more colours than palette rows
+    colors = img.reshape(-1, 3)
+    gpu.patolette_amd_dither_layout(1)
+    prev = gpu.patolette_amd_debug_dither_solo_cap(0)
+    try:
+        ok, pal, pmap, msg = p.quantize(w, h, colors, K, dither=True, color_space=p.ColorSpace_CIELuv, tile_size=0, kmeans_niter=0)
+        st = p.last_stats()
+    finally:
+        gpu.patolette_amd_debug_dither_solo_cap(prev)
+        gpu.patolette_amd_dither_layout(-1)
+    assert ok, msg
+    print("forced fall-back: %s" % {q: st[q] for q in ("dither_segments", "dither_repairs", "dither_rounds", "dither_through", "dither_solo")})
+    ec, pal_o, map_o = ob.patolette(w, h, ob.planar(colors), None, K, dither=True, color_space=1, kmeans_niter=0)
+    assert ec == 0 and np.allclose(pal, pal_o, rtol=0, atol=1e-9)
+    assert np.array_equal(pmap, map_o), int(np.sum(pmap != map_o))

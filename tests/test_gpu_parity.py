@@ -629,6 +629,29 @@ def test_chunked_upload_with_overlapped_conversion(gpu, ob, monkeypatch, rows_ma
     assert np.array_equal(pmap, pmap_o)
 
 
+@pytest.mark.parametrize("channels,weighted,hw", [(3, False, (61, 83)), (4, True, (97, 45)), (3, True, (33, 129))])
+def test_u8_entry_chunked_upload_with_overlapped_conversion(gpu, ob, monkeypatch, channels, weighted, hw):
+    """patolette_amd_u8 uploads large 8-bit images in chunks and converts each behind the next one's copy (run_u8: second stream,
+    the statistics started by chunk 0 only); forced here onto small images of odd sizes, 3 and 4 bytes per pixel, with and without
+    explicit weights: identical to the single-copy path and equal to the oracle fed with the by-hand conversion (README.md:156-158)."""
+    import patolette_amd as p
+    h, w = hw
+    rng = np.random.default_rng(5 + channels)
+    img = rng.integers(0, 256, size=(h, w, channels), dtype=np.uint8)
+    wts = (1.0 + 3.0 * rng.random(h * w)) if weighted else None
+    kw = dict(dither=False, color_space=2, tile_size=0, kmeans_niter=2, kmeans_max_samples=65536, weights=wts)
+    ref = p.quantize_u8(img, 40, **kw)
+    monkeypatch.setenv("PAMD_UPLOAD_CHUNK_MIN", "1000")
+    got = p.quantize_u8(img, 40, **kw)
+    assert ref[0] and got[0], (ref[5], got[5])
+    for a, b in zip(ref[1:5], got[1:5]):
+        assert np.array_equal(a, b)
+    flat = ob.planar(img[:, :, :3].reshape(-1, 3).astype(np.float64) / 255)
+    ec, pal_o, map_o = ob.patolette(w, h, flat, wts, 40, dither=False, color_space=2, kmeans_niter=2, kmeans_max_samples=65536)
+    assert ec == 0 and np.allclose(got[4], pal_o, rtol=0, atol=1e-9)
+    assert np.array_equal(got[2].reshape(-1), map_o)
+
+
 def test_u8_adaptor_accepts_torch_cuda_tensor(gpu):
     """A torch CUDA uint8 tensor goes through the device entry point: same results as the numpy path, outputs stay in
     HBM.  Own process: torch has to load its HIP runtime before libpatolette_amd.so does (as bench.py --gpus N does)."""

@@ -307,4 +307,4 @@ def test_c4_full_size_matches_oracle(gpu, native, ob, dither):
     assert rel <= 1e-9
     assert mism == 0
     if dither:
-        assert st["dither_segments"] > 1000 and st["ms_map"] < 60.0          # round-4 VERDICT's bar for the stage (was 15 s)
+        assert st["dither_segments"] > 1000                                   # (the stage's time is bench.py's business: profiles/*_bench_c4.json)
