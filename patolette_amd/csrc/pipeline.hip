@@ -1437,57 +1437,88 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
             static const bool lq_trace = getenv("PAMD_LQ_TRACE") != nullptr;       // one line per split round on stderr
             if (lq_trace) fprintf(stderr, "patolette_amd: split round %zu: %d nodes, %zu pixels (%.2f of the image), %zu of %zu colours committed\n",
                                   E.stats.lq_rounds + 1, nr, rpx, (double)rpx / (double)(N ? N : 1), count, K);
-            // one packet, one copy: node records, ids, tile prefixes of both tilings, children ids
-            std::vector<int> tA0(nr + 1), tP0(nr + 1), cids;
-            tA0[0] = 0; tP0[0] = 0;
-            for (int r = 0; r < nr; r++) {
-                const unsigned long long n = hn[todo[r]].n;
-                tA0[r + 1] = tA0[r] + (int)((n + kTileA - 1) / kTileA);
-                tP0[r + 1] = tP0[r] + (int)((n + kTileP - 1) / kTileP);
+            // one packet, one copy: node records, ids, children ids, then per GROUP of nodes the tile prefixes of both tilings.
+            // One group = the whole round (the default).  PAMD_LQ_CHUNK_MB=m (experiment, profiles/r06_lq_chunk_major.txt): the round
+            // is issued chunk-major -- groups of nodes of <= m MB, each taken through minmax -> hist -> cut -> count -> scan -> scatter
+            // before the next group starts -- so that the second and third read of a node may find it in the Infinity Cache.
+            static const size_t chunk_mb = getenv("PAMD_LQ_CHUNK_MB") ? (size_t)atoi(getenv("PAMD_LQ_CHUNK_MB")) : 0;
+            std::vector<int> gb = {0};                              // group boundaries in todo[]
+            if (chunk_mb > 0 && !sh) {
+                const size_t cap_px = (chunk_mb << 20) / (planes * sizeof(double));
+                size_t acc = 0;
+                for (int r = 0; r < nr; r++) {
+                    const size_t n = hn[todo[r]].n;
+                    if (acc > 0 && acc + n > cap_px) { gb.push_back(r); acc = 0; }
+                    acc += n;
+                }
             }
-            const int ntA = tA0[nr], ntP = tP0[nr];
+            gb.push_back(nr);
+            const int ng = (int)gb.size() - 1;
+            std::vector<int> cids;
             for (int id : todo) { cids.push_back(hn[id].left); cids.push_back(hn[id].right); }
-            const size_t o_recs = 0, o_ids = o_recs + (size_t)nr * sizeof(NodeIn), o_tA0 = o_ids + (size_t)nr * sizeof(int),
-                         o_tP0 = o_tA0 + (size_t)(nr + 1) * sizeof(int), o_cids = o_tP0 + (size_t)(nr + 1) * sizeof(int),
-                         pk_bytes = o_cids + cids.size() * sizeof(int);
+            std::vector<int> tAg, tPg;                               // the groups' prefixes one after the other (nrg + 1 entries each)
+            std::vector<size_t> g_off(ng), g_px(ng);
+            int ntA_max = 0, ntP_max = 0, nrg_max = 0;
+            for (int g = 0; g < ng; g++) {
+                g_off[g] = tAg.size();
+                int a = 0, b = 0; size_t px = 0;
+                tAg.push_back(0); tPg.push_back(0);
+                for (int r = gb[g]; r < gb[g + 1]; r++) {
+                    const unsigned long long n = hn[todo[r]].n;
+                    recs[r].slot = r - gb[g];
+                    a += (int)((n + kTileA - 1) / kTileA); b += (int)((n + kTileP - 1) / kTileP); px += n;
+                    tAg.push_back(a); tPg.push_back(b);
+                }
+                g_px[g] = px;
+                ntA_max = std::max(ntA_max, a); ntP_max = std::max(ntP_max, b); nrg_max = std::max(nrg_max, gb[g + 1] - gb[g]);
+            }
+            const size_t o_recs = 0, o_ids = o_recs + (size_t)nr * sizeof(NodeIn), o_cids = o_ids + (size_t)nr * sizeof(int),
+                         o_tA = o_cids + cids.size() * sizeof(int), o_tP = o_tA + tAg.size() * sizeof(int),
+                         pk_bytes = o_tP + tPg.size() * sizeof(int);
             E.h_packet.reserve(pk_bytes); E.packet.reserve(pk_bytes);
             std::memcpy(E.h_packet.p + o_recs, recs.data(), (size_t)nr * sizeof(NodeIn));
             std::memcpy(E.h_packet.p + o_ids, ids.data(), (size_t)nr * sizeof(int));
-            std::memcpy(E.h_packet.p + o_tA0, tA0.data(), (size_t)(nr + 1) * sizeof(int));
-            std::memcpy(E.h_packet.p + o_tP0, tP0.data(), (size_t)(nr + 1) * sizeof(int));
             std::memcpy(E.h_packet.p + o_cids, cids.data(), cids.size() * sizeof(int));
+            std::memcpy(E.h_packet.p + o_tA, tAg.data(), tAg.size() * sizeof(int));
+            std::memcpy(E.h_packet.p + o_tP, tPg.data(), tPg.size() * sizeof(int));
             lap(tm_packet);
             HIP_CHECK(hipMemcpyAsync(E.packet.p, E.h_packet.p, pk_bytes, hipMemcpyHostToDevice, s));
             const size_t lqs = (size_t)kNQ_LQ * 2 * kBuckets;
-            E.hist.reserve(std::max(hs, lqs * nr)); E.hsize.reserve((size_t)nr * kBuckets); E.hcount.reserve((size_t)nr * kBuckets);
-            E.lut.reserve((size_t)nr * kBuckets);
-            E.tilesA.reserve(ntA); E.tilesP.reserve(ntP);
-            E.tilecnt.reserve((size_t)ntP * kMaxChildren); E.tileoff.reserve((size_t)ntP * kMaxChildren);
-            const int *d_ids = (const int *)(E.packet.p + o_ids), *d_tP0 = (const int *)(E.packet.p + o_tP0);
-            RoundSetup rs{(const NodeIn *)(E.packet.p + o_recs), d_ids, (const int *)(E.packet.p + o_tA0), d_tP0, nr, ntA, ntP,
-                          E.tilesA.p, E.tilesP.p, E.hist.p, lqs * nr, E.hsize.p, E.hcount.p, (size_t)nr * kBuckets};
-            {
-                const size_t work = std::max<size_t>(std::max<size_t>(std::max<size_t>(ntP, lqs * nr / 4), (size_t)nr * kNodeResetElems), 256);
-                hipLaunchKernelGGL(k_round_setup, (unsigned)std::min<size_t>((work + 255) / 256, 2048), 256, 0, s, E.nodes.p, rs);
-                HIP_CHECK(hipGetLastError());
-            }
+            E.hist.reserve(std::max(hs, lqs * nrg_max)); E.hsize.reserve((size_t)nrg_max * kBuckets); E.hcount.reserve((size_t)nrg_max * kBuckets);
+            E.lut.reserve((size_t)nrg_max * kBuckets);
+            E.tilesA.reserve(ntA_max); E.tilesP.reserve(ntP_max);
+            E.tilecnt.reserve((size_t)ntP_max * kMaxChildren); E.tileoff.reserve((size_t)ntP_max * kMaxChildren);
             // the sweeps of a round alternate their direction through the pixels (the first one runs against the partition that
             // wrote them): each starts on what the previous one touched last.  PAMD_SWEEP_SNAKE=0: all forward
             const bool rev = snake && (E.stats.lq_rounds % 2 == 1);     // (the base clusters' moments were taken back to front)
-            launch_minmax(qlq, E.tilesA.p, ntA, rpx, E.nodes.p, s, rev);
-            if (sh) shard_exchange_keys(E, d_ids, nr);
-            launch_hist(qlq, false, E.tilesA.p, ntA, rpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake && !rev);
-            if (sh) {
-                comm_sum_dev(E, E.hist.p, lqs * nr, 0);
-                if (weighted) comm_sum_dev(E, E.hsize.p, (size_t)nr * kBuckets, 1);
-                comm_sum_dev(E, E.hcount.p, (size_t)nr * kBuckets, 2);
-            }
-            launch_cut(weighted, E.nodes.p, d_ids, nr, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s);
-            launch_partition(qlq, E.tilesP.p, ntP, rpx, d_ids, d_tP0, nr, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s, inv_sums, rev);
-            if (sh) {
-                hipLaunchKernelGGL(k_shard_children_local, (nr + 63) / 64, 64, 0, s, E.nodes.p, d_ids, nr);
-                HIP_CHECK(hipGetLastError());
-                shard_exchange_acc(E, (const int *)(E.packet.p + o_cids), (int)cids.size());
+            for (int g = 0; g < ng; g++) {
+                const int r0 = gb[g], nrg = gb[g + 1] - r0;
+                const int *d_ids = (const int *)(E.packet.p + o_ids) + r0;
+                const int *d_tA0 = (const int *)(E.packet.p + o_tA) + g_off[g], *d_tP0 = (const int *)(E.packet.p + o_tP) + g_off[g];
+                const int ntA = tAg[g_off[g] + nrg], ntP = tPg[g_off[g] + nrg];
+                const size_t gpx = g_px[g];
+                RoundSetup rs{(const NodeIn *)(E.packet.p + o_recs) + r0, d_ids, d_tA0, d_tP0, nrg, ntA, ntP,
+                              E.tilesA.p, E.tilesP.p, E.hist.p, lqs * nrg, E.hsize.p, E.hcount.p, (size_t)nrg * kBuckets};
+                {
+                    const size_t work = std::max<size_t>(std::max<size_t>(std::max<size_t>(ntP, lqs * nrg / 4), (size_t)nrg * kNodeResetElems), 256);
+                    hipLaunchKernelGGL(k_round_setup, (unsigned)std::min<size_t>((work + 255) / 256, 2048), 256, 0, s, E.nodes.p, rs);
+                    HIP_CHECK(hipGetLastError());
+                }
+                launch_minmax(qlq, E.tilesA.p, ntA, gpx, E.nodes.p, s, rev);
+                if (sh) shard_exchange_keys(E, d_ids, nrg);
+                launch_hist(qlq, false, E.tilesA.p, ntA, gpx, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake && !rev);
+                if (sh) {
+                    comm_sum_dev(E, E.hist.p, lqs * nrg, 0);
+                    if (weighted) comm_sum_dev(E, E.hsize.p, (size_t)nrg * kBuckets, 1);
+                    comm_sum_dev(E, E.hcount.p, (size_t)nrg * kBuckets, 2);
+                }
+                launch_cut(weighted, E.nodes.p, d_ids, nrg, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s);
+                launch_partition(qlq, E.tilesP.p, ntP, gpx, d_ids, d_tP0, nrg, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s, inv_sums, rev);
+                if (sh) {
+                    hipLaunchKernelGGL(k_shard_children_local, (nrg + 63) / 64, 64, 0, s, E.nodes.p, d_ids, nrg);
+                    HIP_CHECK(hipGetLastError());
+                    shard_exchange_acc(E, (const int *)(E.packet.p + o_cids) + 2 * r0, 2 * nrg);
+                }
             }
             lap(tm_enqueue);
             get_nodes_dev(E, (const int *)(E.packet.p + o_cids), (int)cids.size(), got);
