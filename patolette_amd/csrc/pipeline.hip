@@ -185,6 +185,9 @@ __global__ __launch_bounds__(256) void k_round_setup(NodeDev *table, RoundSetup 
 // a surplus round is nine empty launches, a deficit one more synchronisation), downloads 16 bytes per node and replays.
 // Same decisions as the host-driven loop: same sums, same solver, same comparisons; only the SET of evaluated nodes differs
 // (a few more: the host prunes with a heuristic a replay in lock-step can afford).
+// what the global quantiser left when it ran on the device (k_gq_control below): base clusters, failure, the cuts [0 = q0 .. q_kbase = 512]
+struct GqOut { int kbase, error, pad[2]; int cuts[16]; unsigned long long ticks[8]; };   // ticks: wall_clock64 (100 MHz) at the kernel's phase boundaries, a diagnostic
+
 constexpr int kLqDevMaxK = 256;                       // palette sizes the device-driven loop takes
 constexpr int kLqNodeCap = 16 * kLqDevMaxK + 256;     // candidate-tree nodes; beyond it the call starts over on the host-driven loop
 constexpr int kLqRoundCap = 512;                      // nodes evaluated per round (more candidates wait for the next one)
@@ -231,17 +234,24 @@ __device__ __forceinline__ double dpp_max_f64(const double v) {
 // (hm::lambda_max_bound x sum of weights: the scatter between two groups along their mean difference cannot exceed the node's
 // scatter along that direction; see leaf_bound).  init_kbase > 0: the call's first launch, which also sets the loop's state up
 // (the base clusters are nodes init_first .. init_first + init_kbase - 1).
-__global__ __launch_bounds__(256) void k_lq_children(NodeDev *nodes, LqCtl *c, const int call, const int eigen_bound, const int init_kbase,
-                                                     const int init_first, const int init_nnodes, const int init_K) {
+__global__ __launch_bounds__(256) void k_lq_children(NodeDev *nodes, LqCtl *c, const int call, const int eigen_bound, int init_kbase,
+                                                     const int init_first, int init_nnodes, const int init_K, const GqOut *gq) {
     const bool init = init_kbase > 0;
     if (!init && c->h.done) return;
+    if (init && gq) { init_kbase = gq->kbase; init_nnodes = init_first + init_kbase; }   // the global quantiser ran on the device (k_gq_control): its count
     const int ncids = init ? init_kbase : c->ncids[call & 1];
     const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (init && blockIdx.x == 0 && threadIdx.x == 0) {
         c->K = init_K; c->M = init_K - init_kbase; c->nleaves = 0; c->ncids[0] = init_kbase; c->dyn = RoundDyn{0, 0, 0, 0};
         c->h.done = 0; c->h.error = 0; c->h.rounds = 0; c->h.nnodes = init_nnodes; c->h.neval = 0; c->h.split_evals = 0ULL; c->h.split_px = 0ULL;
         c->h.tau = 0.0;
+        if (gq && gq->error) { c->h.done = 1; c->h.error = 3; c->ncids[0] = 0; }
+        // the records below the base clusters (the root) belong to no candidate: k_lq_select's rank count runs over ALL records below
+        // nnodes, and what an earlier call or the allocator left there must not pass for an evaluated node (a stale record with a large
+        // priority raised tau by one rank: a leaf the replay needed was dropped -- one call in some hundreds, engines out of the pool)
+        for (int i = 0; i < init_first; i++) { c->nrec[i] = LqRec{0.0, -1, 1}; c->np[i] = 0.0; c->nparent[i] = -1; }
     }
+    if (init && gq && gq->error) return;
     if (wave >= ncids) return;
     const int id = init ? init_first + wave : c->cids[call & 1][wave];
     if (init && lane == 0) c->cids[0][wave] = id;
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256) void k_lq_select(NodeDev *nodes, LqCtl *c, con
     __shared__ int sw[5];
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix, s_px;
-    __shared__ int s_need, s_neval;
+    __shared__ int s_need, s_neval, s_first;
     const int M = c->M;
     const int nn = c->h.nnodes;
     // ---- A. the nodes of the last round are split now: benefit (local.c:256-275) and priority.  A node whose eigen-solve failed a round
@@ -362,11 +372,20 @@ __global__ __launch_bounds__(256) void k_lq_select(NodeDev *nodes, LqCtl *c, con
                 }
             }
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, b = 255;
-                for (; b > 0; b--) { if (acc + (int)hist[b] >= need) break; acc += (int)hist[b]; }
-                s_need = need - acc;
-                s_prefix = prefix | ((unsigned long long)b << shift);
+            // the bin that holds the need-th largest key: the largest b > 0 whose bins b .. 255 hold `need` keys or more (else bin 0).
+            // Thread t takes bin 255 - t: a block scan gives every suffix at once (one thread walking the 256 bins paid an LDS round
+            // trip per bin, three passes a call: ~15 of the launch's 22 us)
+            {
+                const int mine = (int)hist[255 - tid];
+                int total;
+                const int excl = block_excl_scan_256(mine, sw, total);
+                if (tid == 0) s_first = 256;
+                __syncthreads();
+                if (excl + mine >= need && tid <= 254) atomicMin(&s_first, tid);
+                __syncthreads();
+                const int f = s_first;
+                if (f < 256) { if (tid == f) { s_need = need - excl; s_prefix = prefix | ((unsigned long long)(255 - f) << shift); } }
+                else if (tid == 254) { s_need = need - (excl + mine); s_prefix = prefix; }
             }
             __syncthreads();
             need = s_need; prefix = s_prefix;
@@ -451,6 +470,17 @@ __global__ __launch_bounds__(256) void k_lq_select(NodeDev *nodes, LqCtl *c, con
     }
 }
 
+// What the host's replay needs of the loop's state -- the head, 16 bytes per node of the candidate tree and the nodes' centres --
+// stored straight into pinned host memory by one launch (three copy-engine transfers of the full-capacity arrays before)
+__global__ __launch_bounds__(256) void k_lq_export(const LqCtl *c, LqHead *head, LqRec *rec, LqCen *cen) {
+    const int nn = c->h.nnodes;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = t; i < nn; i += stride) { rec[i] = c->nrec[i]; cen[i] = c->ncen[i]; }
+    const double *src = reinterpret_cast<const double *>(&c->h);
+    double *dst = reinterpret_cast<double *>(head);
+    for (int i = t; i < (int)(sizeof(LqHead) / sizeof(double)); i += stride) dst[i] = src[i];
+}
+
 // the split trace's records of a device-driven call, made when somebody asks for them (patolette_amd_last_split_trace): one thread
 // per commit of the replay
 struct LqCommit { int row, node, new_row, left; };
@@ -493,6 +523,268 @@ __global__ __launch_bounds__(256) void k_round_setup_dyn(NodeDev *table, const L
     }
     for (size_t i = tid; i < lqs * (size_t)nr; i += stride) hist[i] = 0.0;
     for (size_t i = tid; i < (size_t)nr * kBuckets; i += stride) { hsize[i] = 0ULL; hcount[i] = 0u; }
+}
+
+// =============================================================================================
+// The global quantiser's decisions on the DEVICE (global.c:189-298, cells.c:114-328; round 6)
+// =============================================================================================
+// Before: eleven DP launches for every k up to 12, three downloads, the host's prefix sums, bias test and backtrack, an upload of
+// the bucket -> cluster table and of the base clusters' records: ~50 us of launches and ~150 us of idle GPU in every call.  Here ONE
+// block does what the host did, in the host's own arithmetic (the same expressions in the same order on the same sums; the
+// eigen-solver is hm::eigen_sym3, compiled for both sides), and the partition follows on the stream without the host looking:
+//   1. the eleven inclusive prefixes of the 512-bucket table, each a sequential chain as cells.c:114-136 builds them (one wavefront
+//      per chain, out of LDS);
+//   2. the principal axis of all buckets (cells.c:225-278);
+//   3. for k = 2 .. 12: the bias termination test on the current cells (global.c:99-187; one wavefront per cell solves its 3x3, one
+//      thread adds up in order), then -- only if the search goes on -- the DP (global.c:232-280): a FULL step k-1 (sixteen
+//      wavefronts, one entry each at a time) and the single entry cut[k][512] the backtrack starts from.  The reference fills the
+//      whole table first; what it reads of it is this.  Same candidates, same strict '<' in descending t (the largest t among equal
+//      minima, t = n-1 first), so the cuts are the reference's.  Noise and most photographs stop at two cells: no full step at all;
+//   4. the bucket -> base cluster table (global.c:328-335) and the base clusters' node records (count, weight, mean from the exact
+//      bucket sums), the root's children.
+// patolette_amd__SplitTrace's header and the host-driven split loop read GqOut after their next synchronisation.
+struct GqTab {                                          // LDS: inclusive prefixes, 1-based (hm::CellMoments)
+    unsigned long long w0[kBuckets + 1];
+    double t[10][kBuckets + 9];                         // 0..2 w1[r], 3 w2, 4..9 wrs (00,01,11,02,12,22); + 8: the chains read ahead
+    __device__ double distortion(int a, int b) const {  // cells.c:141-182
+        if (w0[a] == w0[b]) return 0;
+        const double q0 = t[0][b] - t[0][a], q1 = t[1][b] - t[1][a], q2 = t[2][b] - t[2][a];
+        return t[3][b] - t[3][a] - (q0 * q0 + q1 * q1 + q2 * q2) / (double)(w0[b] - w0[a]);
+    }
+    __device__ double vcov(int a, int b, int r, int s) const {   // cells.c:184-223
+        if (w0[a] == w0[b]) return 0;
+        const double cnt = (double)(w0[b] - w0[a]);
+        const int rs = 4 + s * (s + 1) / 2 + r;
+        return (t[rs][b] - t[rs][a]) / cnt - (t[r][b] - t[r][a]) * (t[s][b] - t[s][a]) / (cnt * cnt);
+    }
+    __device__ bool axis(int a, int b, double ax[3]) const {     // cells.c:225-278
+        double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < 3; s++) for (int r = 0; r <= s; r++) m[s * 3 + r] = vcov(a, b, r, s);
+        m[0 * 3 + 2] = m[2 * 3 + 0]; m[0 * 3 + 1] = m[1 * 3 + 0]; m[1 * 3 + 2] = m[2 * 3 + 1];
+        double w[3];
+        if (hm::eigen_sym3(m, w) != 0) return false;
+        ax[0] = m[6]; ax[1] = m[7]; ax[2] = m[8];
+        return true;
+    }
+    __device__ static double norm3(const double a[3]) { double s = 0; for (int i = 0; i < 3; i++) s += a[i] * a[i]; return sqrt(s); }   // pow(x, 2) is x * x
+    __device__ double bias(int a, int b, const double ax[3]) const {   // cells.c:280-328
+        double ca[3];
+        if (!axis(a, b, ca)) return -1;
+        const double norms = norm3(ax) * norm3(ca);
+        if (norms < 1e-16) return 0;
+        const double dot = (ca[0] * ax[0] + ca[1] * ax[1] + ca[2] * ax[2]);
+        return fmin(1.0, fabs(dot / norms));
+    }
+};
+
+// entry (k, n) of the DP by ONE wavefront (k_gq_dp's block, quant.hip): E_k[n] and L[k][n] from Ep = E_{k-1}
+__device__ __forceinline__ void gq_dp_entry(const GqTab &c, const double *Ep, const int k, const int n, const int lane, double &e_out, int &cut_out) {
+    double best = INFINITY; int bt = -1;
+    for (int t = n - 2 - lane; t >= k - 1; t -= 64) {
+        const double v = Ep[t] + c.distortion(t, n);
+        if (v < best) { best = v; bt = t; }                          // descending t within the lane: first minimum = largest t
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_down(best, o, 64); const int t2 = __shfl_down(bt, o, 64);
+        if (t2 >= 0 && (bt < 0 || v2 < best || (v2 == best && t2 > bt))) { best = v2; bt = t2; }
+    }
+    double e = Ep[n - 1]; int cut = n - 1;
+    if (bt >= 0 && best < e) { e = best; cut = bt; }
+    e_out = e; cut_out = cut;                                        // (lane 0 holds the wavefront's result)
+}
+
+__global__ __launch_bounds__(1024) void k_gq_control(const double *__restrict__ hist, const unsigned int *__restrict__ hcount, GqDpDev *g,
+                                                     const int palette_size, const int weighted, NodeDev *nodes, const int base0,
+                                                     unsigned char *lut, GqOut *out, GqOut *out_host) {
+    __shared__ GqTab c;
+    __shared__ double E[2][kBuckets + 1];
+    __shared__ int s_q[16], s_nq, s_stop, s_err, s_top;
+    __shared__ double s_ax[3], s_cd[16], s_cb[16];
+    __shared__ unsigned char s_lut[kBuckets];
+    __shared__ double s_part[kGqMaxK][4][2];
+    __shared__ unsigned long long s_cnt[kGqMaxK];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ unsigned long long s_ticks[8];
+    if (tid == 0) { for (int i = 0; i < 8; i++) s_ticks[i] = 0; s_ticks[0] = wall_clock64(); }
+    // ---- 1. prefixes
+    for (int i = tid; i < 10 * kBuckets; i += 1024) {
+        const int hq = i / kBuckets, b = i - hq * kBuckets;
+        c.t[hq][b + 1] = hist[(size_t)(hq * 2 + 0) * kBuckets + b] + hist[(size_t)(hq * 2 + 1) * kBuckets + b];
+    }
+    for (int b = tid; b < kBuckets; b += 1024) c.w0[b + 1] = hcount[b];
+    if (tid < 10) c.t[tid][0] = 0;
+    if (tid == 10) c.w0[0] = 0;
+    __syncthreads();
+    if (tid == 0) s_ticks[5] = wall_clock64();
+    if (lane == 0) {
+        // table[i] += table[i-1], i ascending.  Eight entries are read ahead of the eight that are being added and stored: a load
+        // behind a store to the same array waits for it (they may alias for all the compiler knows) and the chain would pay an LDS
+        // round trip per step (k_gq_prefix: 16 us for these chains)
+        if (wv < 10) {
+            double *t = c.t[wv];
+            double a = 0, v[8], nx[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = t[1 + u];
+            for (int i = 1; i <= kBuckets; i += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) nx[u] = t[i + 8 + u];           // (past the end in the last trip: padding, never used)
+#pragma unroll
+                for (int u = 0; u < 8; u++) { a = v[u] + a; t[i + u] = a; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = nx[u];
+            }
+        }
+    }
+    if (wv == 10) {                                                  // the counts: integers, any order -- a wave scan, eight buckets per lane
+        unsigned long long v[8], run = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { run += c.w0[1 + lane * 8 + u]; v[u] = run; }
+        unsigned long long inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        const unsigned long long before = inc - run;
+#pragma unroll
+        for (int u = 0; u < 8; u++) c.w0[1 + lane * 8 + u] = before + v[u];
+    }
+    __syncthreads();
+    if (tid == 0) s_ticks[1] = wall_clock64();
+    // ---- 2. the axis of everything, E_1; L as the reference starts it (zero, L[i][i] = i: global.c:236-238)
+    for (int i = tid; i < (kGqMaxK + 1) * (kBuckets + 1); i += 1024) { const int r = i / (kBuckets + 1), n = i - r * (kBuckets + 1); g->cut[r][n] = r == n ? r : 0; }
+    for (int i = tid; i <= kBuckets; i += 1024) E[1][i] = i >= 1 ? c.distortion(0, i) : 0.0;
+    if (tid == 0) {
+        double ax[3] = {0, 0, 0};
+        s_err = c.axis(0, kBuckets, ax) ? 0 : 1;
+        s_ax[0] = ax[0]; s_ax[1] = ax[1]; s_ax[2] = ax[2];
+        s_q[0] = 0; s_q[1] = kBuckets; s_nq = 2; s_stop = 0;
+    }
+    __syncthreads();
+    const int kmax = palette_size < kGqMaxK ? palette_size : kGqMaxK;
+    if (tid == 0) s_ticks[2] = wall_clock64();
+    // ---- 3. E[k & 1 ^ 1] ... : E[(k - 1) & 1] holds E_{k-1} when iteration k reaches its DP
+    for (int k = 2; k <= kmax && !s_err; k++) {
+        const int cells = s_nq - 1;
+        if (lane == 0 && wv < cells) {
+            const double ax[3] = {s_ax[0], s_ax[1], s_ax[2]};
+            s_cd[wv] = c.distortion(s_q[wv], s_q[wv + 1]);
+            if (cells == 1) {                                        // the one cell is everything: its axis is `ax`, solved a moment ago
+                const double norms = GqTab::norm3(ax) * GqTab::norm3(ax);
+                s_cb[wv] = norms < 1e-16 ? 0.0 : fmin(1.0, fabs((ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]) / norms));
+            } else s_cb[wv] = c.bias(s_q[wv], s_q[wv + 1], ax);
+        }
+        __syncthreads();
+        if (tid == 0) {                                              // gq_should_terminate (global.c:99-187)
+            double distortion = 0;
+            for (int j = 0; j < cells; j++) distortion += s_cd[j];
+            int stop = 0;
+            if (distortion < 1e-16) stop = 1;
+            else {
+                double bias = 0;
+                for (int i = 0; i < cells; i++) {
+                    const double cd = s_cd[i], cb = s_cb[i];
+                    if (cb < 0) { stop = 1; break; }                 // (global.c:174-177 sets a flag its caller never reaches: the loop breaks first)
+                    if (cb < 0.9) continue;
+                    bias += (cd / distortion) * cb;
+                }
+                if (!stop) stop = bias < 0.1 ? 1 : 0;
+            }
+            s_stop = stop;
+        }
+        __syncthreads();
+        if (s_stop) break;
+        if (k > 2) {                                                 // the full step k-1: E_{k-1} and L[k-1][.] from E_{k-2}
+            const int kk = k - 1;
+            const double *Ep = E[(kk - 1) & 1];
+            double *En = E[kk & 1];
+            for (int n = wv; n <= kBuckets; n += 16) {
+                if (n < kk + 1) { if (lane == 0) En[n] = Ep[n]; continue; }
+                double e; int cut;
+                gq_dp_entry(c, Ep, kk, n, lane, e, cut);
+                if (lane == 0) { En[n] = e; g->cut[kk][n] = cut; }
+            }
+            __syncthreads();
+        }
+        if (wv == 0) {
+            double e; int cut;
+            gq_dp_entry(c, E[(k - 1) & 1], k, kBuckets, lane, e, cut);
+            if (lane == 0) s_top = cut;
+        }
+        __syncthreads();
+        if (tid == 0) {                                              // the backtrack (global.c:282-296)
+            int t = s_top;
+            s_q[k - 1] = t;
+            for (int j = k - 2; j >= 1; j--) { t = g->cut[j + 1][t]; s_q[j] = t; }
+            s_q[0] = 0; s_q[k] = kBuckets; s_nq = k + 1;
+        }
+        __syncthreads();
+    }
+    const int kbase = s_nq - 1;
+    if (tid == 0) s_ticks[3] = wall_clock64();
+    // ---- 4. bucket -> base cluster (global.c:328-335), the clusters' records
+    for (int b = tid; b < kBuckets; b += 1024) {
+        int j = 0;
+        while (j < kbase - 1 && !(b + 1 <= s_q[j + 1])) j++;
+        s_lut[b] = (unsigned char)j;
+        lut[b] = (unsigned char)j;
+    }
+    __syncthreads();
+    const int nq = weighted ? 4 : 3;
+    // the clusters' sums: wavefront (q, part) holds its row of the table, eight buckets per lane, and adds up every cluster's share
+    // (exact parts on the bin grids: any order); wavefront 8 the counts
+    if (wv < 2 * nq) {
+        const int q = wv >> 1, part = wv & 1, qi = weighted ? 10 + q : q;
+        const double *h = hist + (size_t)(qi * 2 + part) * kBuckets + lane * 8;
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = h[u];
+        for (int j = 0; j < kbase; j++) {
+            double a = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) a += s_lut[lane * 8 + u] == j ? v[u] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane == 0) s_part[j][q][part] = a;
+        }
+    } else if (wv == 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = hcount[lane * 8 + u];
+        for (int j = 0; j < kbase; j++) {
+            unsigned long long a = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) a += s_lut[lane * 8 + u] == j ? v[u] : 0ULL;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane == 0) s_cnt[j] = a;
+        }
+    }
+    __syncthreads();
+    if (tid < kbase) {
+        const int j = tid;
+        unsigned long long pos = 0;
+        for (int i = 0; i < j; i++) pos += s_cnt[i];
+        const unsigned long long cnt = s_cnt[j];
+        NodeDev &ch = nodes[base0 + j];
+        ch.begin = pos; ch.n = cnt; ch.gn = cnt; ch.buf = 1; ch.slot = -1; ch.child0 = -1; ch.nchild = 0;
+        const double sw = weighted ? (s_part[j][3][0] + s_part[j][3][1]) : (double)cnt;
+        const double inv = 1 / sw;
+        for (int q = 0; q < 3; q++) { ch.axis[q] = 0; ch.mean[q] = (s_part[j][q][0] + s_part[j][q][1]) * inv; }
+        ch.sw = sw; ch.klin = nodes[0].klin; ch.kquad = nodes[0].kquad;
+        node_reset_outputs(ch);
+        ch.split = -1; ch.psplit = -1;
+    }
+    if (tid == 64) {
+        NodeDev &root = nodes[0];
+        root.child0 = base0; root.nchild = kbase;
+        root.split = kbase == 2 ? s_q[1] - 1 : -1;                   // bucket b is in cluster 0 iff b + 1 <= cuts[1] (global.c:328-335)
+        GqOut o;
+        o.kbase = kbase; o.error = s_err; o.pad[0] = o.pad[1] = 0;
+        for (int j = 0; j < 16; j++) o.cuts[j] = j <= kbase ? s_q[j] : 0;
+        for (int j = 0; j < 8; j++) o.ticks[j] = s_ticks[j];
+        o.ticks[4] = wall_clock64();
+        *out = o;
+        *out_host = o;                                               // pinned host memory: read after the caller's next synchronisation
+    }
 }
 
 // the eigen-solver as the control kernel runs it, for the golden test (patolette_amd_eigen_sym3_device)
@@ -625,6 +917,9 @@ struct Engine {
     DevBuf<double> wsal;
     DevBuf<GqDpDev> gq;
     PinBuf<GqDpDev> h_gq;
+    DevBuf<GqOut> gqout;                  // k_gq_control's result (device copy: the split loop's kernels read it; pinned copy: the host, after its next synchronisation)
+    PinBuf<GqOut> h_gqout;
+    PinBuf<double> h_pal;                 // the palette on its way to the mapping kernels
     DevBuf<LqCtl> lqctl;                  // the device-driven split loop's state; the host's copies of what the replay needs
     PinBuf<LqHead> h_lqhead;
     PinBuf<LqRec> h_lqrec;
@@ -963,7 +1258,8 @@ static void gq_prepare(Engine &E, size_t N, bool weighted) {
 // the left child; known).  Exactly the host-driven loop's steps (quantize_clusters_run below), except that nothing is left to
 // evaluate: false if a step is blocked by an undecided node all the same (the device's selection rule forbids it).
 struct LqReplay { std::vector<int> result; std::vector<LqCommit> commits; bool stopped_early = false; };
-static bool lq_replay(const LqRec *rec, int kbase, int first_base, size_t K, LqReplay &out) {
+// the same loop over the whole frontier at every step (the reference's shape): what PAMD_LQ_REPLAY_CHECK=1 holds the blocked form below to
+static bool lq_replay_plain(const LqRec *rec, int kbase, int first_base, size_t K, LqReplay &out) {
     std::vector<int> &result = out.result;
     result.assign(K, -1);
     for (int j = 0; j < kbase; j++) result[j] = first_base + j;
@@ -991,6 +1287,63 @@ static bool lq_replay(const LqRec *rec, int kbase, int first_base, size_t K, LqR
             fval[count] = rec[l].val; fkn[count] = (char)rec[l].kn;
             fval[best] = rec[l + 1].val; fkn[best] = (char)rec[l + 1].kn;
             count++;
+            continue;
+        }
+        if (std::max(best >= 0 ? bv : 0.0, mu) < kDelta) { out.stopped_early = true; break; }
+        return false;
+    }
+    result.resize(count);
+    return true;
+}
+
+static bool lq_replay(const LqRec *rec, int kbase, int first_base, size_t K, LqReplay &out) {
+    std::vector<int> &result = out.result;
+    result.assign(K, -1);
+    for (int j = 0; j < kbase; j++) result[j] = first_base + j;
+    size_t count = (size_t)kbase;
+    // The frontier in blocks of sixteen rows, each with its first maximum among the known rows and the maximum among the unknown
+    // ones: a step changes two rows, so it rescans two blocks and the blocks' summaries instead of the whole frontier (254 steps over
+    // up to 256 rows: 50 us of a 1920x1080 call's 1.6 ms before)
+    constexpr size_t B = 16;
+    const size_t nb = (K + B - 1) / B;
+    std::vector<double> fval(nb * B, 0.0);
+    std::vector<char> fkn(nb * B, 0);
+    std::vector<double> bbv(nb, 0.0), bmu(nb, -1.0);
+    std::vector<int> bbest(nb, -1);
+    auto rescan = [&](const size_t b) {
+        int best = -1; double bv = 0, mu = -1;
+        const size_t lo = b * B, hi = std::min(count, lo + B);
+        for (size_t j = lo; j < hi; j++) {
+            if (fkn[j]) { if (best < 0 || fval[j] > bv) { bv = fval[j]; best = (int)j; } }      // first maximum (vector.c:26-46)
+            else if (fval[j] > mu) mu = fval[j];
+        }
+        bbest[b] = best; bbv[b] = bv; bmu[b] = mu;
+    };
+    for (size_t j = 0; j < count; j++) { fval[j] = rec[result[j]].val; fkn[j] = (char)rec[result[j]].kn; }
+    for (size_t b = 0; b < nb; b++) rescan(b);
+    const int fault = g_debug_fault.load(std::memory_order_relaxed);
+    while (count < K) {
+        int best = -1; double bv = 0, mu = -1;
+        const size_t nbu = (count + B - 1) / B;
+        for (size_t b = 0; b < nbu; b++) {                       // ascending blocks, strict '>': the first maximum of all rows
+            if (bbest[b] >= 0 && (best < 0 || bbv[b] > bv)) { bv = bbv[b]; best = bbest[b]; }
+            if (bmu[b] > mu) mu = bmu[b];
+        }
+        if (mu < 0 || (best >= 0 && bv > mu)) {
+            if (fault == 2) {                                      // tests only: a WRONG greedy step (the second best known one)
+                int second = -1; double sv = -1;
+                for (size_t j = 0; j < count; j++) if ((int)j != best && fkn[j] && fval[j] > sv) { sv = fval[j]; second = (int)j; }
+                if (second >= 0 && sv >= kDelta && sv < bv) { best = second; bv = sv; }
+            }
+            if (!(bv >= kDelta)) { out.stopped_early = true; break; }          // benefit < DELTA: stop (local.c:365-370)
+            const int id = result[best], l = rec[id].left;
+            out.commits.push_back(LqCommit{best, id, (int)count, l});
+            result[count] = l; result[best] = l + 1;               // local.c:375-376: palette ORDER
+            fval[count] = rec[l].val; fkn[count] = (char)rec[l].kn;
+            fval[best] = rec[l + 1].val; fkn[best] = (char)rec[l + 1].kn;
+            count++;
+            rescan((size_t)best / B);
+            if ((count - 1) / B != (size_t)best / B) rescan((count - 1) / B);
             continue;
         }
         if (std::max(best >= 0 ? bv : 0.0, mu) < kDelta) { out.stopped_early = true; break; }
@@ -1028,15 +1381,18 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
     const RoundDyn *dyn = &c->dyn;
     const int *d_round = c->round_ids, *d_tP0 = c->tP0;
     int call = 0;                                                  // control calls so far: the parity selects the children list (LqCtl::cids)
+    // kbase < 0: the global quantiser ran on the device too (k_gq_control): the count of base clusters is in E.gqout, twelve at most
+    const GqOut *gq = kbase < 0 ? (const GqOut *)E.gqout.p : nullptr;
+    const int kb_ub = kbase < 0 ? kGqMaxK : kbase;
     auto control = [&]() {
         const bool first = call == 0;
         {
             KTIME("k_lq_children", s, 0.0);
-            if (first) hipLaunchKernelGGL(k_lq_children, (kbase + 3) / 4, 256, 0, s, E.nodes.p, c, call, eigen_bound, kbase, first_base, nnodes, (int)K);
-            else hipLaunchKernelGGL(k_lq_children, 2 * kLqRoundCap / 4, 256, 0, s, E.nodes.p, c, call, eigen_bound, 0, 0, 0, 0);
+            if (first) hipLaunchKernelGGL(k_lq_children, (kb_ub + 3) / 4, 256, 0, s, E.nodes.p, c, call, eigen_bound, kb_ub, first_base, nnodes, (int)K, gq);
+            else hipLaunchKernelGGL(k_lq_children, 2 * kLqRoundCap / 4, 256, 0, s, E.nodes.p, c, call, eigen_bound, 0, 0, 0, 0, (const GqOut *)nullptr);
         }
         KTIME("k_lq_select", s, 0.0);
-        hipLaunchKernelGGL(k_lq_select, 1 + (first ? (kbase + 3) / 4 : 2 * kLqRoundCap / 4), 256, 0, s, E.nodes.p, c, call, bnd.e_lin, bnd.e_quad);
+        hipLaunchKernelGGL(k_lq_select, 1 + (first ? (kb_ub + 3) / 4 : 2 * kLqRoundCap / 4), 256, 0, s, E.nodes.p, c, call, bnd.e_lin, bnd.e_quad);
         HIP_CHECK(hipGetLastError());
         call++;
     };
@@ -1058,17 +1414,30 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
     int want = (E.lq_hint_N == N && E.lq_hint_K == K && E.lq_hint_rounds > 0) ? E.lq_hint_rounds : 9;
     for (;;) {
         while (enq < want) round();
-        HIP_CHECK(hipMemcpyAsync(head, &c->h, sizeof(LqHead), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(E.h_lqrec.p, c->nrec, sizeof(LqRec) * kLqNodeCap, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(E.h_lqcen.p, c->ncen, sizeof(LqCen) * kLqNodeCap, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_lq_export, 16, 256, 0, s, (const LqCtl *)c, head, E.h_lqrec.p, E.h_lqcen.p);
+        HIP_CHECK(hipGetLastError());
         E.sync();
         if (head->done) break;
         want = enq + 2;
     }
     if (head->error == 2) return -2;
+    if (head->error == 3) return -1;                               // the global quantiser's eigen-solve failed (global.c:214-217)
+    if (kbase < 0) kbase = E.h_gqout.p->kbase;
     E.lq_hint_N = N; E.lq_hint_K = K; E.lq_hint_rounds = head->rounds;
     LqReplay rp;
-    if (!lq_replay(E.h_lqrec.p, kbase, first_base, K, rp)) throw HipError("patolette_amd: split loop: the replay met an unevaluated node");
+    const bool replay_ok = lq_replay(E.h_lqrec.p, kbase, first_base, K, rp);
+    static const bool replay_check = getenv("PAMD_LQ_REPLAY_CHECK") != nullptr;
+    if (replay_check || !replay_ok) {
+        LqReplay ref;
+        const bool ref_ok = lq_replay_plain(E.h_lqrec.p, kbase, first_base, K, ref);
+        if (ref_ok != replay_ok || ref.result != rp.result || ref.stopped_early != rp.stopped_early)
+            fprintf(stderr, "patolette_amd: split loop: the two replays DISAGREE (plain %d, %zu rows; blocked %d, %zu rows), kbase %d, K %zu, nodes %d, rounds %d\n",
+                    (int)ref_ok, ref.result.size(), (int)replay_ok, rp.result.size(), kbase, K, head->nnodes, head->rounds);
+        else if (!replay_ok)
+            fprintf(stderr, "patolette_amd: split loop: both replays blocked after %zu commits, kbase %d, K %zu, nodes %d, rounds %d, evaluated %d, tau %.17g\n",
+                    rp.commits.size(), kbase, K, head->nnodes, head->rounds, head->neval, head->tau);
+    }
+    if (!replay_ok) throw HipError("patolette_amd: split loop: the replay met an unevaluated node");
     len = rp.result.size();
     centers.assign(3 * len, 0.0);
     unsigned long long mg = 0;
@@ -1084,8 +1453,16 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
     E.trace_pending = true;
     E.trace_hdr.stopped_early = rp.stopped_early ? 1 : 0;
     static const bool lq_times = getenv("PAMD_LQ_TIMES") != nullptr;
-    if (lq_times) fprintf(stderr, "patolette_amd: device-driven split loop: %d rounds, %d evaluated, %zu commits, tau %.3g\n", head->rounds, head->neval,
-                          E.lq_commits.size(), head->tau);
+    if (lq_times) {
+        fprintf(stderr, "patolette_amd: device-driven split loop: %d rounds, %d evaluated, %zu commits, tau %.3g\n", head->rounds, head->neval,
+                E.lq_commits.size(), head->tau);
+        if (gq) {
+            const unsigned long long *t = E.h_gqout.p->ticks;
+            fprintf(stderr, "patolette_amd: k_gq_control us: prefixes %.1f, axis %.1f, search %.1f, records %.1f\n", (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01,
+                    (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01);
+            fprintf(stderr, "patolette_amd: k_gq_control us: of the prefixes, staging %.1f\n", (t[5] - t[0]) * 0.01);
+        }
+    }
     return 0;
 }
 
@@ -1205,6 +1582,59 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
     if (sh) shard_exchange_keys(E, shard_upload_ids(E, {0}), 1);
     launch_hist(qroot, true, E.tilesA.p, ntA0, N, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake && !mom_path, Nt >= ((size_t)1 << 18));
     if (sh) { comm_sum_dev(E, E.hist.p, hs, 0); comm_sum_dev(E, E.hcount.p, kBuckets, 2); }
+    // The quantiser's decisions (global.c:189-298) on the device, the partition behind them without the host looking (k_gq_control):
+    // one GPU, palettes of more than twelve colours (so that base clusters < K whatever the image), not verbose.  PAMD_GQ_DEVICE=0:
+    // the host's turn everywhere (A/B; what sliced images, small palettes and verbose calls always take)
+    static const bool gq_dev_env = !(getenv("PAMD_GQ_DEVICE") && atoi(getenv("PAMD_GQ_DEVICE")) == 0);
+    const bool gq_dev = gq_dev_env && !sh && !verbose && K > (size_t)kGqMaxK;
+    int kbase = 0;
+    std::vector<int> base_ids;
+    if (gq_dev) {
+        E.gq.reserve(1); E.gqout.reserve(1); E.h_gqout.reserve(1);
+        *E.h_gqout.p = GqOut{};
+        {
+            KTIME("k_gq_control", s, (double)hs * 8);
+            hipLaunchKernelGGL(k_gq_control, 1, 1024, 0, s, (const double *)E.hist.p, (const unsigned int *)E.hcount.p, E.gq.p, (int)std::min<size_t>(K, (size_t)1 << 30),
+                               weighted ? 1 : 0, E.nodes.p, 1, E.lut.p, E.gqout.p, E.h_gqout.p);
+            HIP_CHECK(hipGetLastError());
+        }
+        launch_partition(qroot, E.tilesP.p, ntP0, N, E.round_nodes.p, E.node_tile0.p, 1, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s, inv_sums,
+                         snake && mom_path, nullptr, nullptr, true);
+        launch_cov_children(qroot, E.tilesA.p, ntA0, N, E.nodes.p, s, snake && !mom_path, true);
+        auto trace_header = [&]() {                              // (after a synchronisation)
+            const GqOut &o = *E.h_gqout.p;
+            E.trace_hdr.n_base = o.kbase;
+            for (int j = 0; j <= o.kbase && j < 14; j++) E.trace_hdr.gq_cuts[j] = (size_t)o.cuts[j];
+        };
+        if (dev_eligible) {
+            E.stats.ms_gq = now_ms() - t0;
+            t0 = now_ms();
+            const int rc = lq_device_loop(E, N, K, weighted, inv_sums, bnd, qlq, -1, 1, 0, snake, centers, len, max_members);
+            trace_header();
+            E.stats.n_base_clusters = (size_t)E.h_gqout.p->kbase;
+            if (rc != 0) return rc;
+            E.stats.n_clusters = len;
+            E.trace_hdr.n_clusters = (int32_t)len; E.trace_hdr.n_records = (int32_t)E.lq_commits.size();
+            E.cluster_centers = centers;
+            E.stats.ms_lq = now_ms() - t0;
+            return 0;
+        }
+        // the host-driven split loop: the count comes down with the base clusters' records (the first kbase of twelve)
+        std::vector<int> all(kGqMaxK);
+        for (int j = 0; j < kGqMaxK; j++) all[j] = 1 + j;
+        get_nodes(E, all, got);
+        if (E.h_gqout.p->error) return -1;
+        trace_header();
+        kbase = E.h_gqout.p->kbase;
+        for (int j = 0; j < kbase; j++) {
+            HNode c; c.buf = 1; c.begin = got[j].begin; c.n = got[j].n; c.gn = got[j].gn; c.sw = got[j].sw;
+            for (int q = 0; q < 3; q++) c.mean[q] = got[j].mean[q];
+            absorb_moments(c, got[j]);
+            leaf_bound(c);
+            base_ids.push_back((int)hn.size());
+            hn.push_back(c);
+        }
+    } else {
     const int gq_kmax = (int)std::min<size_t>(K, kGqMaxK);
     E.gq.reserve(1); E.h_gq.reserve(1);
     launch_gq_dp(E.hist.p, E.hcount.p, gq_kmax, E.gq.p, s);
@@ -1234,7 +1664,7 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
     }
     std::vector<size_t> cuts = hm::gq_principal_quantizer(K, *cm, E.h_gq.p->cut);
     if (cuts.size() < 2) return -1;
-    const int kbase = (int)cuts.size() - 1;
+    kbase = (int)cuts.size() - 1;
     E.trace_hdr.n_base = kbase;
     for (int j = 0; j <= kbase && j < 14; j++) E.trace_hdr.gq_cuts[j] = cuts[j];
 
@@ -1248,7 +1678,6 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
     // Two base clusters (what noise and most photographs give): the partition is a binary split like the local quantiser's, so
     // it takes the same pipelined kernel and the children's centred moments ride along instead of costing a sweep of their own
     const bool gq_binary = kbase == 2;
-    std::vector<int> base_ids;
     {
         unsigned long long pos = 0;
         for (int j = 0; j < kbase; j++) {
@@ -1308,6 +1737,7 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
         if (sh) { hn[base_ids[i]].begin = got[i].begin; hn[base_ids[i]].n = got[i].n; }
         leaf_bound(hn[base_ids[i]]);
     }
+    }                                                           // (the host's turn of the global quantiser)
     E.stats.n_base_clusters = (size_t)kbase;
     if (verbose) printf("patolette ======== Base cluster count: %zu\n", (size_t)kbase);     // patolette.c:227-229
     E.stats.ms_gq = now_ms() - t0;
@@ -1865,8 +2295,11 @@ static void run_device(Engine &E, size_t width, size_t height, Pixels px, const 
             }
             E.map_palette = pal;
             if (d_map) {
-                HIP_CHECK(hipMemcpyAsync(E.dpal.p, pal.data(), 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
-                HIP_CHECK(hipStreamSynchronize(s));
+                // from a pinned copy: no wait for the transfer (a pageable source is staged and waited for, ~15 us with nothing queued
+                // behind it); the copy is this engine's and is next written by its next call, after this one's final synchronisation
+                E.h_pal.reserve(3 * len);
+                std::memcpy(E.h_pal.p, pal.data(), 3 * len * sizeof(double));
+                HIP_CHECK(hipMemcpyAsync(E.dpal.p, E.h_pal.p, 3 * len * sizeof(double), hipMemcpyHostToDevice, s));
                 launch_nn_map(pixels, N, N, E.dpal.p, (int)len, d_map, map_elem, blo, bhi, E.nn, s);
             }
             palette_rows(pal, len, hm::color::ictcp_to_rec2020);

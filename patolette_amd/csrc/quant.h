@@ -133,8 +133,10 @@ void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int n
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
                       unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s,
-                      bool invariant = false, bool from_end = false, const RoundDyn *dyn = nullptr, const double *px_src = nullptr);
-void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end = false);
+                      bool invariant = false, bool from_end = false, const RoundDyn *dyn = nullptr, const double *px_src = nullptr,
+                      bool gated = false);
+void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end = false,
+                         bool gated = false);
 void launch_cov_nodes(const QuantBuffers &qb, const double *planar_override, const Tile *d_tiles, int ntiles, size_t px,
                       NodeDev *d_nodes, hipStream_t s, bool from_end = false);
 

@@ -734,8 +734,9 @@ __global__ __launch_bounds__(256, INV ? 4 : 5) void k_scatter(QuantBuffers qb, c
     // child and quantity in plain f64 -- a fixed set of pixels in a fixed order for a given tiling, so deterministic --
     // and the 14 per-thread partials are split onto the exact grids, reduced over the block and added atomically only
     // when the node changes or the block is done.
+    if ((from_end & 4) && nodes[0].nchild == 2) return;      // gated launch (launch_partition): the binary kernel has this partition
     const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int bid = from_end ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int bid = (from_end & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
     constexpr int NP = INV ? 14 : 7;
     double pl[NP], pr[NP];
@@ -883,13 +884,14 @@ __global__ __launch_bounds__(256, (W || INV) ? 2 : 3) void k_scatter_bin(QuantBu
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned long long ltmask = (1ULL << lane) - 1ULL;
     int nblk = (int)gridDim.x;
+    if ((from_end & 2) && nodes_ro[0].nchild != 2) return;   // gated launch (launch_partition): the root's children are not two, the general kernel has them
     if (dyn) {                                               // the launch is an upper bound (see k_hist)
         ntiles = dyn->ntP;
         nblk = min(ntiles, nblk);
         if ((int)blockIdx.x >= nblk) return;
     }
     const int per = (ntiles + nblk - 1) / nblk;
-    const int bid = from_end ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int bid = (from_end & 1) ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int tfirst = bid * per, tlast = min(ntiles, tfirst + per);
     if (tfirst >= tlast) return;
     constexpr int NP = INV ? 14 : 7;
@@ -1065,7 +1067,8 @@ __device__ __forceinline__ void cov_accumulate(const double *px, const double *p
 template <bool W>
 __global__ __launch_bounds__(256) void k_cov_children(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes, const int from_end) {
     __shared__ double sm[14 * 4];
-    const Tile t = tiles[from_end ? gridDim.x - 1u - blockIdx.x : blockIdx.x];
+    if ((from_end & 4) && nodes[0].nchild == 2) return;      // gated launch: the binary partition took the children's moments along
+    const Tile t = tiles[(from_end & 1) ? gridDim.x - 1u - blockIdx.x : blockIdx.x];
     const NodeDev &nd = nodes[t.node];
     const double *px = qb.buf[1 - nd.buf], *py = px + qb.N, *pz = py + qb.N, *pw = pz + qb.N;
     const size_t t_lo = t.start, t_hi = t.start + t.count;
@@ -1271,10 +1274,13 @@ void launch_cut(bool weighted, NodeDev *d_nodes, const int *d_round_nodes, int n
 void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles, size_t px, const int *d_round_nodes,
                       const int *d_node_tile0, int nround, NodeDev *d_nodes, const unsigned char *d_lut,
                       unsigned int *d_tilecnt, unsigned long long *d_tileoff, bool fuse_cov, hipStream_t s, bool invariant, bool from_end,
-                      const RoundDyn *dyn, const double *px_src) {
-    const int fe = from_end ? 1 : 0;
+                      const RoundDyn *dyn, const double *px_src, bool gated) {
+    // gated (the root's partition after k_gq_control, which alone knows how many base clusters there are): both forms are launched,
+    // the binary one with the children's moments fused (fuse_cov) and the general one; each looks at the root's child count and one
+    // of them returns at once
+    const int fe = (from_end ? 1 : 0) | (gated ? 2 : 0);
     if (!nround) return;
-    if (nptiles) { KTIME_DYN("k_count", s, 2.0, px, px_src); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt, fe, dyn); }
+    if (nptiles) { KTIME_DYN("k_count", s, 2.0, px, px_src); hipLaunchKernelGGL(k_count, nptiles, 256, 0, s, qb, d_ptiles, d_nodes, d_lut, d_tilecnt, fe & 1, dyn); }
     // (a GPU holding none of the round's pixels still needs the children's -- empty -- segments: k_scan runs regardless)
     { KTIME_DYN("k_scan", s, 12.0 * kMaxChildren / (double)kTileP, dyn ? px : (size_t)nptiles * kTileP, px_src);
       hipLaunchKernelGGL(k_scan, nround, 1024, 0, s, d_round_nodes, d_node_tile0, d_nodes, d_tilecnt, d_tileoff, dyn); }
@@ -1282,7 +1288,7 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
         KTIME_DYN(fuse_cov ? "k_scatter_cov" : "k_scatter", s, (qb.weighted ? 66.0 : 50.0), px, px_src);
         if (fuse_cov) {
             static const bool v1 = getenv("PAMD_SCATTER_V1") && atoi(getenv("PAMD_SCATTER_V1")) != 0;   // the round-trip-per-round kernel (A/B)
-            if (!v1 || dyn) {
+            if (!v1 || dyn || gated) {
                 const int gb = std::min(nptiles, 256 * ((invariant || qb.weighted) ? 2 : 3));
                 if (invariant) {
                     if (qb.weighted) hipLaunchKernelGGL((k_scatter_bin<true, true>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe, dyn);
@@ -1290,6 +1296,12 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
                 } else if (qb.weighted) hipLaunchKernelGGL((k_scatter_bin<true, false>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe, dyn);
                 else hipLaunchKernelGGL((k_scatter_bin<false, false>), gb, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, (const NodeDev *)d_nodes, d_tileoff, fe, dyn);
                 HIP_CHECK(hipGetLastError());
+                if (gated) {
+                    const int fg = (from_end ? 1 : 0) | 4;
+                    if (qb.weighted) hipLaunchKernelGGL((k_scatter<true, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fg);
+                    else hipLaunchKernelGGL((k_scatter<false, false>), nptiles, 256, 0, s, qb, d_ptiles, nptiles, d_nodes, d_lut, d_tileoff, fg);
+                    HIP_CHECK(hipGetLastError());
+                }
                 return;
             }
             const int g = std::min(nptiles, 256 * (invariant ? 4 : 5));   // resident blocks per CU, each loops over its run of tiles
@@ -1306,11 +1318,12 @@ void launch_partition(const QuantBuffers &qb, const Tile *d_ptiles, int nptiles,
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end) {
+void launch_cov_children(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end, bool gated) {
     if (!ntiles) return;
     KTIME("k_cov", s, (qb.weighted ? 32.0 : 24.0) * px);
-    if (qb.weighted) hipLaunchKernelGGL(k_cov_children<true>, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0);
-    else hipLaunchKernelGGL(k_cov_children<false>, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0);
+    const int fe = (from_end ? 1 : 0) | (gated ? 4 : 0);
+    if (qb.weighted) hipLaunchKernelGGL(k_cov_children<true>, ntiles, 256, 0, s, qb, d_tiles, d_nodes, fe);
+    else hipLaunchKernelGGL(k_cov_children<false>, ntiles, 256, 0, s, qb, d_tiles, d_nodes, fe);
     HIP_CHECK(hipGetLastError());
 }
 
