@@ -617,24 +617,28 @@ __global__ __launch_bounds__(1024) void k_gq_control(const double *__restrict__ 
     if (tid == 10) c.w0[0] = 0;
     __syncthreads();
     if (tid == 0) s_ticks[5] = wall_clock64();
-    if (lane == 0) {
-        // table[i] += table[i-1], i ascending.  Eight entries are read ahead of the eight that are being added and stored: a load
-        // behind a store to the same array waits for it (they may alias for all the compiler knows) and the chain would pay an LDS
-        // round trip per step (k_gq_prefix: 16 us for these chains)
-        if (wv < 10) {
-            double *t = c.t[wv];
-            double a = 0, v[8], nx[8];
+    if (wv < 10) {
+        // table[i] += table[i-1], i ascending: ONE sequential chain of 512 additions per table (cells.c:114-136), in registers.  Lane l
+        // holds entries 8 l + 1 .. 8 l + 8.  Pass A walks the lanes in order -- every lane adds its eight entries to the running sum
+        // it is handed (only lane l's are the chain's; the others' work is discarded) and the sum after lane l's entries goes on to
+        // lane l + 1 through a scalar register; pass B lets every lane redo ITS eight additions from the sum it was handed: the same
+        // operands in the same order, so the same bits.  (Through LDS, one lane per chain: ten wavefronts' loads and stores queued
+        // on the CU's one LDS pipeline, 23 us; k_gq_prefix's chains, with a round trip per step, 16 us for five.)
+        double *t = c.t[wv];
+        double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = t[1 + u];
-            for (int i = 1; i <= kBuckets; i += 8) {
+        for (int u = 0; u < 8; u++) v[u] = t[1 + lane * 8 + u];
+        double carry = 0, cin = 0;
+        for (int l = 0; l < 64; l++) {
+            double a = carry;
 #pragma unroll
-                for (int u = 0; u < 8; u++) nx[u] = t[i + 8 + u];           // (past the end in the last trip: padding, never used)
-#pragma unroll
-                for (int u = 0; u < 8; u++) { a = v[u] + a; t[i + u] = a; }
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = nx[u];
-            }
+            for (int u = 0; u < 8; u++) a = v[u] + a;
+            cin = lane == l ? carry : cin;
+            carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), l), __builtin_amdgcn_readlane(__double2loint(a), l));
         }
+        double a = cin;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a = v[u] + a; t[1 + lane * 8 + u] = a; }
     }
     if (wv == 10) {                                                  // the counts: integers, any order -- a wave scan, eight buckets per lane
         unsigned long long v[8], run = 0;
@@ -1425,7 +1429,9 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
     if (kbase < 0) kbase = E.h_gqout.p->kbase;
     E.lq_hint_N = N; E.lq_hint_K = K; E.lq_hint_rounds = head->rounds;
     LqReplay rp;
+    const double t_rp0 = now_ms();
     const bool replay_ok = lq_replay(E.h_lqrec.p, kbase, first_base, K, rp);
+    const double t_rp1 = now_ms();
     static const bool replay_check = getenv("PAMD_LQ_REPLAY_CHECK") != nullptr;
     if (replay_check || !replay_ok) {
         LqReplay ref;
@@ -1454,8 +1460,8 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
     E.trace_hdr.stopped_early = rp.stopped_early ? 1 : 0;
     static const bool lq_times = getenv("PAMD_LQ_TIMES") != nullptr;
     if (lq_times) {
-        fprintf(stderr, "patolette_amd: device-driven split loop: %d rounds, %d evaluated, %zu commits, tau %.3g\n", head->rounds, head->neval,
-                E.lq_commits.size(), head->tau);
+        fprintf(stderr, "patolette_amd: device-driven split loop: %d rounds, %d evaluated, %zu commits, tau %.3g; host replay %.1f us\n", head->rounds, head->neval,
+                E.lq_commits.size(), head->tau, 1e3 * (t_rp1 - t_rp0));
         if (gq) {
             const unsigned long long *t = E.h_gqout.p->ticks;
             fprintf(stderr, "patolette_amd: k_gq_control us: prefixes %.1f, axis %.1f, search %.1f, records %.1f\n", (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01,
