@@ -304,7 +304,7 @@ __device__ __forceinline__ int block_excl_scan_256(const int v, int *sw /* [5] *
 // order-preserving 64-bit key of a priority (negative or NaN -> 0: below every threshold that matters)
 __device__ __forceinline__ unsigned long long lq_key(const double p) { return p > 0.0 ? (unsigned long long)__double_as_longlong(p) : 0ULL; }
 
-__global__ __launch_bounds__(256) void k_lq_select(NodeDev *nodes, LqCtl *c, const int call, const int e_lin, const int e_quad) {
+__global__ __launch_bounds__(256) void k_lq_select(NodeDev *nodes, LqCtl *c, const int call, const int e_lin, const int e_quad, const double beta) {
     if (c->h.done) return;                                         // (set by an EARLIER launch only: every block of this one sees the same)
     const int tid = threadIdx.x, lane = tid & 63;
     const int cur = call & 1, nxt = cur ^ 1;
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void k_lq_select(NodeDev *nodes, LqCtl *c, con
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long s_prefix, s_px;
     __shared__ int s_need, s_neval, s_first;
+    __shared__ double s_umax[4];
     const int M = c->M;
     const int nn = c->h.nnodes;
     // ---- A. the nodes of the last round are split now: benefit (local.c:256-275) and priority.  A node whose eigen-solve failed a round
@@ -393,29 +394,46 @@ __global__ __launch_bounds__(256) void k_lq_select(NodeDev *nodes, LqCtl *c, con
         tau = __longlong_as_double((long long)prefix);
     }
     const double thr = fmax(kDelta, tau * (1.0 - 1e-9));
-    // ---- C. the leaves to evaluate: the children just made (and what an earlier round had no room for) whose priority can still
-    // reach tau; the others never will (tau only grows) and are dropped for good
+    // ---- C. the leaves to evaluate: the children just made and what earlier rounds left waiting.  A leaf whose priority cannot reach
+    // tau never will (tau only grows): dropped for good.  Of the others, those far below the best of them wait (`beta`, the host-driven
+    // loop's own rule and value: most of them fall below tau before their turn comes -- 500 evaluations a 256-colour palette without
+    // the rule, ~330 with it); the best one is always taken, so every round evaluates something, and the loop ends when no leaf reaches
+    // tau -- the set the replay needs is complete either way.  After 48 rounds everything that reaches tau is taken (a bound on the
+    // number of rounds whatever the content).
     const int nleaves = c->nleaves + ncids;
+    auto leaf_prio = [&](const int id) -> double {
+        const LqRec r = c->nrec[id];
+        const int par = c->nparent[id];
+        if (r.kn || (par >= 0 && nodes[par].axis_state < 0)) return -1.0;
+        const double pp = par < 0 ? INFINITY : c->np[par];
+        return r.val < pp ? r.val : pp;
+    };
+    double thr2 = thr;
+    if (beta > 0.0 && c->h.rounds < 48) {
+        double u = -1.0;
+        for (int i = tid; i < nleaves; i += 256) { const double pr = leaf_prio(c->leaves[i]); u = pr > u ? pr : u; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const double v = __shfl_xor(u, o, 64); u = v > u ? v : u; }
+        __syncthreads();
+        if (lane == 0) s_umax[tid >> 6] = u;
+        __syncthreads();
+        u = fmax(fmax(s_umax[0], s_umax[1]), fmax(s_umax[2], s_umax[3]));
+        if (beta * u > thr2) thr2 = beta * u;
+    }
     int nkeep = 0, nr = 0;
     for (int base = 0; base < nleaves; base += 256) {
         const int i = base + tid;
-        int id = -1, sel = 0;
+        int id = -1, sel = 0, keep = 0;
         if (i < nleaves) {
             id = c->leaves[i];
-            const LqRec r = c->nrec[id];
-            const int par = c->nparent[id];
-            if (!r.kn && !(par >= 0 && nodes[par].axis_state < 0)) {
-                const double pp = par < 0 ? INFINITY : c->np[par];
-                sel = (r.val < pp ? r.val : pp) >= thr ? 1 : 0;
-            }
+            const double pr = leaf_prio(id);
+            sel = pr >= thr2 ? 1 : 0;
+            keep = (!sel && pr >= thr) ? 1 : 0;                      // waits
         }
-        int tsel;
+        int tsel, tkeep;
         const int psel = block_excl_scan_256(sel, sw, tsel);
-        int keep = 0, tkeep = 0, pkeep = 0;
-        if (nr + tsel > kLqRoundCap) {                              // the round is full: the rest waits for the next one (block-uniform branch)
-            if (sel && nr + psel >= kLqRoundCap) { sel = 0; keep = 1; }
-            pkeep = block_excl_scan_256(keep, sw, tkeep);
-        }
+        if (nr + tsel > kLqRoundCap && sel && nr + psel >= kLqRoundCap) { sel = 0; keep = 1; }   // the round is full: the rest waits for the next one
+        const int pkeep = block_excl_scan_256(keep, sw, tkeep);
         if (sel) c->round_ids[nr + psel] = id;
         __syncthreads();
         if (keep) c->leaves[nkeep + pkeep] = id;
@@ -1358,11 +1376,11 @@ static bool lq_replay(const LqRec *rec, int kbase, int first_base, size_t K, LqR
 }
 
 // patolette_amd_set_split_loop: 2 (default) the device-driven loop for images below kLqDeviceAutoPixels, 1 wherever it applies,
-// 0 the host-driven one everywhere.  Measured (profiles/r06_split_loop_ab.txt): 1920x1080 1.61 against 1.77 ms per call, 4096^2
-// 5.81 against 5.80, 8192^2 21.7 against 21.0 -- the device's selection rule evaluates ~50 % more (small) candidate nodes than the
-// host's lock-step pruning, +8 % pixels swept, which costs a large image what the nine host turns cost a small one.
-std::atomic<int> g_lq_device{getenv("PAMD_LQ_DEVICE") ? atoi(getenv("PAMD_LQ_DEVICE")) : 2};
-constexpr size_t kLqDeviceAutoPixels = (size_t)12 << 20;
+// 0 the host-driven one everywhere.  Measured, round 6 (profiles/r06_split_loop_ab.txt), per call, device against host-driven:
+// first version 1920x1080 1.61 / 1.77 ms, 4096^2 5.81 / 5.80, 8192^2 21.7 / 21.0 (every leaf that could reach tau was evaluated at
+// once: ~500 evaluations where the host's lock-step pruning makes ~320); with the global quantiser on the device too and the
+// host loop's own waiting rule in k_lq_select (same ~320 evaluations): 1.38 / 1.53, 5.28-5.46 / 5.66-5.87, 21.4-21.5 / 21.2-21.7.
+constexpr size_t kLqDeviceAutoPixels = (size_t)40 << 20;
 
 // The local quantiser driven from the device (k_lq_children / k_lq_select above).  In: the base clusters are nodes first_base ..
 // first_base + kbase - 1 of the table with their segments, means and moment accumulators complete on the stream (no synchronisation
@@ -1385,6 +1403,7 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
     const RoundDyn *dyn = &c->dyn;
     const int *d_round = c->round_ids, *d_tP0 = c->tP0;
     int call = 0;                                                  // control calls so far: the parity selects the children list (LqCtl::cids)
+    static const double spec_beta_dev = getenv("PAMD_SPEC_BETA_DEV") ? atof(getenv("PAMD_SPEC_BETA_DEV")) : 0.25;   // 0: every leaf that reaches tau is evaluated at once
     // kbase < 0: the global quantiser ran on the device too (k_gq_control): the count of base clusters is in E.gqout, twelve at most
     const GqOut *gq = kbase < 0 ? (const GqOut *)E.gqout.p : nullptr;
     const int kb_ub = kbase < 0 ? kGqMaxK : kbase;
@@ -1396,7 +1415,7 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
             else hipLaunchKernelGGL(k_lq_children, 2 * kLqRoundCap / 4, 256, 0, s, E.nodes.p, c, call, eigen_bound, 0, 0, 0, 0, (const GqOut *)nullptr);
         }
         KTIME("k_lq_select", s, 0.0);
-        hipLaunchKernelGGL(k_lq_select, 1 + (first ? (kb_ub + 3) / 4 : 2 * kLqRoundCap / 4), 256, 0, s, E.nodes.p, c, call, bnd.e_lin, bnd.e_quad);
+        hipLaunchKernelGGL(k_lq_select, 1 + (first ? (kb_ub + 3) / 4 : 2 * kLqRoundCap / 4), 256, 0, s, E.nodes.p, c, call, bnd.e_lin, bnd.e_quad, spec_beta_dev);
         HIP_CHECK(hipGetLastError());
         call++;
     };
