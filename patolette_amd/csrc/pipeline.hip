@@ -1380,6 +1380,7 @@ static bool lq_replay(const LqRec *rec, int kbase, int first_base, size_t K, LqR
 // first version 1920x1080 1.61 / 1.77 ms, 4096^2 5.81 / 5.80, 8192^2 21.7 / 21.0 (every leaf that could reach tau was evaluated at
 // once: ~500 evaluations where the host's lock-step pruning makes ~320); with the global quantiser on the device too and the
 // host loop's own waiting rule in k_lq_select (same ~320 evaluations): 1.38 / 1.53, 5.28-5.46 / 5.66-5.87, 21.4-21.5 / 21.2-21.7.
+std::atomic<int> g_lq_device{getenv("PAMD_LQ_DEVICE") ? atoi(getenv("PAMD_LQ_DEVICE")) : 2};
 constexpr size_t kLqDeviceAutoPixels = (size_t)40 << 20;
 
 // The local quantiser driven from the device (k_lq_children / k_lq_select above).  In: the base clusters are nodes first_base ..
