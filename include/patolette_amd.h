@@ -204,6 +204,12 @@ int patolette_amd_set_kmeans_update(int mode);
  * decisions and results either way (the children's moments may differ in their last bit: DESIGN.md 4.2).  Process-wide; returns
  * the previous setting.  Environment: PAMD_LQ_DEVICE=0|1|2. */
 int patolette_amd_set_split_loop(int mode);
+/* Where the decisions of the global quantiser are taken (lib/src/quantize/global.c:189-298: prefix sums of the 512-bucket table,
+ * the bias termination test, the dynamic programme's backtrack, the bucket -> base cluster table, the base clusters' records):
+ * 1 (default) on the device, in one kernel between the histogram and the partition (no host turn; palettes of more than 12
+ * colours on one GPU, not verbose), 0 on the host.  Same arithmetic either way: same cuts, same clusters.  Returns the
+ * previous setting. */
+int patolette_amd_set_global_quantiser(int on_device);
 
 /* The KMeans subsample list (faiss rand_perm(N, seed 1234), Clustering.cpp:311-319: a pure function of the pixel count) is made
  * on a helper thread that starts at call entry and is joined when the KMeans stage begins.  1 (default): the list stays on the

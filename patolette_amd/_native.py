@@ -113,6 +113,7 @@ SYMBOLS = {
     "patolette_amd_quantize_clusters": (C.c_int, [dp, dp, C.c_size_t, C.c_size_t, dp, zp]),
     "patolette_amd_kmeans_refine": (C.c_int, [dp, dp, C.c_size_t, dp, C.c_size_t, C.c_int, C.c_size_t]),
     "patolette_amd_nn_map": (C.c_int, [dp, C.c_size_t, dp, C.c_size_t, zp]),
+    "patolette_amd_set_global_quantiser": (C.c_int, [C.c_int]),
     "patolette_amd_dither": (C.c_int, [dp, C.c_size_t, C.c_size_t, dp, C.c_size_t, zp]),
     "patolette_amd_dither_config": (None, [C.c_int, C.c_int]),
     "patolette_amd_dither_layout": (None, [C.c_int]),

@@ -1381,6 +1381,8 @@ static bool lq_replay(const LqRec *rec, int kbase, int first_base, size_t K, LqR
 // once: ~500 evaluations where the host's lock-step pruning makes ~320); with the global quantiser on the device too and the
 // host loop's own waiting rule in k_lq_select (same ~320 evaluations): 1.38 / 1.53, 5.28-5.46 / 5.66-5.87, 21.4-21.5 / 21.2-21.7.
 std::atomic<int> g_lq_device{getenv("PAMD_LQ_DEVICE") ? atoi(getenv("PAMD_LQ_DEVICE")) : 2};
+// patolette_amd_set_global_quantiser: 1 (default) the global quantiser's decisions on the device (k_gq_control), 0 the host's turn
+std::atomic<int> g_gq_device{getenv("PAMD_GQ_DEVICE") ? atoi(getenv("PAMD_GQ_DEVICE")) : 1};
 constexpr size_t kLqDeviceAutoPixels = (size_t)40 << 20;
 
 // The local quantiser driven from the device (k_lq_children / k_lq_select above).  In: the base clusters are nodes first_base ..
@@ -1611,8 +1613,7 @@ static int quantize_clusters_run(Engine &E, size_t N, size_t K, bool weighted, c
     // The quantiser's decisions (global.c:189-298) on the device, the partition behind them without the host looking (k_gq_control):
     // one GPU, palettes of more than twelve colours (so that base clusters < K whatever the image), not verbose.  PAMD_GQ_DEVICE=0:
     // the host's turn everywhere (A/B; what sliced images, small palettes and verbose calls always take)
-    static const bool gq_dev_env = !(getenv("PAMD_GQ_DEVICE") && atoi(getenv("PAMD_GQ_DEVICE")) == 0);
-    const bool gq_dev = gq_dev_env && !sh && !verbose && K > (size_t)kGqMaxK;
+    const bool gq_dev = g_gq_device.load(std::memory_order_relaxed) != 0 && !sh && !verbose && K > (size_t)kGqMaxK;
     int kbase = 0;
     std::vector<int> base_ids;
     if (gq_dev) {
@@ -3201,6 +3202,7 @@ int patolette_amd_dither(const double *colors, size_t width, size_t height, cons
 
 int patolette_amd_debug_fault(int which) { return g_debug_fault.exchange(which); }
 int patolette_amd_set_split_loop(int mode) { return g_lq_device.exchange(mode < 0 || mode > 2 ? 2 : mode); }
+int patolette_amd_set_global_quantiser(int on_device) { return g_gq_device.exchange(on_device ? 1 : 0); }
 void patolette_amd_dither_config(int segments, int warm) { dither_config(segments, warm); }
 void patolette_amd_dither_layout(int lanes) { dither_layout(lanes); }
 int patolette_amd_debug_dither_solo_cap(int cap) { return dither_solo_cap(cap); }

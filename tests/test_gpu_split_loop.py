@@ -85,3 +85,64 @@ def test_device_driven_loop_at_bench_sizes(gpu, native, ob, loop):
         assert ec == 0 and np.allclose(pal_d, pal_o, rtol=0, atol=1e-9) and np.array_equal(map_d, map_o)
         print("%dx%d: host loop %d rounds, %d evaluations, ms_lq %.3f; device loop %d rounds, %d evaluations, ms_lq %.3f" %
               (w, h, st_h["lq_rounds"], st_h["split_evals"], st_h["ms_lq"], st_d["lq_rounds"], st_d["split_evals"], st_d["ms_lq"]))
+
+
+@pytest.fixture
+def gq(gpu):
+    yield lambda on_device: gpu.patolette_amd_set_global_quantiser(on_device)
+    gpu.patolette_amd_set_global_quantiser(1)
+
+
+def _blobs(rng, n, nblobs, spread):
+    """`nblobs` tight clouds strung along one direction of the colour cube: the global quantiser (global.c:189-298) finds several cells
+    biased along the principal axis and goes on beyond two base clusters"""
+    direction = rng.random(3) + 0.2
+    direction /= np.linalg.norm(direction)
+    centres = 0.15 + 0.7 * np.sort(rng.random(nblobs))[:, None] * direction[None, :] / direction.max()
+    which = rng.integers(0, nblobs, size=n)
+    return np.clip(centres[which] + spread * rng.standard_normal((n, 3)), 0.0, 1.0)
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_global_quantiser_on_the_device_equals_the_hosts_turn(gpu, native, ob, loop, gq, seed):
+    """k_gq_control (prefix chains, bias termination test, the dynamic programme's full steps and backtrack, bucket -> base cluster
+    table, base clusters' records -- all on the device) against the host's turn over the same downloaded table, and against the oracle:
+    same number of base clusters and cuts (split trace header), same centres, palette and map.  Content with MORE THAN TWO base
+    clusters included (the DP's full steps run only then), both split loops, weighted and unweighted, several palette sizes."""
+    import patolette_amd as p
+    rng = np.random.default_rng(seed)
+    seen = []
+    for case in range(14):
+        h, w = int(rng.integers(40, 160)), int(rng.integers(40, 160))
+        n = h * w
+        kind = case % 4
+        if kind == 0:
+            colors = _blobs(rng, n, int(rng.integers(3, 9)), float(rng.choice([0.002, 0.01, 0.03])))
+        elif kind == 1:
+            colors = np.ascontiguousarray(content(rng, "scene", h, w))
+        elif kind == 2:
+            colors = _blobs(rng, n, int(rng.integers(2, 5)), 0.05)
+        else:
+            colors = np.ascontiguousarray(content(rng, str(rng.choice(["noise", "post", "gradient"])), h, w))
+        colors = np.ascontiguousarray(colors)
+        K = int(rng.choice([13, 16, 40, 256]))
+        cs = int(rng.integers(0, 3))
+        wts = (1.0 + 3.0 * rng.random(n)) if rng.integers(0, 2) else None
+        on_device_loop = int(rng.integers(0, 2))
+        loop(on_device_loop)
+        gq(0)
+        pal_h, map_h, tr_h, cen_h, st_h = _run(p, native, w, h, colors, K, cs, wts)
+        gq(1)
+        pal_d, map_d, tr_d, cen_d, st_d = _run(p, native, w, h, colors, K, cs, wts)
+        desc = (seed, case, w, h, kind, K, cs, wts is not None, on_device_loop, st_h["n_base_clusters"])
+        assert st_h["n_base_clusters"] == st_d["n_base_clusters"] and tr_h["n_base"] == tr_d["n_base"], desc
+        assert list(tr_h["gq_cuts"]) == list(tr_d["gq_cuts"]), desc
+        assert _same_decisions(tr_h, tr_d), desc
+        assert np.array_equal(cen_h, cen_d) and np.array_equal(pal_h, pal_d) and np.array_equal(map_h, map_d), desc
+        ec, pal_o, map_o = ob.patolette(w, h, ob.planar(colors), wts, K, dither=False, color_space=cs, kmeans_niter=0)
+        assert ec == 0, desc
+        if kind in (0, 1, 2) or np.allclose(pal_d, pal_o, rtol=0, atol=1e-9):
+            assert np.allclose(pal_d, pal_o, rtol=0, atol=1e-9) and np.array_equal(map_d, map_o), desc
+        seen.append(st_d["n_base_clusters"])
+    print("seed %d: base clusters per case %s" % (seed, seen))
+    assert max(seen) >= 4 and sum(1 for k in seen if k >= 3) >= 3, seen
