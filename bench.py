@@ -472,7 +472,7 @@ def small_image(L, native, reps=7):
         L.patolette_amd_free(dmap)
     return {"config": desc, "ms": round(1e3 * med, 3), "value": round(n / med / 1e6, 1), "unit": "Mpx/s", "reps": reps,
             "stages_ms": {k: round(v, 3) for k, v in st.items() if k.startswith("ms_") and v}, "lq_rounds": st["lq_rounds"],
-            "split_evals": st["split_evals"], "split_loop": "device-driven (the default below 12 Mpixel): one host synchronisation per image",
+            "split_evals": st["split_evals"], "split_loop": "device-driven (the default up to 40 Mpixel), global quantiser's decisions on the device: one host synchronisation per image before the map",
             "host_driven_split_loop": None if med_h is None else {"ms": round(1e3 * med_h, 3), "ms_lq": round(st_h["ms_lq"], 3),
                                                                     "lq_rounds": st_h["lq_rounds"], "split_evals": st_h["split_evals"]}}
 
@@ -589,7 +589,8 @@ def dither_content(L, native, side=4096, reps=3):
                 if i:
                     ms.append(st["ms_map"])
             out[name] = {"ms_map": round(sorted(ms)[len(ms) // 2], 3), "ns_per_px": round(1e6 * sorted(ms)[len(ms) // 2] / n, 4), "runs": st["dither_segments"],
-                         "repairs": st["dither_repairs"], "passes": st["dither_rounds"], "through_walks": st["dither_through"]}
+                         "repairs": st["dither_repairs"], "passes": st["dither_rounds"], "through_walks": st["dither_through"],
+                         "periodic_jumps": st["dither_jumps"], "solo_passes": st["dither_solo"]}
     finally:
         L.patolette_amd_free(img)
         L.patolette_amd_free(dmap)

@@ -2441,13 +2441,13 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
     E.src.reserve(3 * N);
     // Large images go up in pieces and what a piece completes is converted (on a second stream) while the next one is on the link:
     // the conversion (0.5 ms of a 4096^2 image's 7 ms upload) disappears behind the copy.  Its statistics are exact sums and keyed
-    // extrema, so the chunking changes no bit.  Not with derived weights (the saliency stage reads the whole sRGB image first).
+    // extrema, so the chunking changes no bit.  With derived weights too: the saliency stage reads the sRGB source, which stays where it is.
     const size_t chunk_min = getenv("PAMD_UPLOAD_CHUNK_MIN") ? (size_t)atoll(getenv("PAMD_UPLOAD_CHUNK_MIN")) : ((size_t)1 << 21);   // (read per call: tests lower it)
     const bool derive = !weights && tile_size > 0.0;
     const bool chunked = N >= chunk_min && !E.shard;
     bool converted = false;
     if (chunked) {
-        const bool overlap = !derive;
+        const bool overlap = true;
         // planar source: the first two planes go up whole (every copy call has a fixed cost: 24 pieces made the upload 0.44 ms
         // longer than one), the third in four pieces with the conversion of the pixels it completes behind each; row-major
         // source: four pieces of whole pixels
@@ -2459,7 +2459,7 @@ static void run_host(Engine &E, size_t width, size_t height, const double *data,
                 for (hipEvent_t *e : {&E.ev_up[0], &E.ev_up[1], &E.ev_join}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
             }
             cp = convert_plan(E, opt, N);
-            E.cvt.reserve((weights ? 4 : 3) * N);
+            E.cvt.reserve(((weights || derive) ? 4 : 3) * N);        // (the derived weights' plane: run_device must not move what is converted here)
             E.cstats.reserve(1);
             HIP_CHECK(hipEventRecord(E.ev_join, E.stream));          // whatever the engine's stream still holds comes first
             HIP_CHECK(hipStreamWaitEvent(E.stream2, E.ev_join, 0));
@@ -2541,14 +2541,14 @@ static void run_u8(Engine &E, size_t width, size_t height, const unsigned char *
         d_px = E.src8.p;
         // as run_host: a large image goes up in four pieces of whole pixels, each converted (second stream) while the next is on the link
         const size_t chunk_min = getenv("PAMD_UPLOAD_CHUNK_MIN") ? (size_t)atoll(getenv("PAMD_UPLOAD_CHUNK_MIN")) : ((size_t)1 << 21);
-        const bool derive = !weights && tile_size > 0.0;             // the saliency stage reads the whole sRGB image first
-        if (N >= chunk_min && !derive && !E.shard) {
+        const bool derive = !weights && tile_size > 0.0;             // the saliency stage reads the 8-bit image itself (it stays where it is)
+        if (N >= chunk_min && !E.shard) {
             if (!E.stream2) {
                 HIP_CHECK(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
                 for (hipEvent_t *e : {&E.ev_up[0], &E.ev_up[1], &E.ev_join}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
             }
             const ConvertPlan cp = convert_plan(E, opt, N);
-            E.cvt.reserve((weights ? 4 : 3) * N);
+            E.cvt.reserve(((weights || derive) ? 4 : 3) * N);        // (the derived weights' plane: run_device must not move what is converted here)
             E.cstats.reserve(1);
             HIP_CHECK(hipEventRecord(E.ev_join, E.stream));
             HIP_CHECK(hipStreamWaitEvent(E.stream2, E.ev_join, 0));

@@ -731,3 +731,29 @@ def test_large_weighted_image_end_to_end(gpu, ob, rows, cols, K, cs, kind):
     assert ok and ec == 0
     assert np.allclose(pal, pal_o, rtol=0, atol=1e-9)
     assert np.array_equal(pmap, pmap_o)
+
+
+@pytest.mark.parametrize("entry", ["f64", "u8"])
+def test_chunked_upload_with_derived_weights(gpu, monkeypatch, entry):
+    """With the saliency weights derived on the device (tile_size > 0, the binding's default) the image still goes up in pieces with the
+    conversion of each behind the next one's copy: the saliency stage reads the sRGB source, which the conversion leaves alone, and the
+    weights' plane is reserved up front.  Forced onto a small image: identical to the single-copy path, both entries."""
+    import patolette_amd as p
+    rng = np.random.default_rng(41)
+    h, w, K = 83, 97, 24
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+
+    def call():
+        if entry == "u8":
+            r = p.quantize_u8(img, K, dither=False, color_space=2, tile_size=32, kmeans_niter=2, kmeans_max_samples=65536)
+            assert r[0], r[5]
+            return r[1:5]
+        ok, pal, pmap, msg = p.quantize(w, h, img.reshape(-1, 3).astype(np.float64) / 255, K, dither=False, color_space=1, tile_size=32,
+                                        kmeans_niter=2, kmeans_max_samples=65536)
+        assert ok, msg
+        return pal, pmap
+    ref = call()
+    monkeypatch.setenv("PAMD_UPLOAD_CHUNK_MIN", "1000")
+    got = call()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
