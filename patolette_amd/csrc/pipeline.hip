@@ -718,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_gq_control(const double *__restrict__ 
             const int kk = k - 1;
             const double *Ep = E[(kk - 1) & 1];
             double *En = E[kk & 1];
-            for (int n = wv; n <= kBuckets; n += 16) {
+            for (int n = wv; n <= kBuckets; n += 16) {                   // (sixteen wavefronts: the launch is 1024 threads, launch_bounds above)
                 if (n < kk + 1) { if (lane == 0) En[n] = Ep[n]; continue; }
                 double e; int cut;
                 gq_dp_entry(c, Ep, kk, n, lane, e, cut);
