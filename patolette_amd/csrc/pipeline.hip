@@ -107,6 +107,15 @@ __global__ void k_put_nodes(NodeDev *table, const NodeIn *stage, const int *ids,
     node_reset_outputs(d);
     d.split = in.split; d.psplit = -1;
 }
+// one record, passed as a kernel argument: no staging copies (the root's record at the start of every call)
+__global__ void k_put_node1(NodeDev *table, const int id, const NodeIn in) {
+    NodeDev &d = table[id];
+    d.begin = in.begin; d.n = in.n; d.gn = in.gn; d.buf = in.buf; d.slot = in.slot; d.child0 = in.child0; d.nchild = in.nchild;
+    for (int j = 0; j < 3; j++) { d.axis[j] = in.axis[j]; d.mean[j] = in.mean[j]; }
+    d.sw = in.sw; d.klin = in.klin; d.kquad = in.kquad;
+    node_reset_outputs(d);
+    d.split = in.split; d.psplit = -1;
+}
 __global__ void k_get_nodes(const NodeDev *table, NodeOut *stage, const int *ids, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1173,6 +1182,11 @@ static void upload_ints(Engine &E, const std::vector<int> &v, DevBuf<int> &dst, 
 static void put_nodes(Engine &E, const std::vector<int> &ids, const std::vector<NodeIn> &recs) {
     const int n = (int)ids.size();
     if (!n) return;
+    if (n == 1) {
+        hipLaunchKernelGGL(k_put_node1, 1, 1, 0, E.stream, E.nodes.p, ids[0], recs[0]);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     E.stage_in.reserve(n); E.ids.reserve(n); E.h_stage_in.reserve(n); E.h_ids.reserve(n);
     std::memcpy(E.h_stage_in.p, recs.data(), n * sizeof(NodeIn));
     std::memcpy(E.h_ids.p, ids.data(), n * sizeof(int));
