@@ -46,9 +46,26 @@ __device__ __forceinline__ void rgb_to_lab(const double c[3], double lab[3]) {
     linear_to_lab(v, lab);
 }
 
+// State per pixel as one 16-byte record {img, D, U, L} (row-major): a visit reads and writes one record.
+constexpr size_t kMbdPad = 256;      // records of padding on both sides of the state (lanes read past row ends)
+
+// The scans work on a SKEWED copy of the state: record (r, c) lives at [group g][diagonal d][l], g = (r + 63) / 64,
+// l = (r + 63) % 64, d = c + l + 128, so the 64 records a strip touches in one step -- rows 64 s + l, columns t - l: one
+// anti-diagonal -- are 1 KB of consecutive memory instead of 64 different cache lines (the address unit, not HBM, bounded the
+// row-major scan: 110 ns per step).  The backward scan's strips are aligned to the bottom of the image, so one of its steps
+// covers at most two such runs.  Cells of the skewed array that correspond to no pixel are only ever read, their values
+// discarded.
+struct SkewGeom {
+    int dn;                          // diagonals per group: cols + 320 (columns -128 .. cols + 128 of every row of the group)
+    __host__ __device__ size_t idx(int r, int c) const {
+        const int rr = r + 63;
+        return ((size_t)(rr >> 6) * (size_t)dn + (size_t)(c + (rr & 63) + 128)) * 64 + (size_t)(rr & 63);
+    }
+};
+
 // channel mean (patolette.pyx:204), minimum-barrier initial state (:160-170) and CIELAB (:213)
 template <class SRC>
-__global__ __launch_bounds__(256) void k_sal_prepare(SRC src, size_t n, int rows, int cols, float4 *__restrict__ st,
+__global__ __launch_bounds__(256) void k_sal_prepare(SRC src, size_t n, int rows, int cols, float4 *__restrict__ sk, const SkewGeom geo,
                                                      double *__restrict__ lab) {
     constexpr bool kLut = std::is_same<SRC, SrcU8>::value;
     __shared__ double glut[kLut ? 256 : 1];                // companding of the 256 possible 8-bit values
@@ -63,7 +80,7 @@ __global__ __launch_bounds__(256) void k_sal_prepare(SRC src, size_t n, int rows
         const float m = (float)(((c[0] + c[1]) + c[2]) / 3.0);
         const int r = (int)(i / (size_t)cols), q = (int)(i - (size_t)r * cols);
         const bool frame = r == 0 || q == 0 || r == rows - 1 || q == cols - 1;
-        st[i] = make_float4(m, frame ? 0.0f : INFINITY, m, m);      // {img, D, U, L}
+        sk[geo.idx(r, q)] = make_float4(m, frame ? 0.0f : INFINITY, m, m);      // {img, D, U, L}, straight into the scans' skewed layout
         if constexpr (kLut) {
             unsigned r8, g8, b8;
             src.load_bytes(i, r8, g8, b8);
@@ -220,14 +237,14 @@ __global__ void k_sal_fold(SalDev *d, int first, int count, int as_f32) {
 }
 
 // pass A: maxima of the four contrasts (patolette.pyx:272-275) and of the barrier distance (:289)
-__global__ __launch_bounds__(256) void k_sal_pass_a(const double *__restrict__ lab, const float4 *__restrict__ st, size_t n, SalDev *d) {
+__global__ __launch_bounds__(256) void k_sal_pass_a(const double *__restrict__ lab, const float *__restrict__ D, size_t n, SalDev *d) {
     double mx[5] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double c[3] = {lab[i], lab[n + i], lab[2 * n + i]};
 #pragma unroll
         for (int r = 0; r < 4; r++) mx[r] = fmax(mx[r], mahalanobis(c, d->mean[r], d->vi[r]));
-        mx[4] = fmax(mx[4], (double)st[i].y);
+        mx[4] = fmax(mx[4], (double)D[i]);
     }
     const int which[5] = {0, 1, 2, 3, 4};
     block_max_publish<5>(mx, which, d);
@@ -254,13 +271,13 @@ __global__ __launch_bounds__(256) void k_sal_pass_b(const double *__restrict__ l
 }
 
 // pass C: sal / sal_max (f32 / f32) + u_final / u_max_final (:291)
-__global__ __launch_bounds__(256) void k_sal_pass_c(const float4 *__restrict__ st, size_t n, SalDev *d, double *__restrict__ s) {
+__global__ __launch_bounds__(256) void k_sal_pass_c(const float *__restrict__ D, size_t n, SalDev *d, double *__restrict__ s) {
     double mx[1] = {-INFINITY};
     const float dmax = (float)d->mx[4];
     const double ufmax = d->mx[5];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double v = (double)(st[i].y / dmax) + s[i] / ufmax;
+        const double v = (double)(D[i] / dmax) + s[i] / ufmax;
         s[i] = v;
         mx[0] = fmax(mx[0], v);
     }
@@ -300,23 +317,6 @@ __global__ __launch_bounds__(256) void k_sal_pass_e(size_t n, double npx, double
 // ---------------------------------------------------------------------------------------------------
 // minimum-barrier raster scan (patolette.pyx:54-152)
 // ---------------------------------------------------------------------------------------------------
-// State per pixel as one 16-byte record {img, D, U, L} (row-major): a visit reads and writes one record.
-constexpr size_t kMbdPad = 256;      // records of padding on both sides of the state (lanes read past row ends)
-
-// The scans work on a SKEWED copy of the state: record (r, c) lives at [group g][diagonal d][l], g = (r + 63) / 64,
-// l = (r + 63) % 64, d = c + l + 128, so the 64 records a strip touches in one step -- rows 64 s + l, columns t - l: one
-// anti-diagonal -- are 1 KB of consecutive memory instead of 64 different cache lines (the address unit, not HBM, bounded the
-// row-major scan: 110 ns per step).  The backward scan's strips are aligned to the bottom of the image, so one of its steps
-// covers at most two such runs.  Cells of the skewed array that correspond to no pixel are only ever read, their values
-// discarded.
-struct SkewGeom {
-    int dn;                          // diagonals per group: cols + 320 (columns -128 .. cols + 128 of every row of the group)
-    __host__ __device__ size_t idx(int r, int c) const {
-        const int rr = r + 63;
-        return ((size_t)(rr >> 6) * (size_t)dn + (size_t)(c + (rr & 63) + 128)) * 64 + (size_t)(rr & 63);
-    }
-};
-
 struct MbdArgs {
     float4 *st;                      // the skewed state (SkewGeom)
     SkewGeom geo;
@@ -500,11 +500,6 @@ __global__ __launch_bounds__(256) void k_mbd_init(const float *__restrict__ img,
     }
 }
 
-__global__ __launch_bounds__(256) void k_mbd_extract(const float4 *__restrict__ st, size_t n, float *__restrict__ D) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) D[i] = st[i].y;
-}
-
 // row-major state -> skewed copy: one thread per skewed cell (coalesced writes; the reads are one line per lane)
 __global__ __launch_bounds__(256) void k_mbd_skew(const float4 *__restrict__ st, int rows, int cols, SkewGeom geo, int groups, float4 *__restrict__ sk) {
     const size_t cells = (size_t)groups * geo.dn * 64, stride = (size_t)gridDim.x * blockDim.x;
@@ -516,27 +511,34 @@ __global__ __launch_bounds__(256) void k_mbd_skew(const float4 *__restrict__ st,
         if (r >= 0 && r < rows && c >= 0 && c < cols) sk[i] = st[(size_t)r * cols + c];
     }
 }
-// and back: one thread per pixel (coalesced writes)
-__global__ __launch_bounds__(256) void k_mbd_unskew(const float4 *__restrict__ sk, size_t n, int cols, SkewGeom geo, float4 *__restrict__ st) {
+// and back: one thread per pixel (coalesced writes), the barrier distance alone -- nothing else of the state is read after the scans
+__global__ __launch_bounds__(256) void k_mbd_unskew(const float4 *__restrict__ sk, size_t n, int cols, SkewGeom geo, float *__restrict__ D) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int r = (int)(i / (size_t)cols), c = (int)(i - (size_t)r * cols);
-        st[i] = sk[geo.idx(r, c)];
+        D[i] = reinterpret_cast<const float *>(sk + geo.idx(r, c))[1];
     }
 }
 
 // pass p of mbd(img, iters) is the forward scan when p is odd, the inverse scan when p is even (patolette.pyx:180-199)
-static void run_mbd_scans(SalWork &w, int rows, int cols, int iters, hipStream_t s) {
+static SkewGeom mbd_geometry(SalWork &w, int rows, int cols) {
+    const SkewGeom geo{cols + 320};
+    const int groups = ((rows + 126) >> 6) + 1;              // rows -63 .. rows + 62 (the lanes of the last strips run past the image)
+    w.skew.reserve((size_t)groups * geo.dn * 64 + 64);
+    return geo;
+}
+// st_rowmajor: the state in row-major order to start from (mbd_device), or nullptr when w.skew holds it already (k_sal_prepare);
+// d_out: the barrier distance, row-major
+static void run_mbd_scans(SalWork &w, int rows, int cols, int iters, hipStream_t s, const float4 *st_rowmajor, float *d_out) {
     const int strips_f = (int)ceil_div((size_t)rows - 2, 64), strips_i = (int)ceil_div((size_t)rows - 3, 64);
     w.progress.reserve((size_t)strips_f + 1);                // [strips] progress + [1] stall flag
     static const int hs = getenv("PAMD_MBD_HS") ? std::max(1, atoi(getenv("PAMD_MBD_HS"))) : 1;
-    const SkewGeom geo{cols + 320};
-    const int groups = ((rows + 126) >> 6) + 1;              // rows -63 .. rows + 62 (the lanes of the last strips run past the image)
+    const SkewGeom geo = mbd_geometry(w, rows, cols);
+    const int groups = ((rows + 126) >> 6) + 1;
     const size_t cells = (size_t)groups * geo.dn * 64;
-    w.skew.reserve(cells + 64);
-    {
+    if (st_rowmajor) {
         KTIME("k_mbd_skew", s, 32.0 * rows * cols);
-        hipLaunchKernelGGL(k_mbd_skew, stream_grid(cells), 256, 0, s, w.st.p + kMbdPad, rows, cols, geo, groups, w.skew.p);
+        hipLaunchKernelGGL(k_mbd_skew, stream_grid(cells), 256, 0, s, st_rowmajor, rows, cols, geo, groups, w.skew.p);
     }
     MbdArgs ma{w.skew.p, geo, rows, cols, w.progress.p, w.progress.p + strips_f, hs};
     w.d_stall = w.progress.p + strips_f;
@@ -548,8 +550,8 @@ static void run_mbd_scans(SalWork &w, int rows, int cols, int iters, hipStream_t
         else hipLaunchKernelGGL(k_mbd_scan<-1>, strips_i, 64, 0, s, ma);
     }
     {
-        KTIME("k_mbd_skew", s, 32.0 * rows * cols);
-        hipLaunchKernelGGL(k_mbd_unskew, stream_grid((size_t)rows * cols), 256, 0, s, w.skew.p, (size_t)rows * cols, cols, geo, w.st.p + kMbdPad);
+        KTIME("k_mbd_skew", s, 8.0 * rows * cols);
+        hipLaunchKernelGGL(k_mbd_unskew, stream_grid((size_t)rows * cols), 256, 0, s, w.skew.p, (size_t)rows * cols, cols, geo, d_out);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -560,8 +562,7 @@ int mbd_device(SalWork &w, const float *h_img, size_t rows, size_t cols, int ite
     w.st.reserve(n + 2 * kMbdPad); w.tmp.reserve(n);
     HIP_CHECK(hipMemcpyAsync(w.tmp.p, h_img, n * sizeof(float), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_mbd_init, stream_grid(n), 256, 0, s, w.tmp.p, n, (int)rows, (int)cols, w.st.p + kMbdPad);
-    run_mbd_scans(w, (int)rows, (int)cols, iters, s);
-    hipLaunchKernelGGL(k_mbd_extract, stream_grid(n), 256, 0, s, w.st.p + kMbdPad, n, w.tmp.p);
+    run_mbd_scans(w, (int)rows, (int)cols, iters, s, w.st.p + kMbdPad, w.tmp.p);     // (the input image in w.tmp has been consumed by k_mbd_init)
     HIP_CHECK(hipMemcpyAsync(h_out, w.tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
     unsigned int stalled = 0;
     HIP_CHECK(hipMemcpyAsync(&stalled, w.d_stall, sizeof stalled, hipMemcpyDeviceToHost, s));
@@ -578,8 +579,9 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     const int bt = (int)std::floor(0.1 * std::sqrt((double)(height * width)));
     if (rows <= 3 || cols <= 3 || bt < 1 || rows < bt + 1 || cols < bt + 1) return kSalBadShape;
 
-    w.st.reserve(n + 2 * kMbdPad);
+    w.tmp.reserve(n);                                         // the barrier distance after the scans
     w.lab.reserve(3 * n); w.s.reserve(n);
+    const SkewGeom geo = mbd_geometry(w, rows, cols);        // the barrier state is made in the scans' skewed layout at once (k_sal_prepare)
     w.dev.reserve(1);
     w.host.reserve(1);
     const int g = stream_grid(n);
@@ -587,9 +589,9 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     hipLaunchKernelGGL(k_sal_init, 1, 256, 0, s, w.dev.p);
     {
         KTIME("k_sal_prepare", s, (d_u8 ? (double)channels : 24.0) * n + 40.0 * n);
-        if (d_u8) hipLaunchKernelGGL((k_sal_prepare<SrcU8>), g, 256, 0, s, SrcU8{d_u8, channels}, n, rows, cols, w.st.p + kMbdPad, w.lab.p);
-        else if (channels < 0) hipLaunchKernelGGL((k_sal_prepare<SrcF64Rows>), g, 256, 0, s, SrcF64Rows{d_f64}, n, rows, cols, w.st.p + kMbdPad, w.lab.p);
-        else hipLaunchKernelGGL((k_sal_prepare<SrcF64>), g, 256, 0, s, SrcF64{d_f64, n}, n, rows, cols, w.st.p + kMbdPad, w.lab.p);
+        if (d_u8) hipLaunchKernelGGL((k_sal_prepare<SrcU8>), g, 256, 0, s, SrcU8{d_u8, channels}, n, rows, cols, w.skew.p, geo, w.lab.p);
+        else if (channels < 0) hipLaunchKernelGGL((k_sal_prepare<SrcF64Rows>), g, 256, 0, s, SrcF64Rows{d_f64}, n, rows, cols, w.skew.p, geo, w.lab.p);
+        else hipLaunchKernelGGL((k_sal_prepare<SrcF64>), g, 256, 0, s, SrcF64{d_f64, n}, n, rows, cols, w.skew.p, geo, w.lab.p);
     }
     // border bands in the reference's order and naming (patolette.pyx:215-219): "left" = first bt rows, "right" = bt rows
     // ending one short of the last, "top" = first bt columns, "bottom" = bt columns ending one short of the last
@@ -613,10 +615,10 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     }
     hipLaunchKernelGGL(k_sal_invcov, 1, 64, 0, s, w.dev.p, bands);
 
-    run_mbd_scans(w, rows, cols, 3, s);                      // mbd(img_mean, 3), patolette.pyx:205
+    run_mbd_scans(w, rows, cols, 3, s, nullptr, w.tmp.p);    // mbd(img_mean, 3), patolette.pyx:205
     {
-        KTIME("k_sal_pass_a", s, 40.0 * n);
-        hipLaunchKernelGGL(k_sal_pass_a, g, 256, 0, s, w.lab.p, w.st.p + kMbdPad, n, w.dev.p);
+        KTIME("k_sal_pass_a", s, 28.0 * n);
+        hipLaunchKernelGGL(k_sal_pass_a, g, 256, 0, s, w.lab.p, (const float *)w.tmp.p, n, w.dev.p);
     }
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 0, 5, 1);
     {
@@ -625,8 +627,8 @@ int saliency_weights(SalWork &w, const double *d_f64, const unsigned char *d_u8,
     }
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 5, 1, 1);
     {
-        KTIME("k_sal_pass_c", s, 32.0 * n);
-        hipLaunchKernelGGL(k_sal_pass_c, g, 256, 0, s, w.st.p + kMbdPad, n, w.dev.p, w.s.p);
+        KTIME("k_sal_pass_c", s, 20.0 * n);
+        hipLaunchKernelGGL(k_sal_pass_c, g, 256, 0, s, (const float *)w.tmp.p, n, w.dev.p, w.s.p);
     }
     hipLaunchKernelGGL(k_sal_fold, 1, 64, 0, s, w.dev.p, 6, 1, 0);
     const double w2 = (double)rows / 2.0, h2 = (double)cols / 2.0;
