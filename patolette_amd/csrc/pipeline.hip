@@ -1441,10 +1441,17 @@ static int lq_device_loop(Engine &E, size_t N, size_t K, bool weighted, bool inv
     auto round = [&]() {
         if (enq >= kLqMaxRounds) throw HipError("patolette_amd: split loop exceeded its round limit");
         const double *px_src = &head->round_px[enq], *nr_src = &head->round_nr[enq];
-        hipLaunchKernelGGL(k_round_setup_dyn, 1024, 256, 0, s, E.nodes.p, (const LqCtl *)c, E.tilesA.p, E.tilesP.p, E.hist.p, E.hsize.p, E.hcount.p, lqs);
-        HIP_CHECK(hipGetLastError());
         const bool rev = snake && (enq % 2 == 1);                  // the sweeps alternate their direction (see the host loop)
-        launch_minmax(qlq, E.tilesA.p, ntA_ub, 0, E.nodes.p, s, rev, dyn, px_src);
+        // the round's set-up (tile lists, cleared bucket tables) rides on its first sweep; PAMD_LQ_SETUP_KERNEL=1: a launch of its own (A/B)
+        static const bool setup_kernel = getenv("PAMD_LQ_SETUP_KERNEL") && atoi(getenv("PAMD_LQ_SETUP_KERNEL")) != 0;
+        if (setup_kernel) {
+            hipLaunchKernelGGL(k_round_setup_dyn, 1024, 256, 0, s, E.nodes.p, (const LqCtl *)c, E.tilesA.p, E.tilesP.p, E.hist.p, E.hsize.p, E.hcount.p, lqs);
+            HIP_CHECK(hipGetLastError());
+            launch_minmax(qlq, E.tilesA.p, ntA_ub, 0, E.nodes.p, s, rev, dyn, px_src);
+        } else {
+            const RoundLists rl{c->round_ids, c->tA0, c->tP0, E.tilesA.p, E.tilesP.p, E.hist.p, lqs, E.hsize.p, E.hcount.p};
+            launch_minmax(qlq, E.tilesA.p, ntA_ub, 0, E.nodes.p, s, rev, dyn, px_src, &rl);
+        }
         launch_hist(qlq, false, E.tilesA.p, ntA_ub, 0, E.nodes.p, E.hist.p, E.hsize.p, E.hcount.p, s, snake && !rev, false, dyn, px_src);
         launch_cut(weighted, E.nodes.p, d_round, kLqRoundCap, E.hist.p, E.hsize.p, E.hcount.p, E.lut.p, s, dyn, nr_src);
         launch_partition(qlq, E.tilesP.p, ntP_ub, 0, d_round, d_tP0, kLqRoundCap, E.nodes.p, E.lut.p, E.tilecnt.p, E.tileoff.p, true, s, inv_sums, rev, dyn, px_src);

@@ -90,6 +90,15 @@ struct RoundDyn {
     int pad;
 };
 
+// Device-driven rounds: what the round's first sweep (k_minmax) needs to set the round up itself -- the tile lists of both tilings
+// and zeroed bucket tables -- instead of a launch of its own in front of it (pipeline.hip k_round_setup_dyn did this)
+struct RoundLists {
+    const int *round_ids, *tA0, *tP0;      // the control kernel's lists (LqCtl)
+    struct Tile *tilesA, *tilesP;
+    double *hist; size_t lqs;              // doubles per node in `hist`
+    unsigned long long *hsize; unsigned int *hcount;
+};
+
 struct Tile {
     unsigned long long start;          // absolute pixel slot
     unsigned int count;
@@ -120,8 +129,9 @@ void launch_gq_dp(const double *d_hist, const unsigned int *d_hcount, int kmax, 
 // so that each starts on the lines the previous one touched last
 // dyn (every launcher below): the launch covers `ntiles` / `nround` as UPPER BOUNDS and the kernels take the real sizes from *dyn;
 // px_src then points at the round's pixel count (a double the control kernel wrote to pinned host memory) for the kernel timer
+// lists (with dyn): the kernel builds the round's tile lists and clears its bucket tables itself (d_tiles is ignored)
 void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end = false,
-                   const RoundDyn *dyn = nullptr, const double *px_src = nullptr);
+                   const RoundDyn *dyn = nullptr, const double *px_src = nullptr, const RoundLists *lists = nullptr);
 // fixed_point (global quantiser only): block-local sums as 64-bit integers (k_hist_fix); a property of the IMAGE (its total
 // pixel count), so that every GPU sharing an image takes the same path
 void launch_hist(const QuantBuffers &qb, bool gq, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes,

@@ -102,13 +102,45 @@ __device__ __forceinline__ double project(double x, double y, double z, const do
     return (x * a0 + y * a1) + z * a2;
 }
 
+__device__ __forceinline__ int tile_node(const int *t0, int nr, int t) {   // largest r with t0[r] <= t
+    int lo = 0, hi = nr;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t0[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+template <bool LISTS>
 __global__ __launch_bounds__(256) void k_minmax(QuantBuffers qb, const Tile *__restrict__ tiles, NodeDev *nodes, const int from_end,
-                                                const RoundDyn *__restrict__ dyn) {
+                                                const RoundDyn *__restrict__ dyn, const RoundLists L) {
     // tiles are taken from the END: this sweep follows the partition kernel, whose most recently written lines are the last
     // tiles' (what is still in flight towards HBM is read last; measured on a replica: 80 -> 73 us behind a copy of 403 MB)
     const unsigned nt = dyn ? (unsigned)dyn->ntA : gridDim.x;   // dyn: the launch is an upper bound, the control kernel knows the extent
     if (blockIdx.x >= nt) return;
-    const Tile t = tiles[from_end ? nt - 1u - blockIdx.x : blockIdx.x];
+    const unsigned tix = from_end ? nt - 1u - blockIdx.x : blockIdx.x;
+    Tile t;
+    if constexpr (LISTS) {
+        // a device-driven round: this sweep is the round's first kernel and sets the round up as it goes -- block b makes tile b of
+        // this tiling (for the sweeps behind it too), its share of the partition's tiles and of the cleared bucket tables.  (The
+        // round's nodes need no reset: a node's outputs are cleared when k_cut / k_gq_control / k_put_nodes make it, and nothing
+        // touches them until its own round.)
+        const int nr = dyn->nr, ntP = dyn->ntP;
+        {
+            const int r = tile_node(L.tA0, nr, (int)tix);
+            const int id = L.round_ids[r];
+            const unsigned long long o = (unsigned long long)((int)tix - L.tA0[r]) * kTileA, n = nodes[id].n;
+            t = Tile{nodes[id].begin + o, (unsigned)(n - o < (unsigned long long)kTileA ? n - o : kTileA), (unsigned)id};
+            if (threadIdx.x == 0) L.tilesA[tix] = t;
+        }
+        for (int tp = (int)blockIdx.x + (int)threadIdx.x * (int)nt; tp < ntP; tp += (int)nt * 256) {
+            const int r = tile_node(L.tP0, nr, tp);
+            const int id = L.round_ids[r];
+            const unsigned long long o = (unsigned long long)(tp - L.tP0[r]) * kTileP, n = nodes[id].n;
+            L.tilesP[tp] = Tile{nodes[id].begin + o, (unsigned)(n - o < (unsigned long long)kTileP ? n - o : kTileP), (unsigned)id};
+        }
+        const size_t nh = L.lqs * (size_t)nr, nb = (size_t)nr * kBuckets;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (size_t)nt * 256) L.hist[i] = 0.0;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (size_t)nt * 256) { L.hsize[i] = 0ULL; L.hcount[i] = 0u; }
+    } else {
+        t = tiles[tix];
+    }
     NodeDev &nd = nodes[t.node];
     const double a0 = nd.axis[0], a1 = nd.axis[1], a2 = nd.axis[2];
     const double *px = qb.buf[nd.buf], *py = px + qb.N, *pz = py + qb.N;
@@ -1120,10 +1152,11 @@ void launch_sum3(const double *planar, size_t N, BinK k, double *d_out6, hipStre
 }
 
 void launch_minmax(const QuantBuffers &qb, const Tile *d_tiles, int ntiles, size_t px, NodeDev *d_nodes, hipStream_t s, bool from_end,
-                   const RoundDyn *dyn, const double *px_src) {
+                   const RoundDyn *dyn, const double *px_src, const RoundLists *lists) {
     if (!ntiles) return;
     KTIME_DYN("k_minmax", s, 24.0, px, px_src);
-    hipLaunchKernelGGL(k_minmax, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0, dyn);
+    if (dyn && lists) hipLaunchKernelGGL(k_minmax<true>, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0, dyn, *lists);
+    else hipLaunchKernelGGL(k_minmax<false>, ntiles, 256, 0, s, qb, d_tiles, d_nodes, from_end ? 1 : 0, dyn, RoundLists{});
     HIP_CHECK(hipGetLastError());
 }
 
